@@ -1,0 +1,29 @@
+# Builds libsccd_hip.so (gfx950 only) and the CPU oracle.  hipcc cross-compiles without a GPU.
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+CSRC    := scalable-ccd_amd/csrc
+OUT     := scalable-ccd_amd/sccd/libsccd_hip.so
+# -ffp-contract=off: Tight-Inclusion parity needs every product/sum rounded as written; the
+# only FMAs are explicit __builtin_fma calls (SCCD_OPT_ARITH = 1).
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
+            -Wall -Wextra -Wno-unused-parameter -Wno-unused-function -Wno-missing-field-initializers
+SRCS    := $(CSRC)/api.hip $(CSRC)/boxes.hip $(CSRC)/sort.hip $(CSRC)/sweep.hip $(CSRC)/narrow.hip
+OBJS    := $(SRCS:.hip=.o)
+HDRS    := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inc) include/sccd.h
+
+all: $(OUT) oracle
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OUT): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -s -C oracle
+
+clean:
+	rm -f $(OBJS) $(OUT)
+	$(MAKE) -s -C oracle clean
+
+.PHONY: all oracle clean

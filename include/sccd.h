@@ -1,0 +1,201 @@
+/*
+ * sccd.h -- C ABI of libsccd_hip.so: the MI355X (gfx950) implementation of the Scalable-CCD
+ * hot path (STQ broad phase + Tight-Inclusion narrow phase).
+ *
+ * The reference (Continuous-Collision-Detection/Scalable-CCD) has no FFI layer; its boundary
+ * is the C++ host API under src/scalable_ccd/cuda/.  Each entry point below names the
+ * reference interface it replaces (file:line relative to the reference root).  The C++ header
+ * include/scalable_ccd/hip/ccd.hpp re-creates those C++ signatures on top of this ABI.
+ *
+ * Conventions
+ *  - every call returns SCCD_OK (0) or a negative error code; sccd_last_error() gives the text.
+ *  - inputs are borrowed; host matrices are COLUMN-MAJOR (Eigen default), V: n x 3 double,
+ *    E: m x 2 int32, F: k x 3 int32 -- exactly the storage of the Eigen arguments of ccd().
+ *  - Scalar = double (reference default SCALABLE_CCD_USE_DOUBLE=ON, CMakeLists.txt:69).
+ *  - calls are blocking on the context's stream unless stated; a context is not thread-safe,
+ *    different contexts are independent (no global state, unlike the reference's
+ *    __constant__ CONFIG in root_finder.cu:19).
+ *  - there is NO CPU fallback: without a HIP device sccd_create fails with SCCD_E_NO_DEVICE.
+ */
+#ifndef SCCD_H
+#define SCCD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCCD_OK 0
+#define SCCD_E_INVALID (-1)    /* bad argument (reference: assert / std::runtime_error)          */
+#define SCCD_E_NO_DEVICE (-2)  /* no HIP device / device out of range                           */
+#define SCCD_E_HIP (-3)        /* HIP runtime error (reference: gpuErrchk -> std::runtime_error) */
+#define SCCD_E_NOMEM (-4)      /* out of device memory (memory_handler.cpp:66-68)               */
+#define SCCD_E_NOT_BUILT (-5)  /* detect_overlaps before build (broad_phase.cu:123-126)         */
+#define SCCD_E_OVERFLOW (-6)   /* internal work-queue capacity exhausted after retries          */
+
+typedef struct sccd_ctx sccd_ctx;
+typedef struct sccd_mesh sccd_mesh;
+typedef struct sccd_boxes sccd_boxes;
+typedef struct sccd_broad_phase sccd_broad_phase;
+
+/* 64-byte box, bit-compatible with scalable_ccd::cuda::AABB
+ * (src/scalable_ccd/cuda/broad_phase/aabb.cuh:82-92). */
+typedef struct sccd_aabb {
+    double min[3];
+    double max[3];
+    int32_t vertex_ids[3];
+    int32_t element_id;
+} sccd_aabb;
+
+/* (aid, bid, toi) of SCALABLE_CCD_TOI_PER_QUERY builds (narrow_phase.cu:84-103). */
+typedef struct sccd_collision {
+    int32_t aid;
+    int32_t bid;
+    double toi;
+} sccd_collision;
+
+/* ------------------------------------------------------------------------------------------ */
+/* context                                                                                    */
+
+int sccd_create(int device, sccd_ctx** out);
+void sccd_destroy(sccd_ctx* ctx);
+const char* sccd_last_error(const sccd_ctx* ctx);
+const char* sccd_version(void);
+/* hipStream_t to launch on (e.g. torch's current stream); NULL = the context's own stream. */
+int sccd_set_stream(sccd_ctx* ctx, void* hip_stream);
+int sccd_synchronize(sccd_ctx* ctx);
+
+/* options (sccd_set_option) */
+#define SCCD_OPT_ARITH 1            /* 0 strict (default): *, +/- rounded separately; 1: a*b+c fused (nvcc -fmad form) */
+#define SCCD_OPT_NARROW_ALGO 2      /* 0 per-wave work queues (default); 1 level-synchronous BFS (root_finder.cu:431-447) */
+#define SCCD_OPT_SWEEP_ALGO 3       /* 0 filter/queue/confirm STQ (default); 1 plain sweep-and-prune (sweep.cu:48-99)    */
+#define SCCD_OPT_SORT_AXIS 4        /* 0/1/2 = x/y/z (reference device path: x, aabb.cu:85-86); -1 = arg-max variance   */
+#define SCCD_OPT_SHARD_RANK 5       /* multi-GPU: this rank's index ...                                                  */
+#define SCCD_OPT_SHARD_COUNT 6      /* ... of this many ranks; the sweep emits only this rank's share of the candidates   */
+#define SCCD_OPT_OVERLAP_CAPACITY 7 /* initial overlap buffer capacity in pairs (0 = automatic)                           */
+#define SCCD_OPT_PROFILE 8          /* 1: record hipEvents around every kernel class (sccd_get_profile)                   */
+#define SCCD_OPT_MAX_OVERLAP_CUTOFF 9 /* boxes swept per detect_overlaps_partial call (0 = all; memory_handler.hpp:9)      */
+int sccd_set_option(sccd_ctx* ctx, int option, int64_t value);
+int64_t sccd_get_option(const sccd_ctx* ctx, int option);
+
+/* ------------------------------------------------------------------------------------------ */
+/* mesh  == the four DeviceMatrix objects of ccd() (src/scalable_ccd/cuda/ccd.cu:103-106)     */
+
+/* src_on_device: 0 = host pointers, 1 = device pointers (same column-major layout). */
+int sccd_mesh_create(sccd_ctx* ctx, const double* V0, const double* V1, int nV, const int32_t* E,
+                     int nE, const int32_t* F, int nF, int src_on_device, sccd_mesh** out);
+int sccd_mesh_update_vertices(sccd_mesh* mesh, const double* V0, const double* V1, int src_on_device);
+void sccd_mesh_destroy(sccd_mesh* mesh);
+
+/* ------------------------------------------------------------------------------------------ */
+/* boxes                                                                                      */
+
+/* build_vertex_boxes(V0, V1, boxes, inflation_radius): aabb.cuh:166-170 / aabb.cu:146-184.
+ * Host in, host out; computed on the device. */
+int sccd_build_vertex_boxes(sccd_ctx* ctx, const double* V0, const double* V1, int nV,
+                            double inflation_radius, sccd_aabb* out);
+/* build_edge_boxes / build_face_boxes: aabb.cuh:176-188 / aabb.cu:186-229. */
+int sccd_build_edge_boxes(sccd_ctx* ctx, const sccd_aabb* vertex_boxes, int nV, const int32_t* E,
+                          int nE, sccd_aabb* out);
+int sccd_build_face_boxes(sccd_ctx* ctx, const sccd_aabb* vertex_boxes, int nV, const int32_t* F,
+                          int nF, sccd_aabb* out);
+
+/* DeviceAABBs(const std::vector<AABB>&): aabb.cuh:122-150 / aabb.cu:75-111 -- upload, split
+ * into major-axis keys + payload, sort by min on the sort axis. */
+int sccd_boxes_create(sccd_ctx* ctx, const sccd_aabb* boxes, int n, int src_on_device,
+                      sccd_boxes** out);
+/* Fused device path used by ccd(): vertex/edge/face boxes straight from the mesh, sorted
+ * (ccd.cu:112-121 without the host round trip).  Any of the three outputs may be NULL. */
+int sccd_boxes_from_mesh(sccd_ctx* ctx, const sccd_mesh* mesh, double inflation_radius,
+                         sccd_boxes** vertex_boxes, sccd_boxes** edge_boxes,
+                         sccd_boxes** face_boxes);
+int sccd_boxes_size(const sccd_boxes* boxes);
+/* copy the sorted boxes back (sorted order along the sort axis) */
+int sccd_boxes_download(const sccd_boxes* boxes, sccd_aabb* out);
+void sccd_boxes_destroy(sccd_boxes* boxes);
+
+/* ------------------------------------------------------------------------------------------ */
+/* broad phase == class BroadPhase (src/scalable_ccd/cuda/broad_phase/broad_phase.cuh:15-92)  */
+
+int sccd_broad_phase_create(sccd_ctx* ctx, sccd_broad_phase** out);
+void sccd_broad_phase_destroy(sccd_broad_phase* bp);
+/* build(boxes) (B == NULL) and build(boxesA, boxesB): broad_phase.cu:29-101.  The boxes are
+ * shared, not consumed (the reference clears them on the next build -- a quirk not kept). */
+int sccd_broad_phase_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes* B);
+/* detect_overlaps_partial(): broad_phase.cu:121-224.  *d_pairs is a DEVICE pointer to n rows
+ * of int32[2], valid until the next call on bp.  One list: (min id, max id); two lists:
+ * (A id, B id).  Order unspecified. */
+int sccd_broad_phase_detect_overlaps_partial(sccd_broad_phase* bp, const int32_t** d_pairs,
+                                             int64_t* n);
+/* detect_overlaps(): broad_phase.cu:226-252.  *pairs is malloc'ed host memory (sccd_free). */
+int sccd_broad_phase_detect_overlaps(sccd_broad_phase* bp, int32_t** pairs, int64_t* n);
+int sccd_broad_phase_is_complete(const sccd_broad_phase* bp); /* broad_phase.cuh:57 */
+int64_t sccd_broad_phase_num_boxes(const sccd_broad_phase* bp); /* broad_phase.cuh:63 */
+/* number of sort-axis candidate tests of the last detect call (work metric) */
+int64_t sccd_broad_phase_candidates(const sccd_broad_phase* bp);
+void sccd_free(void* host_ptr);
+
+/* ------------------------------------------------------------------------------------------ */
+/* narrow phase == narrow_phase<is_vf>() (src/scalable_ccd/cuda/narrow_phase/narrow_phase.cuh:30-46) */
+
+/* pairs: n rows int32[2]; is_vf: (vertex, face) else (edge, edge).  *toi is in/out and must be
+ * >= 0 (narrow_phase.cu:126).  collisions (may be NULL) receives a malloc'ed list of the
+ * queries with toi < 1 as in SCALABLE_CCD_TOI_PER_QUERY builds. */
+int sccd_narrow_phase(sccd_ctx* ctx, const sccd_mesh* mesh, const int32_t* pairs, int64_t n,
+                      int pairs_on_device, int is_vf, int max_iter, double tol, double ms,
+                      int allow_zero_toi, double* toi, sccd_collision** collisions,
+                      int64_t* n_collisions);
+
+/* ------------------------------------------------------------------------------------------ */
+/* drivers                                                                                    */
+
+typedef struct sccd_stats {
+    int64_t n_vf_pairs, n_ee_pairs;           /* overlaps fed to the narrow phase             */
+    int64_t n_vf_candidates, n_ee_candidates; /* sort-axis candidate tests                    */
+    int64_t n_vf_checks, n_ee_checks;         /* inclusion-function evaluations               */
+    double ms_boxes, ms_sort, ms_sweep, ms_narrow, ms_total; /* device time, SCCD_OPT_PROFILE */
+} sccd_stats;
+
+/* ccd(V0,V1,E,F,min_distance,max_iterations,tolerance,allow_zero_toi,memory_limit_GB):
+ * src/scalable_ccd/cuda/ccd.cuh:26-38 / ccd.cu:80-146.  Host matrices in, earliest TOI out. */
+int sccd_ccd(sccd_ctx* ctx, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
+             const int32_t* F, int nF, double min_distance, int max_iterations, double tolerance,
+             int allow_zero_toi, int memory_limit_GB, double* toi);
+/* Same on a device-resident mesh; stats may be NULL.  This is what bench.py times. */
+int sccd_ccd_mesh(sccd_ctx* ctx, const sccd_mesh* mesh, double min_distance, int max_iterations,
+                  double tolerance, int allow_zero_toi, double* toi, sccd_stats* stats);
+/* The two halves of ccd() for multi-GPU runs (one process per GPU): every rank builds and sorts
+ * all boxes (prepare), sweeps only its SCCD_OPT_SHARD_RANK/COUNT share of the candidates and
+ * runs the narrow phase on the pairs it found (pass).  The caller min-reduces *toi over the
+ * ranks (RCCL all-reduce) after the VF pass and after the EE pass -- the only exchange step,
+ * mirroring how ccd.cu:125-143 threads toi from the VF pass into the EE pass. */
+int sccd_ccd_mesh_prepare(sccd_ctx* ctx, const sccd_mesh* mesh, double min_distance);
+int sccd_ccd_mesh_pass(sccd_ctx* ctx, const sccd_mesh* mesh, int is_vf, double min_distance,
+                       int max_iterations, double tolerance, int allow_zero_toi, double* toi_inout,
+                       sccd_stats* stats);
+/* ipc_ccd_strategy(): src/scalable_ccd/cuda/ipc_ccd_strategy.hpp:17-24 / .cu:97-152. */
+int sccd_ipc_ccd_strategy(sccd_ctx* ctx, const double* V0, const double* V1, int nV,
+                          const int32_t* E, int nE, const int32_t* F, int nF, double min_distance,
+                          int max_iterations, double tolerance, double* toi);
+
+/* ------------------------------------------------------------------------------------------ */
+/* profiling (replaces the reference's Profiler/ProfilePoint, utils/profiler.hpp:15-99)       */
+
+#define SCCD_PROF_BOXES 0
+#define SCCD_PROF_SORT 1
+#define SCCD_PROF_RANGES 2
+#define SCCD_PROF_SWEEP 3
+#define SCCD_PROF_NARROW 4
+#define SCCD_PROF_COUNT 5
+/* accumulated device milliseconds and launch counts per kernel class since the last reset */
+int sccd_get_profile(sccd_ctx* ctx, double ms[SCCD_PROF_COUNT], int64_t launches[SCCD_PROF_COUNT]);
+int sccd_reset_profile(sccd_ctx* ctx);
+
+/* standalone kernels exposed for roofline measurements (bench.py --workload sort) */
+int sccd_sort_pairs_u32(sccd_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCCD_H */

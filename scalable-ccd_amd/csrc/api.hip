@@ -1,0 +1,917 @@
+// api.hip -- the C ABI of include/sccd.h: context, HBM-resident objects and the host drivers
+// (ccd(), BroadPhase, narrow_phase, ipc_ccd_strategy of the reference, see sccd.h for the
+// file:line each entry point replaces).  Host code only; kernels live in the other .hip files.
+#include "internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+// ------------------------------------------------------------------------------------------
+// error trampolines
+static thread_local std::string g_create_error;
+
+template <class Fn> static int guarded(sccd_ctx* c, Fn&& fn)
+{
+    try {
+        if (c) SCCD_HIP(hipSetDevice(c->device));
+        fn();
+        return SCCD_OK;
+    } catch (const SccdError& e) {
+        if (c) c->err = e.msg;
+        else g_create_error = e.msg;
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        if (c) c->err = "host allocation failed";
+        return SCCD_E_NOMEM;
+    } catch (const std::exception& e) {
+        if (c) c->err = e.what();
+        return SCCD_E_INVALID;
+    }
+}
+
+// pipeline objects cached in the context so that repeated ccd() calls allocate nothing
+struct Pipeline {
+    DevBuf raw_v, raw_e, raw_f; // unsorted AoS boxes
+    DevBuf idx;                 // sort permutation
+    sccd_boxes vb, eb, fb;
+    sccd_broad_phase bp;
+};
+static Pipeline* pipeline_of(sccd_ctx* c)
+{
+    if (!c->pipeline) {
+        auto* p = new Pipeline();
+        p->vb.ctx = p->eb.ctx = p->fb.ctx = c;
+        p->bp.ctx = c;
+        c->pipeline = p;
+    }
+    return static_cast<Pipeline*>(c->pipeline);
+}
+
+void sccd_collect_profile(sccd_ctx* c)
+{
+    for (auto& pe : c->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pe.b) == hipSuccess && hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess)
+            c->prof_ms[pe.cls] += ms;
+        c->event_pool.push_back(pe.a);
+        c->event_pool.push_back(pe.b);
+    }
+    c->pending.clear();
+}
+
+extern "C" {
+
+const char* sccd_version(void) { return "sccd-hip 0.1 (gfx950)"; }
+
+int sccd_create(int device, sccd_ctx** out)
+{
+    if (!out) return SCCD_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        g_create_error = "no HIP device available (libsccd_hip has no CPU fallback)";
+        return SCCD_E_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        g_create_error = "device ordinal out of range";
+        return SCCD_E_NO_DEVICE;
+    }
+    sccd_ctx* c = new sccd_ctx();
+    c->device = device;
+    const int rc = guarded(c, [&] {
+        hipDeviceProp_t prop;
+        SCCD_HIP(hipGetDeviceProperties(&prop, device));
+        c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        SCCD_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+        c->scalars.ensure(4096);
+        c->h_scalars.ensure(4096);
+    });
+    if (rc != SCCD_OK) {
+        g_create_error = c->err;
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return SCCD_OK;
+}
+
+void sccd_destroy(sccd_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    delete static_cast<Pipeline*>(c->pipeline);
+    c->pipeline = nullptr;
+    sccd_collect_profile(c);
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* sccd_last_error(const sccd_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int sccd_set_stream(sccd_ctx* c, void* s)
+{
+    if (!c) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+        if (s) {
+            if (c->own_stream) SCCD_HIP(hipStreamDestroy(c->stream));
+            c->stream = (hipStream_t)s;
+            c->own_stream = false;
+        } else if (!c->own_stream) {
+            SCCD_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+            c->own_stream = true;
+        }
+    });
+}
+
+int sccd_synchronize(sccd_ctx* c)
+{
+    if (!c) return SCCD_E_INVALID;
+    return guarded(c, [&] { SCCD_HIP(hipStreamSynchronize(c->stream)); });
+}
+
+int sccd_set_option(sccd_ctx* c, int opt, int64_t v)
+{
+    if (!c) return SCCD_E_INVALID;
+    switch (opt) {
+    case SCCD_OPT_ARITH: c->arith = v ? 1 : 0; break;
+    case SCCD_OPT_NARROW_ALGO: c->narrow_algo = v ? 1 : 0; break;
+    case SCCD_OPT_SWEEP_ALGO: c->sweep_algo = v ? 1 : 0; break;
+    case SCCD_OPT_SORT_AXIS:
+        if (v < -1 || v > 2) return SCCD_E_INVALID;
+        c->sort_axis = (int)v;
+        break;
+    case SCCD_OPT_SHARD_RANK: c->shard_rank = (int)v; break;
+    case SCCD_OPT_SHARD_COUNT:
+        if (v < 1) return SCCD_E_INVALID;
+        c->shard_count = (int)v;
+        break;
+    case SCCD_OPT_OVERLAP_CAPACITY: c->overlap_capacity = v; break;
+    case SCCD_OPT_PROFILE: c->profile = v ? 1 : 0; break;
+    case SCCD_OPT_MAX_OVERLAP_CUTOFF: c->max_overlap_cutoff = v; break;
+    default: c->err = "unknown option"; return SCCD_E_INVALID;
+    }
+    return SCCD_OK;
+}
+
+int64_t sccd_get_option(const sccd_ctx* c, int opt)
+{
+    if (!c) return 0;
+    switch (opt) {
+    case SCCD_OPT_ARITH: return c->arith;
+    case SCCD_OPT_NARROW_ALGO: return c->narrow_algo;
+    case SCCD_OPT_SWEEP_ALGO: return c->sweep_algo;
+    case SCCD_OPT_SORT_AXIS: return c->sort_axis;
+    case SCCD_OPT_SHARD_RANK: return c->shard_rank;
+    case SCCD_OPT_SHARD_COUNT: return c->shard_count;
+    case SCCD_OPT_OVERLAP_CAPACITY: return c->overlap_capacity;
+    case SCCD_OPT_PROFILE: return c->profile;
+    case SCCD_OPT_MAX_OVERLAP_CUTOFF: return c->max_overlap_cutoff;
+    default: return 0;
+    }
+}
+
+int sccd_get_profile(sccd_ctx* c, double ms[SCCD_PROF_COUNT], int64_t launches[SCCD_PROF_COUNT])
+{
+    if (!c) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+        sccd_collect_profile(c);
+        for (int k = 0; k < SCCD_PROF_COUNT; k++) {
+            if (ms) ms[k] = c->prof_ms[k];
+            if (launches) launches[k] = c->prof_launches[k];
+        }
+    });
+}
+
+int sccd_reset_profile(sccd_ctx* c)
+{
+    if (!c) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+        sccd_collect_profile(c);
+        for (int k = 0; k < SCCD_PROF_COUNT; k++) {
+            c->prof_ms[k] = 0;
+            c->prof_launches[k] = 0;
+        }
+    });
+}
+
+void sccd_free(void* p) { std::free(p); }
+
+} // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// mesh
+static void copy_in(sccd_ctx* c, void* dst, const void* src, size_t bytes, int src_on_device)
+{
+    if (bytes == 0) return;
+    SCCD_HIP(hipMemcpyAsync(dst, src, bytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                            c->stream));
+}
+
+static void mesh_set_vertices(sccd_mesh* m, const double* V0, const double* V1, int src_on_device)
+{
+    sccd_ctx* c = m->ctx;
+    const size_t nb = sizeof(double) * 3 * (size_t)m->nV;
+    const double *d0 = V0, *d1 = V1;
+    if (!src_on_device) {
+        c->tmp0.ensure(nb);
+        c->tmp1.ensure(nb);
+        copy_in(c, c->tmp0.p, V0, nb, 0);
+        copy_in(c, c->tmp1.p, V1, nb, 0);
+        d0 = c->tmp0.as<double>();
+        d1 = c->tmp1.as<double>();
+    }
+    launch_pack_vertices(c, d0, d1, m->nV, m->V.as<double>());
+    SCCD_HIP(hipStreamSynchronize(c->stream)); // borrowed inputs may go away after return
+}
+
+extern "C" int sccd_mesh_create(sccd_ctx* c, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
+                                const int32_t* F, int nF, int src_on_device, sccd_mesh** out)
+{
+    if (!c || !out) return SCCD_E_INVALID;
+    *out = nullptr;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(nV >= 0 && nE >= 0 && nF >= 0, "mesh: negative size");
+        SCCD_REQUIRE((nV == 0 || (V0 && V1)) && (nE == 0 || E) && (nF == 0 || F), "mesh: null matrix");
+        std::unique_ptr<sccd_mesh> m(new sccd_mesh());
+        m->ctx = c;
+        m->nV = nV;
+        m->nE = nE;
+        m->nF = nF;
+        m->V.ensure(sizeof(double) * 8 * (size_t)std::max(nV, 1));
+        m->E.ensure(sizeof(int2) * (size_t)std::max(nE, 1));
+        m->F.ensure(sizeof(int4) * (size_t)std::max(nF, 1));
+        const int32_t *dE = E, *dF = F;
+        if (!src_on_device) {
+            c->tmp2.ensure(sizeof(int32_t) * (2 * (size_t)nE + 3 * (size_t)nF + 4));
+            int32_t* t = c->tmp2.as<int32_t>();
+            copy_in(c, t, E, sizeof(int32_t) * 2 * (size_t)nE, 0);
+            copy_in(c, t + 2 * (size_t)nE, F, sizeof(int32_t) * 3 * (size_t)nF, 0);
+            dE = t;
+            dF = t + 2 * (size_t)nE;
+        }
+        launch_pack_edges(c, dE, nE, m->E.as<int2>());
+        launch_pack_faces(c, dF, nF, m->F.as<int4>());
+        mesh_set_vertices(m.get(), V0, V1, src_on_device);
+        *out = m.release();
+    });
+}
+
+extern "C" int sccd_mesh_update_vertices(sccd_mesh* m, const double* V0, const double* V1, int src_on_device)
+{
+    if (!m) return SCCD_E_INVALID;
+    return guarded(m->ctx, [&] {
+        SCCD_REQUIRE(m->nV == 0 || (V0 && V1), "mesh: null matrix");
+        mesh_set_vertices(m, V0, V1, src_on_device);
+    });
+}
+
+extern "C" void sccd_mesh_destroy(sccd_mesh* m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    delete m;
+}
+
+// ------------------------------------------------------------------------------------------
+// boxes
+
+// sort `raw` (device AoS, n boxes) into `b` along the configured axis
+static void boxes_sort_into(sccd_ctx* c, const sccd_aabb* raw, int n, DevBuf& idx, sccd_boxes* b)
+{
+    b->n = n;
+    int axis = c->sort_axis;
+    if (axis < 0) axis = pick_sort_axis(c, raw, n);
+    b->axis = axis;
+    const size_t pad = 64; // the sweep streams whole 32-column blocks
+    b->key.ensure(sizeof(uint32_t) * ((size_t)n + pad));
+    b->kmax.ensure(sizeof(uint32_t) * ((size_t)n + pad));
+    b->filt.ensure(sizeof(float4) * ((size_t)n + pad));
+    b->box.ensure(sizeof(sccd_aabb) * ((size_t)n + 1));
+    idx.ensure(sizeof(uint32_t) * ((size_t)n + pad));
+    if (n == 0) return;
+    {
+        ProfScope ps(c, SCCD_PROF_BOXES);
+        launch_box_keys(c, raw, n, axis, b->key.as<uint32_t>(), idx.as<uint32_t>());
+    }
+    {
+        ProfScope ps(c, SCCD_PROF_SORT);
+        radix_sort_pairs_u32(c, b->key.as<uint32_t>(), idx.as<uint32_t>(), n);
+    }
+    {
+        ProfScope ps(c, SCCD_PROF_BOXES);
+        launch_box_gather(c, raw, idx.as<uint32_t>(), n, axis, b->box.as<sccd_aabb>(), b->filt.as<float4>(),
+                          b->kmax.as<uint32_t>());
+    }
+}
+
+extern "C" int sccd_build_vertex_boxes(sccd_ctx* c, const double* V0, const double* V1, int nV, double r,
+                                       sccd_aabb* out)
+{
+    if (!c) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(nV >= 0 && (nV == 0 || (V0 && V1 && out)), "build_vertex_boxes: bad arguments");
+        if (nV == 0) return;
+        const size_t nb = sizeof(double) * 3 * (size_t)nV;
+        c->tmp0.ensure(nb);
+        c->tmp1.ensure(nb);
+        c->tmp2.ensure(sizeof(double) * 8 * (size_t)nV);
+        c->np_scratch0.ensure(sizeof(sccd_aabb) * (size_t)nV);
+        copy_in(c, c->tmp0.p, V0, nb, 0);
+        copy_in(c, c->tmp1.p, V1, nb, 0);
+        launch_pack_vertices(c, c->tmp0.as<double>(), c->tmp1.as<double>(), nV, c->tmp2.as<double>());
+        launch_vertex_boxes(c, c->tmp2.as<double>(), nV, r, c->np_scratch0.as<sccd_aabb>());
+        SCCD_HIP(hipMemcpyAsync(out, c->np_scratch0.p, sizeof(sccd_aabb) * (size_t)nV, hipMemcpyDeviceToHost,
+                                c->stream));
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+static int build_elem_boxes(sccd_ctx* c, const sccd_aabb* vb, int nV, const int32_t* M, int nM, int cols,
+                            sccd_aabb* out)
+{
+    if (!c) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(nV >= 0 && nM >= 0 && (nM == 0 || (vb && M && out)), "build_*_boxes: bad arguments");
+        if (nM == 0) return;
+        for (size_t k = 0; k < (size_t)cols * (size_t)nM; k++)
+            SCCD_REQUIRE(M[k] >= 0 && M[k] < nV, "build_*_boxes: vertex index out of range");
+        c->tmp0.ensure(sizeof(sccd_aabb) * (size_t)std::max(nV, 1));
+        c->tmp1.ensure(sizeof(int32_t) * (size_t)cols * (size_t)nM);
+        c->tmp2.ensure(sizeof(int4) * (size_t)nM);
+        c->np_scratch0.ensure(sizeof(sccd_aabb) * (size_t)nM);
+        copy_in(c, c->tmp0.p, vb, sizeof(sccd_aabb) * (size_t)nV, 0);
+        copy_in(c, c->tmp1.p, M, sizeof(int32_t) * (size_t)cols * (size_t)nM, 0);
+        if (cols == 2) {
+            launch_pack_edges(c, c->tmp1.as<int32_t>(), nM, c->tmp2.as<int2>());
+            launch_edge_boxes(c, c->tmp0.as<sccd_aabb>(), c->tmp2.as<int2>(), nM, c->np_scratch0.as<sccd_aabb>());
+        } else {
+            launch_pack_faces(c, c->tmp1.as<int32_t>(), nM, c->tmp2.as<int4>());
+            launch_face_boxes(c, c->tmp0.as<sccd_aabb>(), c->tmp2.as<int4>(), nM, c->np_scratch0.as<sccd_aabb>());
+        }
+        SCCD_HIP(hipMemcpyAsync(out, c->np_scratch0.p, sizeof(sccd_aabb) * (size_t)nM, hipMemcpyDeviceToHost,
+                                c->stream));
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+extern "C" int sccd_build_edge_boxes(sccd_ctx* c, const sccd_aabb* vb, int nV, const int32_t* E, int nE,
+                                     sccd_aabb* out)
+{
+    return build_elem_boxes(c, vb, nV, E, nE, 2, out);
+}
+extern "C" int sccd_build_face_boxes(sccd_ctx* c, const sccd_aabb* vb, int nV, const int32_t* F, int nF,
+                                     sccd_aabb* out)
+{
+    return build_elem_boxes(c, vb, nV, F, nF, 3, out);
+}
+
+extern "C" int sccd_boxes_create(sccd_ctx* c, const sccd_aabb* boxes, int n, int src_on_device, sccd_boxes** out)
+{
+    if (!c || !out) return SCCD_E_INVALID;
+    *out = nullptr;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(n >= 0 && (n == 0 || boxes), "boxes_create: bad arguments");
+        std::unique_ptr<sccd_boxes> b(new sccd_boxes());
+        b->ctx = c;
+        const sccd_aabb* raw = boxes;
+        if (!src_on_device && n > 0) {
+            c->np_scratch3.ensure(sizeof(sccd_aabb) * (size_t)n);
+            copy_in(c, c->np_scratch3.p, boxes, sizeof(sccd_aabb) * (size_t)n, 0);
+            raw = c->np_scratch3.as<sccd_aabb>();
+        }
+        DevBuf idx;
+        boxes_sort_into(c, raw, n, idx, b.get());
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+        *out = b.release();
+    });
+}
+
+// vertex boxes -> (edge, face) boxes -> sorted lists, all on the device (ccd.cu:112-121)
+static void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline* pl, bool want_v, bool want_e,
+                            bool want_f)
+{
+    pl->raw_v.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nV, 1));
+    {
+        ProfScope ps(c, SCCD_PROF_BOXES);
+        launch_vertex_boxes(c, m->V.as<double>(), m->nV, r, pl->raw_v.as<sccd_aabb>());
+        if (want_e) {
+            pl->raw_e.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nE, 1));
+            launch_edge_boxes(c, pl->raw_v.as<sccd_aabb>(), m->E.as<int2>(), m->nE, pl->raw_e.as<sccd_aabb>());
+        }
+        if (want_f) {
+            pl->raw_f.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nF, 1));
+            launch_face_boxes(c, pl->raw_v.as<sccd_aabb>(), m->F.as<int4>(), m->nF, pl->raw_f.as<sccd_aabb>());
+        }
+    }
+    if (want_v) boxes_sort_into(c, pl->raw_v.as<sccd_aabb>(), m->nV, pl->idx, &pl->vb);
+    if (want_e) boxes_sort_into(c, pl->raw_e.as<sccd_aabb>(), m->nE, pl->idx, &pl->eb);
+    if (want_f) boxes_sort_into(c, pl->raw_f.as<sccd_aabb>(), m->nF, pl->idx, &pl->fb);
+}
+
+static sccd_boxes* clone_boxes(sccd_ctx* c, const sccd_boxes& s)
+{
+    std::unique_ptr<sccd_boxes> b(new sccd_boxes());
+    b->ctx = c;
+    b->n = s.n;
+    b->axis = s.axis;
+    const size_t pad = 64, n = (size_t)s.n;
+    b->key.ensure(sizeof(uint32_t) * (n + pad));
+    b->kmax.ensure(sizeof(uint32_t) * (n + pad));
+    b->filt.ensure(sizeof(float4) * (n + pad));
+    b->box.ensure(sizeof(sccd_aabb) * (n + 1));
+    if (n) {
+        copy_in(c, b->key.p, s.key.p, sizeof(uint32_t) * n, 1);
+        copy_in(c, b->kmax.p, s.kmax.p, sizeof(uint32_t) * n, 1);
+        copy_in(c, b->filt.p, s.filt.p, sizeof(float4) * n, 1);
+        copy_in(c, b->box.p, s.box.p, sizeof(sccd_aabb) * n, 1);
+    }
+    return b.release();
+}
+
+extern "C" int sccd_boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, sccd_boxes** vb, sccd_boxes** eb,
+                                    sccd_boxes** fb)
+{
+    if (!c || !m) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        Pipeline* pl = pipeline_of(c);
+        boxes_from_mesh(c, m, r, pl, vb != nullptr, eb != nullptr, fb != nullptr);
+        if (vb) *vb = clone_boxes(c, pl->vb);
+        if (eb) *eb = clone_boxes(c, pl->eb);
+        if (fb) *fb = clone_boxes(c, pl->fb);
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+
+extern "C" int sccd_boxes_size(const sccd_boxes* b) { return b ? b->n : 0; }
+
+extern "C" int sccd_boxes_download(const sccd_boxes* b, sccd_aabb* out)
+{
+    if (!b || !out) return SCCD_E_INVALID;
+    return guarded(b->ctx, [&] {
+        if (b->n == 0) return;
+        SCCD_HIP(hipMemcpyAsync(out, b->box.p, sizeof(sccd_aabb) * (size_t)b->n, hipMemcpyDeviceToHost,
+                                b->ctx->stream));
+        SCCD_HIP(hipStreamSynchronize(b->ctx->stream));
+    });
+}
+
+extern "C" void sccd_boxes_destroy(sccd_boxes* b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    delete b;
+}
+
+// ------------------------------------------------------------------------------------------
+// broad phase
+extern "C" int sccd_broad_phase_create(sccd_ctx* c, sccd_broad_phase** out)
+{
+    if (!c || !out) return SCCD_E_INVALID;
+    *out = new sccd_broad_phase();
+    (*out)->ctx = c;
+    return SCCD_OK;
+}
+
+extern "C" void sccd_broad_phase_destroy(sccd_broad_phase* bp)
+{
+    if (!bp) return;
+    (void)hipSetDevice(bp->ctx->device);
+    (void)hipStreamSynchronize(bp->ctx->stream);
+    delete bp;
+}
+
+static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes* B)
+{
+    SCCD_REQUIRE(A != nullptr, "BroadPhase::build: boxes are null");
+    SCCD_REQUIRE(!B || A->axis == B->axis, "BroadPhase::build: lists sorted along different axes");
+    bp->A = A;
+    bp->B = B;
+    bp->built = true;
+    bp->cursor = 0;
+    bp->n_overlaps = 0;
+    bp->candidates = 0;
+    // two lists with an empty side produce nothing (sort_and_sweep.cpp:221-223)
+    bp->total_rows = B ? ((A->n == 0 || B->n == 0) ? 0 : (int64_t)A->n + B->n) : A->n;
+}
+
+extern "C" int sccd_broad_phase_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes* B)
+{
+    if (!bp) return SCCD_E_INVALID;
+    return guarded(bp->ctx, [&] { bp_build(bp, A, B); });
+}
+
+extern "C" int sccd_broad_phase_is_complete(const sccd_broad_phase* bp)
+{
+    return (!bp || bp->cursor >= bp->total_rows) ? 1 : 0;
+}
+extern "C" int64_t sccd_broad_phase_num_boxes(const sccd_broad_phase* bp)
+{
+    if (!bp || !bp->A) return 0;
+    return (int64_t)bp->A->n + (bp->B ? bp->B->n : 0);
+}
+extern "C" int64_t sccd_broad_phase_candidates(const sccd_broad_phase* bp) { return bp ? bp->candidates : 0; }
+
+// candidate-balanced share of rows [lo, hi) for this rank: equal sums of (end - start)
+static void shard_rows(sccd_ctx* c, const uint2* d_ranges, int lo, int hi, int* out_lo, int* out_hi)
+{
+    *out_lo = lo;
+    *out_hi = hi;
+    if (c->shard_count <= 1 || hi <= lo) return;
+    const int n = hi - lo;
+    std::vector<uint2> h((size_t)n);
+    SCCD_HIP(hipMemcpyAsync(h.data(), d_ranges + lo, sizeof(uint2) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    SCCD_HIP(hipStreamSynchronize(c->stream));
+    // weight = candidates + 1 so that empty rows still spread
+    unsigned long long total = 0;
+    for (int i = 0; i < n; i++) total += (unsigned long long)(h[(size_t)i].y - h[(size_t)i].x) + 1ull;
+    const unsigned long long t0 = total * (unsigned long long)c->shard_rank / (unsigned long long)c->shard_count;
+    const unsigned long long t1 = total * (unsigned long long)(c->shard_rank + 1) / (unsigned long long)c->shard_count;
+    unsigned long long run = 0;
+    int a = n, b = n;
+    for (int i = 0; i < n; i++) {
+        if (a == n && run >= t0) a = i;
+        if (b == n && run >= t1) b = i;
+        run += (unsigned long long)(h[(size_t)i].y - h[(size_t)i].x) + 1ull;
+    }
+    if (c->shard_rank == c->shard_count - 1) b = n;
+    *out_lo = lo + a;
+    *out_hi = lo + b;
+}
+
+static void bp_detect_partial(sccd_broad_phase* bp)
+{
+    sccd_ctx* c = bp->ctx;
+    if (!bp->built) throw SccdError { SCCD_E_NOT_BUILT, "Must initialize build broad phase before detecting overlaps!" };
+    bp->n_overlaps = 0;
+    if (bp->cursor >= bp->total_rows) return;
+    const sccd_boxes* A = bp->A;
+    const sccd_boxes* B = bp->B;
+    const int64_t cutoff = c->max_overlap_cutoff > 0 ? c->max_overlap_cutoff : bp->total_rows;
+    const int64_t chunk_lo = bp->cursor, chunk_hi = std::min(bp->cursor + cutoff, bp->total_rows);
+
+    SweepCounters* d_cnt = c->scalars.as<SweepCounters>();
+    unsigned long long* d_cand = &d_cnt->candidates;
+
+    // ranges are (re)computed on the first chunk of a build
+    if (bp->cursor == 0) {
+        SCCD_HIP(hipMemsetAsync(d_cnt, 0, sizeof(SweepCounters), c->stream));
+        ProfScope ps(c, SCCD_PROF_RANGES);
+        bp->ranges_a.ensure(sizeof(uint2) * (size_t)std::max(A->n, 1));
+        if (!B) {
+            launch_ranges(c, A, A, 0, bp->ranges_a.as<uint2>(), d_cand);
+        } else {
+            bp->ranges_b.ensure(sizeof(uint2) * (size_t)std::max(B->n, 1));
+            launch_ranges(c, A, B, 1, bp->ranges_a.as<uint2>(), d_cand);
+            launch_ranges(c, B, A, 2, bp->ranges_b.as<uint2>(), d_cand);
+        }
+    }
+
+    // rows of this chunk per sweep class
+    int a_lo = (int)std::min<int64_t>(chunk_lo, A->n), a_hi = (int)std::min<int64_t>(chunk_hi, A->n);
+    int b_lo = 0, b_hi = 0;
+    if (B) {
+        b_lo = (int)std::max<int64_t>(0, chunk_lo - A->n);
+        b_hi = (int)std::max<int64_t>(0, chunk_hi - A->n);
+    }
+    shard_rows(c, bp->ranges_a.as<uint2>(), a_lo, a_hi, &a_lo, &a_hi);
+    if (B) shard_rows(c, bp->ranges_b.as<uint2>(), b_lo, b_hi, &b_lo, &b_hi);
+
+    if (bp->capacity == 0) {
+        int64_t cap = c->overlap_capacity > 0 ? c->overlap_capacity : std::max<int64_t>(1 << 20, 32 * bp->total_rows);
+        bp->overlaps.ensure(sizeof(int2) * (size_t)cap);
+        bp->capacity = cap;
+    }
+    for (int attempt = 0;; attempt++) { // overflow -> exact-size rerun (broad_phase.cu:142-203)
+        SCCD_HIP(hipMemsetAsync(&d_cnt->n_pairs, 0, sizeof(unsigned long long), c->stream));
+        {
+            ProfScope ps(c, SCCD_PROF_SWEEP);
+            if (!B) {
+                launch_sweep(c, A, A, bp->ranges_a.as<uint2>(), a_lo, a_hi, EMIT_ONE_LIST, bp->overlaps.as<int2>(),
+                             bp->capacity, d_cnt);
+            } else {
+                launch_sweep(c, A, B, bp->ranges_a.as<uint2>(), a_lo, a_hi, EMIT_ROWS_A, bp->overlaps.as<int2>(),
+                             bp->capacity, d_cnt);
+                launch_sweep(c, B, A, bp->ranges_b.as<uint2>(), b_lo, b_hi, EMIT_ROWS_B, bp->overlaps.as<int2>(),
+                             bp->capacity, d_cnt);
+            }
+        }
+        SweepCounters h;
+        SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+        bp->candidates = (int64_t)h.candidates;
+        if ((int64_t)h.n_pairs <= bp->capacity) {
+            bp->n_overlaps = (int64_t)h.n_pairs;
+            break;
+        }
+        SCCD_REQUIRE(attempt < 3, "broad phase: overlap buffer keeps overflowing");
+        const int64_t cap = (int64_t)h.n_pairs + (int64_t)h.n_pairs / 16 + 1024;
+        bp->overlaps.ensure(sizeof(int2) * (size_t)cap);
+        bp->capacity = cap;
+    }
+    bp->cursor = chunk_hi; // thread_start_box_id += MAX_OVERLAP_CUTOFF (broad_phase.cu:207)
+}
+
+extern "C" int sccd_broad_phase_detect_overlaps_partial(sccd_broad_phase* bp, const int32_t** d_pairs, int64_t* n)
+{
+    if (!bp) return SCCD_E_INVALID;
+    return guarded(bp->ctx, [&] {
+        bp_detect_partial(bp);
+        if (d_pairs) *d_pairs = bp->overlaps.as<int32_t>();
+        if (n) *n = bp->n_overlaps;
+    });
+}
+
+extern "C" int sccd_broad_phase_detect_overlaps(sccd_broad_phase* bp, int32_t** pairs, int64_t* n)
+{
+    if (!bp || !pairs || !n) return SCCD_E_INVALID;
+    *pairs = nullptr;
+    *n = 0;
+    return guarded(bp->ctx, [&] {
+        sccd_ctx* c = bp->ctx;
+        if (!bp->built) throw SccdError { SCCD_E_NOT_BUILT, "Must initialize build broad phase before detecting overlaps!" };
+        std::vector<int32_t> acc;
+        int64_t cand = 0;
+        while (bp->cursor < bp->total_rows) { // broad_phase.cu:236-247
+            bp_detect_partial(bp);
+            cand = bp->candidates;
+            const size_t at = acc.size();
+            acc.resize(at + 2 * (size_t)bp->n_overlaps);
+            if (bp->n_overlaps) {
+                SCCD_HIP(hipMemcpyAsync(acc.data() + at, bp->overlaps.p, sizeof(int2) * (size_t)bp->n_overlaps,
+                                        hipMemcpyDeviceToHost, c->stream));
+                SCCD_HIP(hipStreamSynchronize(c->stream));
+            }
+        }
+        bp->candidates = cand;
+        int32_t* o = (int32_t*)std::malloc(std::max<size_t>(8, acc.size() * sizeof(int32_t)));
+        if (!o) throw SccdError { SCCD_E_NOMEM, "host allocation failed" };
+        if (!acc.empty()) std::memcpy(o, acc.data(), acc.size() * sizeof(int32_t));
+        *pairs = o;
+        *n = (int64_t)(acc.size() / 2);
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// narrow phase
+static NarrowCounters* narrow_counters(sccd_ctx* c)
+{
+    return reinterpret_cast<NarrowCounters*>(c->scalars.as<char>() + 256);
+}
+
+struct NarrowResult {
+    unsigned long long n_checks;
+};
+
+static NarrowResult run_narrow(sccd_ctx* c, const sccd_mesh* m, const int2* d_pairs, int64_t n, int is_vf, int max_iter,
+                               double tol, double ms, int allow_zero_toi, double* toi, double* d_per_query)
+{
+    NarrowParams p;
+    p.V = m->V.as<double>();
+    p.E = m->E.as<int2>();
+    p.F = m->F.as<int4>();
+    p.pairs = d_pairs;
+    p.d_npairs = nullptr;
+    p.n_pairs = n;
+    p.is_vf = is_vf;
+    p.max_iter = max_iter;
+    p.tol = tol;
+    p.ms = ms;
+    p.allow_zero_toi = allow_zero_toi;
+    p.arith = c->arith;
+    narrow_phase_run(c, p, narrow_counters(c), toi, d_per_query);
+    NarrowCounters h;
+    std::memcpy(&h, c->h_scalars.p, sizeof h);
+    return NarrowResult { h.n_checks };
+}
+
+extern "C" int sccd_narrow_phase(sccd_ctx* c, const sccd_mesh* m, const int32_t* pairs, int64_t n, int pairs_on_device,
+                                 int is_vf, int max_iter, double tol, double ms, int allow_zero_toi, double* toi,
+                                 sccd_collision** collisions, int64_t* n_collisions)
+{
+    if (!c || !m || !toi) return SCCD_E_INVALID;
+    if (collisions) *collisions = nullptr;
+    if (n_collisions) *n_collisions = 0;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(n >= 0 && (n == 0 || pairs), "narrow_phase: bad pair list");
+        SCCD_REQUIRE(*toi >= 0, "narrow_phase: toi must be >= 0");
+        const int2* d_pairs = reinterpret_cast<const int2*>(pairs);
+        std::vector<int32_t> h_pairs;
+        if (n > 0) {
+            // validate indices on the host copy (the reference asserts nothing and would fault)
+            if (!pairs_on_device) {
+                const int na = is_vf ? m->nV : m->nE, nb = is_vf ? m->nF : m->nE;
+                for (int64_t i = 0; i < n; i++)
+                    SCCD_REQUIRE(pairs[2 * i] >= 0 && pairs[2 * i] < na && pairs[2 * i + 1] >= 0 && pairs[2 * i + 1] < nb,
+                                 "narrow_phase: pair index out of range");
+                c->np_scratch3.ensure(sizeof(int2) * (size_t)n);
+                copy_in(c, c->np_scratch3.p, pairs, sizeof(int2) * (size_t)n, 0);
+                d_pairs = c->np_scratch3.as<int2>();
+            }
+        }
+        double* d_pq = nullptr;
+        DevBuf pq;
+        if (collisions && n > 0) {
+            pq.ensure(sizeof(double) * (size_t)n);
+            d_pq = pq.as<double>();
+        }
+        run_narrow(c, m, d_pairs, n, is_vf, max_iter, tol, ms, allow_zero_toi, toi, d_pq);
+        if (collisions && n > 0) { // copy_out_collisions (narrow_phase.cu:84-103)
+            std::vector<double> hq((size_t)n);
+            std::vector<int32_t> hp;
+            SCCD_HIP(hipMemcpyAsync(hq.data(), d_pq, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+            const int32_t* src = pairs;
+            if (pairs_on_device) {
+                hp.resize(2 * (size_t)n);
+                SCCD_HIP(hipMemcpyAsync(hp.data(), d_pairs, sizeof(int2) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+                src = hp.data();
+            }
+            SCCD_HIP(hipStreamSynchronize(c->stream));
+            int64_t k = 0;
+            for (int64_t i = 0; i < n; i++) k += hq[(size_t)i] < 1;
+            sccd_collision* o = (sccd_collision*)std::malloc(std::max<size_t>(16, sizeof(sccd_collision) * (size_t)k));
+            if (!o) throw SccdError { SCCD_E_NOMEM, "host allocation failed" };
+            k = 0;
+            for (int64_t i = 0; i < n; i++)
+                if (hq[(size_t)i] < 1) o[k++] = sccd_collision { src[2 * i], src[2 * i + 1], hq[(size_t)i] };
+            *collisions = o;
+            if (n_collisions) *n_collisions = k;
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// drivers
+
+// partial_ccd<run_vf> (ccd.cu:14-78): build, then alternate detect_overlaps_partial / narrow_phase
+static void ccd_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, bool vf, double ms, int max_iter, double tol,
+                     int allow_zero_toi, double* toi, sccd_stats* st)
+{
+    if (vf) bp_build(&pl->bp, &pl->vb, &pl->fb);
+    else bp_build(&pl->bp, &pl->eb, nullptr);
+    while (pl->bp.cursor < pl->bp.total_rows) {
+        bp_detect_partial(&pl->bp);
+        const NarrowResult r = run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, vf ? 1 : 0, max_iter,
+                                          tol, ms, allow_zero_toi, toi, nullptr);
+        if (st) {
+            (vf ? st->n_vf_pairs : st->n_ee_pairs) += pl->bp.n_overlaps;
+            (vf ? st->n_vf_checks : st->n_ee_checks) += (int64_t)r.n_checks;
+        }
+    }
+    if (st) (vf ? st->n_vf_candidates : st->n_ee_candidates) = pl->bp.candidates;
+}
+
+static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter, double tol, int allow_zero_toi,
+                        double* toi_out, sccd_stats* st)
+{
+    Pipeline* pl = pipeline_of(c);
+    if (st) std::memset(st, 0, sizeof *st);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (st && c->profile) {
+        SCCD_HIP(hipEventCreate(&e0));
+        SCCD_HIP(hipEventCreate(&e1));
+        SCCD_HIP(hipEventRecord(e0, c->stream));
+    }
+    double before[SCCD_PROF_COUNT];
+    if (st && c->profile) {
+        sccd_collect_profile(c);
+        std::memcpy(before, c->prof_ms, sizeof before);
+    }
+    boxes_from_mesh(c, m, ms, pl, true, true, true); // inflation radius = min_distance (ccd.cu:112)
+    double toi = 1; // ccd.cu:125
+    ccd_pass(c, m, pl, true, ms, max_iter, tol, allow_zero_toi, &toi, st);
+    ccd_pass(c, m, pl, false, ms, max_iter, tol, allow_zero_toi, &toi, st);
+    *toi_out = toi;
+    if (st && c->profile) {
+        SCCD_HIP(hipEventRecord(e1, c->stream));
+        SCCD_HIP(hipEventSynchronize(e1));
+        float msf = 0;
+        SCCD_HIP(hipEventElapsedTime(&msf, e0, e1));
+        st->ms_total = msf;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        sccd_collect_profile(c);
+        st->ms_boxes = c->prof_ms[SCCD_PROF_BOXES] - before[SCCD_PROF_BOXES];
+        st->ms_sort = c->prof_ms[SCCD_PROF_SORT] - before[SCCD_PROF_SORT];
+        st->ms_sweep = (c->prof_ms[SCCD_PROF_SWEEP] - before[SCCD_PROF_SWEEP])
+            + (c->prof_ms[SCCD_PROF_RANGES] - before[SCCD_PROF_RANGES]);
+        st->ms_narrow = c->prof_ms[SCCD_PROF_NARROW] - before[SCCD_PROF_NARROW];
+    }
+}
+
+extern "C" int sccd_ccd_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter, double tol, int allow_zero_toi,
+                             double* toi, sccd_stats* stats)
+{
+    if (!c || !m || !toi) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(m->ctx == c, "ccd: mesh belongs to another context");
+        ccd_on_mesh(c, m, ms, max_iter, tol, allow_zero_toi, toi, stats);
+    });
+}
+
+extern "C" int sccd_ccd_mesh_prepare(sccd_ctx* c, const sccd_mesh* m, double ms)
+{
+    if (!c || !m) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(m->ctx == c, "ccd: mesh belongs to another context");
+        boxes_from_mesh(c, m, ms, pipeline_of(c), true, true, true);
+    });
+}
+
+extern "C" int sccd_ccd_mesh_pass(sccd_ctx* c, const sccd_mesh* m, int is_vf, double ms, int max_iter, double tol,
+                                  int allow_zero_toi, double* toi, sccd_stats* st)
+{
+    if (!c || !m || !toi) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(m->ctx == c, "ccd: mesh belongs to another context");
+        Pipeline* pl = pipeline_of(c);
+        SCCD_REQUIRE(pl->vb.n == m->nV && pl->eb.n == m->nE && pl->fb.n == m->nF,
+                     "ccd_mesh_pass: call sccd_ccd_mesh_prepare first");
+        if (st) std::memset(st, 0, sizeof *st);
+        ccd_pass(c, m, pl, is_vf != 0, ms, max_iter, tol, allow_zero_toi, toi, st);
+    });
+}
+
+static void check_mesh_host(const double* V0, const double* V1, int nV, const int32_t* E, int nE, const int32_t* F,
+                            int nF)
+{
+    SCCD_REQUIRE(nV >= 0 && nE >= 0 && nF >= 0, "ccd: negative size");
+    SCCD_REQUIRE((nV == 0 || (V0 && V1)) && (nE == 0 || E) && (nF == 0 || F), "ccd: null matrix");
+    for (size_t k = 0; k < 2 * (size_t)nE; k++) SCCD_REQUIRE(E[k] >= 0 && E[k] < nV, "ccd: edge index out of range");
+    for (size_t k = 0; k < 3 * (size_t)nF; k++) SCCD_REQUIRE(F[k] >= 0 && F[k] < nV, "ccd: face index out of range");
+}
+
+extern "C" int sccd_ccd(sccd_ctx* c, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
+                        const int32_t* F, int nF, double ms, int max_iter, double tol, int allow_zero_toi,
+                        int memory_limit_GB, double* toi)
+{
+    (void)memory_limit_GB; // sizing is exact-with-retry here; the knob is accepted for API parity
+    if (!c || !toi) return SCCD_E_INVALID;
+    sccd_mesh* m = nullptr;
+    int rc = guarded(c, [&] { check_mesh_host(V0, V1, nV, E, nE, F, nF); });
+    if (rc != SCCD_OK) return rc;
+    rc = sccd_mesh_create(c, V0, V1, nV, E, nE, F, nF, 0, &m);
+    if (rc != SCCD_OK) return rc;
+    rc = sccd_ccd_mesh(c, m, ms, max_iter, tol, allow_zero_toi, toi, nullptr);
+    sccd_mesh_destroy(m);
+    return rc;
+}
+
+// partial_ipc_ccd_strategy<run_vf> (ipc_ccd_strategy.cu:12-92)
+static void ipc_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, bool vf, double ms, int max_iter, double tol,
+                     double* earliest)
+{
+    if (vf) bp_build(&pl->bp, &pl->vb, &pl->fb);
+    else bp_build(&pl->bp, &pl->eb, nullptr);
+    while (pl->bp.cursor < pl->bp.total_rows) {
+        bp_detect_partial(&pl->bp);
+        const double before = *earliest;
+        run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, vf ? 1 : 0, max_iter, tol, ms,
+                   /*allow_zero_toi=*/1, earliest, nullptr);
+        if (*earliest < 1e-6) { // :72-91: conservative re-run without minimum separation
+            *earliest = before;
+            run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, vf ? 1 : 0, /*max_iter=*/-1, tol,
+                       /*ms=*/0.0, /*allow_zero_toi=*/0, earliest, nullptr);
+            *earliest *= 0.8;
+        }
+    }
+}
+
+extern "C" int sccd_ipc_ccd_strategy(sccd_ctx* c, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
+                                     const int32_t* F, int nF, double ms, int max_iter, double tol, double* toi)
+{
+    if (!c || !toi) return SCCD_E_INVALID;
+    sccd_mesh* m = nullptr;
+    int rc = guarded(c, [&] { check_mesh_host(V0, V1, nV, E, nE, F, nF); });
+    if (rc != SCCD_OK) return rc;
+    rc = sccd_mesh_create(c, V0, V1, nV, E, nE, F, nF, 0, &m);
+    if (rc != SCCD_OK) return rc;
+    rc = guarded(c, [&] {
+        Pipeline* pl = pipeline_of(c);
+        boxes_from_mesh(c, m, ms, pl, true, true, true); // ipc_ccd_strategy.cu:123-125
+        double earliest = 1.0;                           // :136
+        ipc_pass(c, m, pl, true, ms, max_iter, tol, &earliest);
+        ipc_pass(c, m, pl, false, ms, max_iter, tol, &earliest);
+        *toi = earliest;
+    });
+    sccd_mesh_destroy(m);
+    return rc;
+}
+
+extern "C" int sccd_sort_pairs_u32(sccd_ctx* c, uint32_t* d_keys, uint32_t* d_vals, int64_t n)
+{
+    if (!c) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        ProfScope ps(c, SCCD_PROF_SORT);
+        radix_sort_pairs_u32(c, d_keys, d_vals, n);
+    });
+}

@@ -1,0 +1,268 @@
+// boxes.hip -- box construction and the split/gather around the sort, on the device.
+//
+// Replaces (reference paths relative to the reference root):
+//   AABB::conservative_inflation / from_point      src/scalable_ccd/cuda/broad_phase/aabb.cu:19-37
+//   build_vertex/edge/face_boxes (host, TBB)       aabb.cu:115-229   (CPU twin: broad_phase/aabb.cpp:38-133)
+//   split_boxes + the payload movement of the sort aabb.cu:40-111
+// The reference builds boxes on the host and copies 64 B/box to the device; here the mesh is
+// already resident and the boxes never leave HBM.
+#include "internal.hpp"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int TPB = 256;
+inline int grid_for(long long n) { return (int)((n + TPB - 1) / TPB); }
+
+// column-major V0,V1 (Eigen) -> packed {x0,y0,z0,0,x1,y1,z1,0}
+__global__ void pack_vertices_k(const double* __restrict__ V0, const double* __restrict__ V1, int nV,
+                                double* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nV) return;
+    double4 a = make_double4(V0[i], V0[i + (size_t)nV], V0[i + 2 * (size_t)nV], 0.0);
+    double4 b = make_double4(V1[i], V1[i + (size_t)nV], V1[i + 2 * (size_t)nV], 0.0);
+    double4* o = reinterpret_cast<double4*>(out) + 2 * (size_t)i;
+    o[0] = a;
+    o[1] = b;
+}
+
+__global__ void pack_edges_k(const int* __restrict__ E, int nE, int2* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nE) return;
+    out[i] = make_int2(E[i], E[i + (size_t)nE]);
+}
+
+__global__ void pack_faces_k(const int* __restrict__ F, int nF, int4* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nF) return;
+    out[i] = make_int4(F[i], F[i + (size_t)nF], F[i + 2 * (size_t)nF], 0);
+}
+
+__device__ __forceinline__ void store_box(sccd_aabb* out, const double lo[3], const double hi[3], int v0, int v1,
+                                          int v2, int eid)
+{
+    double4* o = reinterpret_cast<double4*>(out);
+    o[0] = make_double4(lo[0], lo[1], lo[2], hi[0]);
+    double2* o2 = reinterpret_cast<double2*>(out) + 2;
+    o2[0] = make_double2(hi[1], hi[2]);
+    int4* oi = reinterpret_cast<int4*>(out) + 3;
+    oi[0] = make_int4(v0, v1, v2, eid);
+}
+
+// AABB::from_point(p_t0, p_t1, r): per coordinate
+//   lo = min(nextafter_down(p0) - nextafter_up(r), nextafter_down(p1) - nextafter_up(r))
+//   hi = max(nextafter_up(p0)   + nextafter_up(r), nextafter_up(p1)   + nextafter_up(r))
+// (aabb.cu:19-37, aabb.cuh:55-63; ids aabb.cu:180-181)
+__global__ void vertex_boxes_k(const double* __restrict__ V, int nV, double r, sccd_aabb* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nV) return;
+    const double4* v = reinterpret_cast<const double4*>(V) + 2 * (size_t)i;
+    const double4 a = v[0], b = v[1];
+    const double p0[3] = { a.x, a.y, a.z }, p1[3] = { b.x, b.y, b.z };
+    const double ru = nextafter_up(r);
+    double lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double l0 = nextafter_down(p0[k]) - ru, l1 = nextafter_down(p1[k]) - ru;
+        const double h0 = nextafter_up(p0[k]) + ru, h1 = nextafter_up(p1[k]) + ru;
+        lo[k] = (l1 < l0) ? l1 : l0;
+        hi[k] = (h0 < h1) ? h1 : h0;
+    }
+    store_box(out + i, lo, hi, i, -i - 1, -i - 1, i);
+}
+
+struct BoxLoad {
+    double lo[3], hi[3];
+};
+__device__ __forceinline__ BoxLoad load_box_geom(const sccd_aabb* b)
+{
+    const double4 q = reinterpret_cast<const double4*>(b)[0];
+    const double2 q2 = reinterpret_cast<const double2*>(b)[2];
+    BoxLoad r;
+    r.lo[0] = q.x;
+    r.lo[1] = q.y;
+    r.lo[2] = q.z;
+    r.hi[0] = q.w;
+    r.hi[1] = q2.x;
+    r.hi[2] = q2.y;
+    return r;
+}
+
+// AABB(a, b): component-wise min/max (aabb.cuh:18-29); ids aabb.cu:200-203
+__global__ void edge_boxes_k(const sccd_aabb* __restrict__ vb, const int2* __restrict__ E, int nE,
+                             sccd_aabb* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nE) return;
+    const int2 e = E[i];
+    const BoxLoad a = load_box_geom(vb + e.x), b = load_box_geom(vb + e.y);
+    double lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        lo[k] = (b.lo[k] < a.lo[k]) ? b.lo[k] : a.lo[k];
+        hi[k] = (a.hi[k] < b.hi[k]) ? b.hi[k] : a.hi[k];
+    }
+    store_box(out + i, lo, hi, e.x, e.y, -e.x - 1, i);
+}
+
+// AABB(a, b, c) (aabb.cuh:31-42); ids aabb.cu:223-225
+__global__ void face_boxes_k(const sccd_aabb* __restrict__ vb, const int4* __restrict__ F, int nF,
+                             sccd_aabb* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nF) return;
+    const int4 f = F[i];
+    const BoxLoad a = load_box_geom(vb + f.x), b = load_box_geom(vb + f.y), c = load_box_geom(vb + f.z);
+    double lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double l = (b.lo[k] < a.lo[k]) ? b.lo[k] : a.lo[k];
+        l = (c.lo[k] < l) ? c.lo[k] : l;
+        double h = (a.hi[k] < b.hi[k]) ? b.hi[k] : a.hi[k];
+        h = (h < c.hi[k]) ? c.hi[k] : h;
+        lo[k] = l;
+        hi[k] = h;
+    }
+    store_box(out + i, lo, hi, f.x, f.y, f.z, i);
+}
+
+// split_boxes, key part (aabb.cu:40-72): 32-bit monotone key of min[axis] + identity index
+__global__ void box_keys_k(const sccd_aabb* __restrict__ raw, int n, int axis, uint32_t* __restrict__ key,
+                           uint32_t* __restrict__ idx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    key[i] = key32(raw[i].min[axis]);
+    idx[i] = (uint32_t)i;
+}
+
+// payload movement of thrust::sort_by_key (aabb.cu:107-109) as ONE gather after the index sort,
+// fused with the construction of the filter record and the max-key.
+__global__ void box_gather_k(const sccd_aabb* __restrict__ raw, const uint32_t* __restrict__ idx, int n, int axis,
+                             sccd_aabb* __restrict__ sorted, float4* __restrict__ filt, uint32_t* __restrict__ kmax)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const sccd_aabb* src = raw + idx[i];
+    const double4 q0 = reinterpret_cast<const double4*>(src)[0];
+    const double4 q1 = reinterpret_cast<const double4*>(src)[1];
+    double4* dst = reinterpret_cast<double4*>(sorted + i);
+    dst[0] = q0;
+    dst[1] = q1;
+    const double lo[3] = { q0.x, q0.y, q0.z };
+    const double hi[3] = { q0.w, q1.x, q1.y };
+    const int a = (axis == 0) ? 1 : 0;
+    const int b = (axis == 2) ? 1 : 2;
+    // outward rounding keeps the filter conservative: filt.min <= min, filt.max >= max
+    filt[i] = make_float4(__double2float_rd(lo[a]), __double2float_ru(hi[a]), __double2float_rd(lo[b]),
+                          __double2float_ru(hi[b]));
+    kmax[i] = key32(hi[axis]);
+}
+
+// sum and sum of squares of the box centres per axis (sort_and_sweep.cpp:176-186)
+__global__ void centre_moments_k(const sccd_aabb* __restrict__ raw, int n, double* __restrict__ acc)
+{
+    double s[3] = { 0, 0, 0 }, s2[3] = { 0, 0, 0 };
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const BoxLoad b = load_box_geom(raw + i);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double cc = (b.lo[k] + b.hi[k]) / 2;
+            s[k] += cc;
+            s2[k] += cc * cc;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s[k] += __shfl_xor(s[k], o, 64);
+            s2[k] += __shfl_xor(s2[k], o, 64);
+        }
+    }
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            atomicAdd(&acc[k], s[k]);
+            atomicAdd(&acc[3 + k], s2[k]);
+        }
+    }
+}
+
+} // namespace
+
+void launch_pack_vertices(sccd_ctx* c, const double* dV0, const double* dV1, int nV, double* dV)
+{
+    if (nV == 0) return;
+    hipLaunchKernelGGL(pack_vertices_k, dim3(grid_for(nV)), dim3(TPB), 0, c->stream, dV0, dV1, nV, dV);
+    SCCD_HIP(hipGetLastError());
+}
+void launch_pack_edges(sccd_ctx* c, const int32_t* dE, int nE, int2* out)
+{
+    if (nE == 0) return;
+    hipLaunchKernelGGL(pack_edges_k, dim3(grid_for(nE)), dim3(TPB), 0, c->stream, dE, nE, out);
+    SCCD_HIP(hipGetLastError());
+}
+void launch_pack_faces(sccd_ctx* c, const int32_t* dF, int nF, int4* out)
+{
+    if (nF == 0) return;
+    hipLaunchKernelGGL(pack_faces_k, dim3(grid_for(nF)), dim3(TPB), 0, c->stream, dF, nF, out);
+    SCCD_HIP(hipGetLastError());
+}
+void launch_vertex_boxes(sccd_ctx* c, const double* dV, int nV, double inflation, sccd_aabb* out)
+{
+    if (nV == 0) return;
+    hipLaunchKernelGGL(vertex_boxes_k, dim3(grid_for(nV)), dim3(TPB), 0, c->stream, dV, nV, inflation, out);
+    SCCD_HIP(hipGetLastError());
+}
+void launch_edge_boxes(sccd_ctx* c, const sccd_aabb* vb, const int2* E, int nE, sccd_aabb* out)
+{
+    if (nE == 0) return;
+    hipLaunchKernelGGL(edge_boxes_k, dim3(grid_for(nE)), dim3(TPB), 0, c->stream, vb, E, nE, out);
+    SCCD_HIP(hipGetLastError());
+}
+void launch_face_boxes(sccd_ctx* c, const sccd_aabb* vb, const int4* F, int nF, sccd_aabb* out)
+{
+    if (nF == 0) return;
+    hipLaunchKernelGGL(face_boxes_k, dim3(grid_for(nF)), dim3(TPB), 0, c->stream, vb, F, nF, out);
+    SCCD_HIP(hipGetLastError());
+}
+void launch_box_keys(sccd_ctx* c, const sccd_aabb* raw, int n, int axis, uint32_t* key, uint32_t* idx)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(box_keys_k, dim3(grid_for(n)), dim3(TPB), 0, c->stream, raw, n, axis, key, idx);
+    SCCD_HIP(hipGetLastError());
+}
+void launch_box_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* idx, int n, int axis, sccd_aabb* sorted,
+                       float4* filt, uint32_t* kmax)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(box_gather_k, dim3(grid_for(n)), dim3(TPB), 0, c->stream, raw, idx, n, axis, sorted, filt,
+                       kmax);
+    SCCD_HIP(hipGetLastError());
+}
+
+int pick_sort_axis(sccd_ctx* c, const sccd_aabb* raw, int n)
+{
+    if (n == 0) return 0;
+    c->tmp2.ensure(6 * sizeof(double));
+    double* acc = c->tmp2.as<double>();
+    SCCD_HIP(hipMemsetAsync(acc, 0, 6 * sizeof(double), c->stream));
+    const int grid = std::min(grid_for(n), c->num_cus * 8);
+    hipLaunchKernelGGL(centre_moments_k, dim3(grid), dim3(TPB), 0, c->stream, raw, n, acc);
+    SCCD_HIP(hipGetLastError());
+    double h[6];
+    SCCD_HIP(hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    SCCD_HIP(hipStreamSynchronize(c->stream));
+    double var[3];
+    for (int k = 0; k < 3; k++) var[k] = h[3 + k] - h[k] * h[k] / n;
+    int ax = 0; // sort_and_sweep.cpp:188-195
+    if (var[1] > var[0]) ax = 1;
+    if (var[2] > var[ax]) ax = 2;
+    return ax;
+}

@@ -1,0 +1,245 @@
+// common.hpp -- context, device buffers, error plumbing and wave64 helpers shared by every
+// translation unit of libsccd_hip.so.  gfx950 only: wavefront = 64 lanes everywhere.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../include/sccd.h"
+
+#define SCCD_WAVE 64
+
+// ------------------------------------------------------------------------------------------
+// error plumbing: HIP failures become SCCD_E_HIP / SCCD_E_NOMEM with the text kept in the
+// context (the reference throws std::runtime_error from gpuErrchk, cuda/utils/assert.cuh:18-27)
+struct SccdError {
+    int code;
+    std::string msg;
+};
+
+#define SCCD_HIP(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            throw SccdError { _e == hipErrorOutOfMemory ? SCCD_E_NOMEM : SCCD_E_HIP,           \
+                              std::string(#expr) + ": " + hipGetErrorString(_e) + " ("         \
+                                  + __FILE__ + ":" + std::to_string(__LINE__) + ")" };         \
+        }                                                                                      \
+    } while (0)
+
+#define SCCD_REQUIRE(cond, text)                                                               \
+    do {                                                                                       \
+        if (!(cond)) throw SccdError { SCCD_E_INVALID, std::string(text) };                    \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// grow-only device buffer (no hipMalloc in the steady state of repeated ccd() calls)
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    // contents are NOT preserved on growth
+    void ensure(size_t bytes)
+    {
+        if (bytes <= cap) return;
+        release();
+        size_t want = bytes + bytes / 8 + 256;
+        SCCD_HIP(hipMalloc(&p, want));
+        cap = want;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~PinnedBuf()
+    {
+        if (p) (void)hipHostFree(p);
+    }
+    void ensure(size_t bytes)
+    {
+        if (bytes <= cap) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        SCCD_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        cap = bytes;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ------------------------------------------------------------------------------------------
+struct sccd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    std::string err;
+
+    // options (sccd.h SCCD_OPT_*)
+    int arith = 0;
+    int narrow_algo = 0;
+    int sweep_algo = 0;
+    int sort_axis = 0;
+    int shard_rank = 0;
+    int shard_count = 1;
+    int64_t overlap_capacity = 0;
+    int profile = 0;
+    int64_t max_overlap_cutoff = 0;
+
+    // profiling: accumulated per kernel class
+    double prof_ms[SCCD_PROF_COUNT] = { 0 };
+    int64_t prof_launches[SCCD_PROF_COUNT] = { 0 };
+    struct PendingEvent {
+        int cls;
+        hipEvent_t a, b;
+    };
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+
+    // scratch shared by the pipeline stages
+    DevBuf sort_tmp_keys, sort_tmp_vals, sort_hist, sort_status;
+    DevBuf scalars;      // small device-side counters block
+    PinnedBuf h_scalars; // pinned mirror for async read-back
+    DevBuf np_scratch0, np_scratch1, np_scratch2, np_scratch3;
+    DevBuf tmp0, tmp1, tmp2;
+    void* pipeline = nullptr; // cached pipeline objects (api.hip)
+};
+
+// RAII profile scope: records a hipEvent pair on the context's stream around a kernel class
+struct ProfScope {
+    sccd_ctx* c;
+    int cls;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(sccd_ctx* ctx, int k) : c(ctx), cls(k)
+    {
+        if (!c->profile) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!c->event_pool.empty()) {
+                e = c->event_pool.back();
+                c->event_pool.pop_back();
+            } else {
+                SCCD_HIP(hipEventCreate(&e));
+            }
+            return e;
+        };
+        a = get();
+        b = get();
+        SCCD_HIP(hipEventRecord(a, c->stream));
+    }
+    ~ProfScope()
+    {
+        if (!c->profile || !a) return;
+        (void)hipEventRecord(b, c->stream);
+        c->pending.push_back({ cls, a, b });
+        c->prof_launches[cls]++;
+    }
+};
+
+void sccd_collect_profile(sccd_ctx* c); // api.cpp
+
+// ------------------------------------------------------------------------------------------
+// device-side helpers
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ int mbcnt64(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+__device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
+
+// make LDS writes of this wave visible to its other lanes (single-wave producer/consumer)
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <class T> __device__ __forceinline__ T wave_bcast(T v, int src_lane)
+{
+    return __shfl(v, src_lane, 64);
+}
+
+__device__ __forceinline__ unsigned readfirst_u32(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o, 64));
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+    return v;
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (l >= o) v += t;
+    }
+    return v;
+}
+
+// ---- order-preserving 32-bit sort key of a double -------------------------------------------
+// K(x) = top 32 bits of the monotone u64 image of x (+0.0 canonicalises -0.0).  Monotone
+// non-decreasing: a <= b  =>  K(a) <= K(b).  The sweep only needs that (DESIGN.md "Sort key").
+__device__ __forceinline__ unsigned key32(double x)
+{
+    x = x + 0.0;
+    unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    b ^= (b >> 63) ? 0xFFFFFFFFFFFFFFFFull : 0x8000000000000000ull;
+    return (unsigned)(b >> 32);
+}
+
+// nextafter(x, -DBL_MAX) / nextafter(x, +DBL_MAX) of the reference (scalar.hpp:31-49) by bit
+// arithmetic: no libm call, identical results including zeros, subnormals and infinities.
+__device__ __forceinline__ double nextafter_up(double x)
+{
+    if (x != x) return x;
+    const double dmax = 1.7976931348623157e308;
+    if (x == dmax) return x;      // x == y
+    if (x > dmax) return dmax;    // +inf steps down towards y
+    if (x == 0.0) return __longlong_as_double(1ll); // smallest positive subnormal
+    long long b = __double_as_longlong(x);
+    b += (x > 0.0) ? 1 : -1;
+    return __longlong_as_double(b);
+}
+__device__ __forceinline__ double nextafter_down(double x)
+{
+    if (x != x) return x;
+    const double dmax = 1.7976931348623157e308;
+    if (x == -dmax) return x;
+    if (x < -dmax) return -dmax;
+    if (x == 0.0) return __longlong_as_double((long long)0x8000000000000001ull);
+    long long b = __double_as_longlong(x);
+    b += (x > 0.0) ? -1 : 1;
+    return __longlong_as_double(b);
+}
+
+#endif // __HIPCC__

@@ -1,0 +1,101 @@
+// internal.hpp -- object layouts in HBM and the launcher functions each .hip file exports.
+#pragma once
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------
+// HBM layouts (DESIGN.md "Data layout in HBM")
+//
+// mesh.V   : double[nV][8]  = {x0,y0,z0,0, x1,y1,z1,0}  -- both frames of a vertex in ONE
+//            64-byte record, so a narrow-phase query gathers 4 records (reference: two
+//            column-major matrices, 24 separate 8-byte gathers per query, narrow_phase.cu:44-66)
+// mesh.E   : int2[nE], mesh.F : int4[nF] = {f0,f1,f2,0}   (row records instead of columns)
+//
+// boxes    : sorted along the sort axis by key32(min[axis])
+//   key    : uint32[n]  ascending                      (reference: Scalar2 sorted_major_intervals)
+//   kmax   : uint32[n]  key32(max[axis]) in the same order
+//   filt   : float4[n]  {a.min (rounded down), a.max (rounded up), b.min, b.max} of the two
+//            non-sort axes -- the 16-byte record the sweep's filter stage streams
+//   box    : sccd_aabb[n] exact 64-byte boxes in sorted order (confirm stage, download)
+struct sccd_mesh {
+    sccd_ctx* ctx = nullptr;
+    int nV = 0, nE = 0, nF = 0;
+    DevBuf V, E, F;
+};
+
+struct sccd_boxes {
+    sccd_ctx* ctx = nullptr;
+    int n = 0;
+    int axis = 0;
+    DevBuf key, kmax, filt, box;
+};
+
+struct sccd_broad_phase {
+    sccd_ctx* ctx = nullptr;
+    const sccd_boxes* A = nullptr;
+    const sccd_boxes* B = nullptr; // nullptr: one list
+    bool built = false;
+    int64_t cursor = 0;     // thread_start_box_id of broad_phase.cuh:86 (in sorted rows)
+    int64_t total_rows = 0; // rows of all sweep classes
+    DevBuf ranges_a, ranges_b; // uint2[n] (start,end) per row, per sweep class
+    DevBuf overlaps;           // int2[capacity]
+    int64_t capacity = 0;
+    int64_t n_overlaps = 0;
+    int64_t candidates = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// boxes.hip
+void launch_pack_vertices(sccd_ctx* c, const double* dV0, const double* dV1, int nV, double* dV);
+void launch_pack_edges(sccd_ctx* c, const int32_t* dE, int nE, int2* out);
+void launch_pack_faces(sccd_ctx* c, const int32_t* dF, int nF, int4* out);
+void launch_vertex_boxes(sccd_ctx* c, const double* dV, int nV, double inflation, sccd_aabb* out);
+void launch_edge_boxes(sccd_ctx* c, const sccd_aabb* vb, const int2* E, int nE, sccd_aabb* out);
+void launch_face_boxes(sccd_ctx* c, const sccd_aabb* vb, const int4* F, int nF, sccd_aabb* out);
+void launch_box_keys(sccd_ctx* c, const sccd_aabb* raw, int n, int axis, uint32_t* key, uint32_t* idx);
+void launch_box_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* idx, int n, int axis,
+                       sccd_aabb* sorted, float4* filt, uint32_t* kmax);
+// variance of box centres per axis -> arg-max axis (sort_and_sweep.cpp:176-195); blocking
+int pick_sort_axis(sccd_ctx* c, const sccd_aabb* raw, int n);
+
+// sort.hip: in-place LSD radix sort of (key, value) pairs by key, ascending, stable
+void radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n);
+
+// sweep.hip
+enum SweepEmit { EMIT_ONE_LIST = 0, EMIT_ROWS_A = 1, EMIT_ROWS_B = 2 };
+struct SweepCounters { // lives in device memory (ctx->scalars)
+    unsigned long long n_pairs;    // pairs found (may exceed capacity: overflow -> rerun)
+    unsigned long long candidates; // sum of (end-start) over the swept rows
+    unsigned int tile_ticket;      // persistent-wave tile counter
+    unsigned int pad;
+};
+// ranges for rows of `rows` against columns `cols` (see sweep.hip for the three modes)
+void launch_ranges(sccd_ctx* c, const sccd_boxes* rows, const sccd_boxes* cols, int mode, uint2* ranges,
+                   unsigned long long* d_candidates);
+void launch_sweep(sccd_ctx* c, const sccd_boxes* rows, const sccd_boxes* cols, const uint2* ranges,
+                  int row_begin, int row_end, int emit, int2* out, int64_t capacity, SweepCounters* d_cnt);
+
+// narrow.hip
+struct NarrowParams {
+    const double* V;
+    const int2* E;
+    const int4* F;
+    const int2* pairs;
+    const unsigned long long* d_npairs; // device-resident count (no host round trip) or nullptr
+    long long n_pairs;                  // used when d_npairs == nullptr
+    int is_vf;
+    int max_iter;
+    double tol;
+    double ms;
+    int allow_zero_toi;
+    int arith;
+};
+struct NarrowCounters {
+    unsigned long long toi_bits;  // running minimum (non-negative double as u64)
+    unsigned long long n_checks;  // inclusion-function evaluations
+    unsigned long long ticket;    // query chunk ticket
+    unsigned int overflow;
+    unsigned int pad;
+};
+// runs the narrow phase on the stream; *toi in/out lives in d_cnt->toi_bits
+void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
+                      double* d_per_query_toi);

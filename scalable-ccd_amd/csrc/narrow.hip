@@ -1,0 +1,223 @@
+// narrow.hip -- Tight-Inclusion narrow phase on gfx950.
+//
+// Replaces add_data<>, compute_tolerance<>, ccd_kernel<>, the host BFS loop ccd<>() and the
+// CCDBuffer ring (src/scalable_ccd/cuda/narrow_phase/narrow_phase.cu:24-206,
+// root_finder.cu:260-457, ccd_buffer.cuh:7-83).
+//
+// Two algorithms, same results for max_iter < 0 (the final TOI is a min over accepted domains
+// and pruning by the running TOI never changes that min -- SURVEY Appendix A.20):
+//   algo 0  np_queue_k: ONE persistent launch.  Every wave owns a work pool of (query slot,
+//           [t]x[u]x[v]) domains in LDS, pops 64 domains per step (one per lane, earliest
+//           sub-intervals on top so the running TOI drops early), and ingests 64 fresh queries
+//           (gather + per-query constants, all lanes busy) whenever the pool runs low.
+//           Divergent bisection depth is absorbed by the pool: lanes never wait for the
+//           deepest query of a batch.  No CCDData array in HBM, no per-level host round trip.
+//   algo 1  np_level_k: level-synchronous BFS with a host loop, the reference's scheme
+//           (root_finder.cu:431-447).  Kept as the in-library cross-check.
+#include "internal.hpp"
+#include "ti_math.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// shared
+__device__ __forceinline__ double toi_load(const unsigned long long* p)
+{
+    // relaxed agent-scope load: bypasses this CU's L1 so other CUs' atomicMin are seen
+    return __longlong_as_double((long long)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// atomicMin on the IEEE bit pattern is valid for non-negative doubles (atomic_min_float.cuh:17-29)
+__device__ __forceinline__ void toi_min(unsigned long long* p, double v)
+{
+    atomicMin(p, (unsigned long long)__double_as_longlong(v));
+}
+
+// ------------------------------------------------------------------------------------------
+// algo 1: level-synchronous BFS (reference scheme)
+struct LvlData { // CCDData (ccd_data.cuh:8-26) minus ms
+    double v[8][3];
+    double err[3];
+    double tol[3];
+    unsigned long long toi_bits; // per-query toi (TOI_PER_QUERY)
+    int nbr_checks;
+    int pad;
+};
+struct LvlDomain { // CCDDomain (interval.cuh:30-44)
+    double lo[3], hi[3];
+    int query_id;
+    int pad;
+};
+
+template <bool VF>
+__global__ void np_level_init_k(const double* __restrict__ V, const int2* __restrict__ E, const int4* __restrict__ F,
+                                const int2* __restrict__ pairs, long long n, double tol, bool use_ms,
+                                LvlData* __restrict__ data, LvlDomain* __restrict__ dom)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    TIQuery q;
+    ti_gather<VF>(V, E, F, pairs[i], q.v);
+    ti_tolerance<VF>(q.v, tol, q.tol);
+    ti_error<VF>(q.v, use_ms, q.err);
+    LvlData d;
+#pragma unroll
+    for (int a = 0; a < 8; a++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) d.v[a][k] = q.v[a][k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        d.err[k] = q.err[k];
+        d.tol[k] = q.tol[k];
+    }
+    d.toi_bits = 0x7FF0000000000000ull; // +inf (narrow_phase.cu:70)
+    d.nbr_checks = 0;
+    d.pad = 0;
+    data[i] = d;
+    LvlDomain r;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        r.lo[k] = 0.0;
+        r.hi[k] = 1.0;
+    }
+    r.query_id = (int)i;
+    r.pad = 0;
+    dom[i] = r;
+}
+
+template <bool VF, int ARITH>
+__global__ void np_level_k(const LvlDomain* __restrict__ cur, long long n_cur, LvlDomain* __restrict__ nxt,
+                           unsigned long long* __restrict__ n_nxt, LvlData* __restrict__ data, double ms,
+                           double tol, int max_iter, bool allow_zero_toi, bool per_query,
+                           NarrowCounters* __restrict__ cnt)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cur) return;
+    const LvlDomain dom = cur[i];
+    LvlData* dp = data + dom.query_id;
+    TIQuery q;
+#pragma unroll
+    for (int a = 0; a < 8; a++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) q.v[a][k] = dp->v[a][k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        q.err[k] = dp->err[k];
+        q.tol[k] = dp->tol[k];
+    }
+    const int before = dp->nbr_checks;  // data_in copy, root_finder.cu:288
+    atomicAdd(&dp->nbr_checks, 1);      // :289
+    const double prune = per_query ? toi_load(&dp->toi_bits) : toi_load(&cnt->toi_bits);
+    if (dom.lo[0] >= prune) return;                       // :295
+    if (max_iter >= 0 && before > max_iter) return;       // :303
+    const TIStep s = ti_step<VF, ARITH>(q, dom.lo, dom.hi, ms, tol, allow_zero_toi, prune);
+    if (s.checked) atomicAdd(&cnt->n_checks, 1ull);
+    if (s.accept) {
+        toi_min(&cnt->toi_bits, dom.lo[0]);
+        toi_min(&dp->toi_bits, dom.lo[0]);
+    }
+    if (s.nk > 0) {
+        const unsigned long long at = atomicAdd(n_nxt, (unsigned long long)s.nk);
+        LvlDomain c = dom;
+        c.hi[s.split] = s.mid;
+        nxt[at] = c;
+        if (s.nk == 2) {
+            c = dom;
+            c.lo[s.split] = s.mid;
+            nxt[at + 1] = c;
+        }
+    }
+}
+
+__global__ void np_copy_per_query_k(const LvlData* __restrict__ data, long long n, double* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __longlong_as_double((long long)data[i].toi_bits);
+}
+
+template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, long long n,
+                                       double* d_per_query_toi)
+{
+    const bool use_ms = p.ms > 0; // narrow_phase.cu:128
+    c->np_scratch0.ensure(sizeof(LvlData) * (size_t)n);
+    LvlData* data = c->np_scratch0.as<LvlData>();
+    c->np_scratch1.ensure(sizeof(LvlDomain) * (size_t)n);
+    c->tmp0.ensure(sizeof(unsigned long long));
+    unsigned long long* d_n = c->tmp0.as<unsigned long long>();
+    const int TPB = 256;
+    hipLaunchKernelGGL((np_level_init_k<VF>), dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, p.V,
+                       p.E, p.F, p.pairs, n, p.tol, use_ms, data, c->np_scratch1.as<LvlDomain>());
+    long long n_cur = n;
+    DevBuf* cur = &c->np_scratch1;
+    DevBuf* nxt = &c->np_scratch2;
+    while (n_cur > 0) { // root_finder.cu:431-447
+        nxt->ensure(sizeof(LvlDomain) * (size_t)(2 * n_cur));
+        SCCD_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream));
+        const dim3 grid((unsigned)((n_cur + TPB - 1) / TPB));
+        if (p.arith == 1)
+            hipLaunchKernelGGL((np_level_k<VF, 1>), grid, dim3(TPB), 0, c->stream, cur->as<LvlDomain>(), n_cur,
+                               nxt->as<LvlDomain>(), d_n, data, p.ms, p.tol, p.max_iter, (bool)p.allow_zero_toi,
+                               d_per_query_toi != nullptr, d_cnt);
+        else
+            hipLaunchKernelGGL((np_level_k<VF, 0>), grid, dim3(TPB), 0, c->stream, cur->as<LvlDomain>(), n_cur,
+                               nxt->as<LvlDomain>(), d_n, data, p.ms, p.tol, p.max_iter, (bool)p.allow_zero_toi,
+                               d_per_query_toi != nullptr, d_cnt);
+        SCCD_HIP(hipGetLastError());
+        unsigned long long h_n = 0;
+        SCCD_HIP(hipMemcpyAsync(&h_n, d_n, sizeof h_n, hipMemcpyDeviceToHost, c->stream));
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+        n_cur = (long long)h_n;
+        std::swap(cur, nxt);
+    }
+    if (d_per_query_toi) {
+        hipLaunchKernelGGL(np_copy_per_query_k, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, data,
+                           n, d_per_query_toi);
+        SCCD_HIP(hipGetLastError());
+    }
+}
+
+} // namespace
+
+#include "narrow_queue.inc"
+
+void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
+                      double* d_per_query_toi)
+{
+    // toi is in/out and must be >= 0 (narrow_phase.cu:126)
+    SCCD_REQUIRE(*h_toi_inout >= 0, "narrow_phase: toi must be >= 0");
+    NarrowCounters h;
+    std::memset(&h, 0, sizeof h);
+    std::memcpy(&h.toi_bits, h_toi_inout, 8);
+    SCCD_HIP(hipMemcpyAsync(d_cnt, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    // the reference's outer loop runs only while toi > 0 (narrow_phase.cu:136); in the
+    // per-query build the guard is absent (:138)
+    const bool run = (*h_toi_inout > 0) || d_per_query_toi != nullptr;
+    long long n = p.n_pairs;
+    if (p.d_npairs) {
+        unsigned long long hn = 0;
+        SCCD_HIP(hipMemcpyAsync(&hn, p.d_npairs, sizeof hn, hipMemcpyDeviceToHost, c->stream));
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+        n = (long long)hn;
+    }
+    if (run && n > 0) {
+        ProfScope ps(c, SCCD_PROF_NARROW);
+        const bool level_sync = c->narrow_algo == 1 || d_per_query_toi != nullptr || p.max_iter >= 0;
+        if (level_sync) {
+            if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi);
+            else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi);
+        } else {
+            run_queue(c, p, d_cnt, n);
+        }
+    }
+    SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    SCCD_HIP(hipStreamSynchronize(c->stream));
+    if (h.overflow) throw SccdError { SCCD_E_OVERFLOW, "narrow phase: work pool spill area exhausted" };
+    std::memcpy(h_toi_inout, &h.toi_bits, 8);
+    c->prof_launches[SCCD_PROF_NARROW] += 0;
+    // n_checks is read by the caller through d_cnt mirror
+    c->h_scalars.ensure(sizeof(NarrowCounters));
+    std::memcpy(c->h_scalars.p, &h, sizeof h);
+}

@@ -1,0 +1,330 @@
+// sweep.hip -- candidate ranges + the sweep (STQ for wave64) that emits overlap pairs.
+//
+// Replaces sweep_and_tiniest_queue<> / sweep_and_prune<> with Queue, add_overlap,
+// RawDeviceBuffer::push (src/scalable_ccd/cuda/broad_phase/sweep.cu:48-182, queue.cuh:5-49,
+// collision.cuh:11-54, utils/device_buffer.cuh:56-61) and the CPU twin batched_sweep
+// (src/scalable_ccd/broad_phase/sort_and_sweep.cpp:77-125).
+//
+// Set semantics (identical to the reference): all (a,b) whose boxes intersect INCLUSIVELY on
+// x, y and z, that share no vertex id, and (two lists) come from different lists.
+//
+// Structure of sweep_stq_k, per wave of 64 lanes, persistent over tiles of 64 sorted rows:
+//   FILTER   lane = row (its conservative float bounds in registers); the column records are
+//            wave-uniform 16-byte loads.  32 columns per block; each lane collects a 32-bit
+//            hit mask.  No cross-lane traffic in the inner loop.
+//   QUEUE    hit masks are expanded into a per-wave LDS queue of (row, col) candidates
+//            (one wave prefix-sum per block) -- the "tiniest queue" of STQ, 64 lanes wide.
+//   CONFIRM  whenever >= 64 candidates are queued, every lane confirms one with the exact
+//            double boxes (6 inclusive compares) and the 3x3 vertex-id test.
+//   EMIT     survivors go to a per-wave LDS staging buffer; one global atomic per ~1000 pairs
+//            reserves space, then the pairs are written coalesced (the reference: two global
+//            atomics per pair, collision.cuh:45-54).
+#include "internal.hpp"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int SW_THREADS = 256;
+constexpr int SW_WAVES = SW_THREADS / 64;
+constexpr int SW_QCAP = 256;  // candidate queue entries per wave
+constexpr int SW_OCAP = 1024; // staged output pairs per wave
+constexpr int SW_BLOCK = 32;  // columns per filter block
+
+// ------------------------------------------------------------------------------------------
+// candidate ranges (prefix information of the sorted keys)
+//   mode 0 one list : cols (i, ub(key, kmax_i))                     pairs i<j, K(min_j) <= K(max_i)
+//   mode 1 rows A   : cols B with K(min_a) <= K(min_b) <= K(max_a)  [lb(keyB,key_a), ub(keyB,kmax_a))
+//   mode 2 rows B   : cols A with K(min_b) <  K(min_a) <= K(max_b)  [ub(keyA,key_b), ub(keyA,kmax_b))
+// Modes 1 and 2 partition the intersecting cross pairs (exactly one of K(min_a) <= K(min_b),
+// K(min_b) < K(min_a) holds), so no pair is emitted twice and none is lost.
+__device__ __forceinline__ unsigned lower_bound_u32(const uint32_t* __restrict__ a, unsigned n, uint32_t v)
+{
+    unsigned lo = 0, hi = n;
+    while (lo < hi) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ unsigned upper_bound_u32(const uint32_t* __restrict__ a, unsigned n, uint32_t v)
+{
+    unsigned lo = 0, hi = n;
+    while (lo < hi) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void ranges_k(const uint32_t* __restrict__ key_r, const uint32_t* __restrict__ kmax_r, int n_rows,
+                         const uint32_t* __restrict__ key_c, int n_cols, int mode, uint2* __restrict__ ranges,
+                         unsigned long long* __restrict__ candidates)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long cnt = 0;
+    if (i < n_rows) {
+        unsigned s, e;
+        if (mode == 0) {
+            s = (unsigned)i + 1;
+            e = upper_bound_u32(key_c, (unsigned)n_cols, kmax_r[i]);
+            if (e < s) e = s;
+        } else if (mode == 1) {
+            s = lower_bound_u32(key_c, (unsigned)n_cols, key_r[i]);
+            e = upper_bound_u32(key_c, (unsigned)n_cols, kmax_r[i]);
+        } else {
+            s = upper_bound_u32(key_c, (unsigned)n_cols, key_r[i]);
+            e = upper_bound_u32(key_c, (unsigned)n_cols, kmax_r[i]);
+        }
+        if (e < s) e = s;
+        ranges[i] = make_uint2(s, e);
+        cnt = e - s;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane_id() == 0 && cnt) atomicAdd(candidates, cnt);
+}
+
+// ------------------------------------------------------------------------------------------
+struct ExactBox {
+    double lo[3], hi[3];
+    int v[3];
+    int eid;
+};
+__device__ __forceinline__ ExactBox load_exact(const sccd_aabb* __restrict__ b)
+{
+    const double4 q0 = reinterpret_cast<const double4*>(b)[0];
+    const double2 q1 = reinterpret_cast<const double2*>(b)[2];
+    const int4 q2 = reinterpret_cast<const int4*>(b)[3];
+    ExactBox r;
+    r.lo[0] = q0.x;
+    r.lo[1] = q0.y;
+    r.lo[2] = q0.z;
+    r.hi[0] = q0.w;
+    r.hi[1] = q1.x;
+    r.hi[2] = q1.y;
+    r.v[0] = q2.x;
+    r.v[1] = q2.y;
+    r.v[2] = q2.z;
+    r.eid = q2.w;
+    return r;
+}
+// AABB::intersects (aabb.cuh:68-73) && !share_a_vertex (collision.cuh:17-21)
+__device__ __forceinline__ bool exact_pair_ok(const ExactBox& a, const ExactBox& b)
+{
+    const bool geo = a.hi[0] >= b.lo[0] && a.lo[0] <= b.hi[0] && a.hi[1] >= b.lo[1] && a.lo[1] <= b.hi[1]
+        && a.hi[2] >= b.lo[2] && a.lo[2] <= b.hi[2];
+    const bool share = a.v[0] == b.v[0] || a.v[0] == b.v[1] || a.v[0] == b.v[2] || a.v[1] == b.v[0]
+        || a.v[1] == b.v[1] || a.v[1] == b.v[2] || a.v[2] == b.v[0] || a.v[2] == b.v[1] || a.v[2] == b.v[2];
+    return geo && !share;
+}
+// output convention: sweep.cu:152-163 / sort_and_sweep.cpp:106-118
+__device__ __forceinline__ int2 make_pair_out(int emit, int row_eid, int col_eid)
+{
+    if (emit == EMIT_ONE_LIST) return make_int2(min(row_eid, col_eid), max(row_eid, col_eid));
+    if (emit == EMIT_ROWS_A) return make_int2(row_eid, col_eid);
+    return make_int2(col_eid, row_eid);
+}
+
+// per-wave emission state (LDS staging + one global atomic per flush)
+struct Emitter {
+    int2* stage;     // LDS, SW_OCAP entries
+    int ocount;      // wave-uniform
+    int2* out;       // global
+    long long capacity;
+    unsigned long long* n_pairs;
+
+    __device__ __forceinline__ void flush()
+    {
+        if (ocount == 0) return;
+        unsigned long long base = 0;
+        if (lane_id() == 0) base = atomicAdd(n_pairs, (unsigned long long)ocount);
+        base = __shfl(base, 0, 64);
+        wave_lds_fence();
+        for (int k = lane_id(); k < ocount; k += 64) {
+            const unsigned long long dst = base + (unsigned long long)k;
+            if ((long long)dst < capacity) out[dst] = stage[k];
+        }
+        wave_lds_fence();
+        ocount = 0;
+    }
+    __device__ __forceinline__ void push(bool ok, int2 pr)
+    {
+        const unsigned long long mask = __ballot(ok);
+        if (mask == 0) return;
+        if (ok) stage[ocount + mbcnt64(mask)] = pr;
+        ocount += popc64(mask);
+        if (ocount > SW_OCAP - 64) flush();
+    }
+};
+
+__device__ __forceinline__ void confirm(bool active, uint2 cand, const sccd_aabb* __restrict__ box_r,
+                                        const sccd_aabb* __restrict__ box_c, int emit, Emitter& em)
+{
+    bool ok = false;
+    int2 pr = make_int2(0, 0);
+    if (active) {
+        const ExactBox a = load_exact(box_r + cand.x);
+        const ExactBox b = load_exact(box_c + cand.y);
+        ok = exact_pair_ok(a, b);
+        pr = make_pair_out(emit, a.eid, b.eid);
+    }
+    em.push(ok, pr);
+}
+
+__global__ __launch_bounds__(SW_THREADS) void sweep_stq_k(
+    const float4* __restrict__ filt_r, const sccd_aabb* __restrict__ box_r, const uint2* __restrict__ ranges,
+    int row_begin, int row_end, const float4* __restrict__ filt_c, const sccd_aabb* __restrict__ box_c, int emit,
+    int2* __restrict__ out, long long capacity, SweepCounters* __restrict__ cnt)
+{
+    __shared__ uint2 q_s[SW_WAVES][SW_QCAP];
+    __shared__ int2 o_s[SW_WAVES][SW_OCAP];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    uint2* q = q_s[w];
+    Emitter em { o_s[w], 0, out, capacity, &cnt->n_pairs };
+    int qcount = 0;
+    const int num_tiles = (row_end - row_begin + 63) / 64;
+
+    for (;;) {
+        unsigned tile = 0;
+        if (lane == 0) tile = atomicAdd(&cnt->tile_ticket, 1u);
+        tile = readfirst_u32(tile);
+        if ((int)tile >= num_tiles) break;
+
+        const int row = row_begin + (int)tile * 64 + lane;
+        const bool valid = row < row_end;
+        uint2 rg = make_uint2(0u, 0u);
+        float4 fr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+            rg = ranges[row];
+            fr = filt_r[row];
+        }
+        const bool nonempty = valid && rg.y > rg.x;
+        const unsigned jmin = readfirst_u32(wave_min_u32(nonempty ? rg.x : 0xFFFFFFFFu));
+        const unsigned jmax = readfirst_u32(wave_max_u32(nonempty ? rg.y : 0u));
+        if (jmin >= jmax) continue;
+
+        for (unsigned j0 = jmin & ~(unsigned)(SW_BLOCK - 1); j0 < jmax; j0 += SW_BLOCK) {
+            // this lane's live columns inside [j0, j0+32)
+            const unsigned lo = max(rg.x, j0), hi = min(rg.y, j0 + SW_BLOCK);
+            unsigned live = 0;
+            if (hi > lo) {
+                const unsigned len = hi - lo;
+                live = (len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u)) << (lo - j0);
+            }
+            unsigned m = 0;
+            const float4* __restrict__ cb = filt_c + j0; // wave-uniform address
+#pragma unroll
+            for (int b = 0; b < SW_BLOCK; b++) {
+                const float4 cc = cb[b];
+                const bool hit = (cc.x <= fr.y) & (fr.x <= cc.y) & (cc.z <= fr.w) & (fr.z <= cc.w);
+                m |= hit ? (1u << b) : 0u;
+            }
+            m &= live;
+            if (__ballot(m != 0) == 0) continue;
+
+            // ---- expand the hit masks into the candidate queue
+            const int mine = __popc(m);
+            const int incl = wave_incl_scan(mine);
+            const int total = (int)readfirst_u32((unsigned)__shfl(incl, 63, 64));
+            if (qcount + total <= SW_QCAP) {
+                int pos = qcount + incl - mine;
+                while (m) {
+                    const int b = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    q[pos++] = make_uint2((unsigned)row, j0 + (unsigned)b);
+                }
+                qcount += total;
+            } else {
+                // crowded block: one candidate per lane per round
+                for (;;) {
+                    const bool has = m != 0;
+                    const unsigned long long mask = __ballot(has);
+                    if (mask == 0) break;
+                    while (qcount > SW_QCAP - 64) {
+                        wave_lds_fence();
+                        const uint2 cand = q[qcount - 64 + lane];
+                        qcount -= 64;
+                        confirm(true, cand, box_r, box_c, emit, em);
+                    }
+                    if (has) {
+                        const int b = __ffs((int)m) - 1;
+                        m &= m - 1;
+                        q[qcount + mbcnt64(mask)] = make_uint2((unsigned)row, j0 + (unsigned)b);
+                    }
+                    qcount += popc64(mask);
+                }
+            }
+            // ---- confirm full batches
+            while (qcount >= 64) {
+                wave_lds_fence();
+                const uint2 cand = q[qcount - 64 + lane];
+                qcount -= 64;
+                confirm(true, cand, box_r, box_c, emit, em);
+            }
+        }
+    }
+    // drain
+    if (qcount > 0) {
+        wave_lds_fence();
+        const bool act = lane < qcount;
+        const uint2 cand = act ? q[lane] : make_uint2(0u, 0u);
+        confirm(act, cand, box_r, box_c, emit, em);
+    }
+    em.flush();
+}
+
+// Plain sweep-and-prune, one thread per row, exact boxes only (the reference's baseline
+// variant sweep_and_prune<>, sweep.cu:48-99).  Kept as an in-library cross-check of the STQ
+// kernel (SCCD_OPT_SWEEP_ALGO = 1); not tuned.
+__global__ void sweep_sap_k(const sccd_aabb* __restrict__ box_r, const uint2* __restrict__ ranges, int row_begin,
+                            int row_end, const sccd_aabb* __restrict__ box_c, int emit, int2* __restrict__ out,
+                            long long capacity, SweepCounters* __restrict__ cnt)
+{
+    const int row = row_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= row_end) return;
+    const uint2 rg = ranges[row];
+    const ExactBox a = load_exact(box_r + row);
+    for (unsigned j = rg.x; j < rg.y; j++) {
+        const ExactBox b = load_exact(box_c + j);
+        if (exact_pair_ok(a, b)) {
+            const unsigned long long dst = atomicAdd(&cnt->n_pairs, 1ull);
+            if ((long long)dst < capacity) out[dst] = make_pair_out(emit, a.eid, b.eid);
+        }
+    }
+}
+
+} // namespace
+
+void launch_ranges(sccd_ctx* c, const sccd_boxes* rows, const sccd_boxes* cols, int mode, uint2* ranges,
+                   unsigned long long* d_candidates)
+{
+    if (rows->n == 0) return;
+    const int grid = (rows->n + 255) / 256;
+    hipLaunchKernelGGL(ranges_k, dim3(grid), dim3(256), 0, c->stream, rows->key.as<uint32_t>(),
+                       rows->kmax.as<uint32_t>(), rows->n, cols->key.as<uint32_t>(), cols->n, mode, ranges,
+                       d_candidates);
+    SCCD_HIP(hipGetLastError());
+}
+
+void launch_sweep(sccd_ctx* c, const sccd_boxes* rows, const sccd_boxes* cols, const uint2* ranges, int row_begin,
+                  int row_end, int emit, int2* out, int64_t capacity, SweepCounters* d_cnt)
+{
+    if (row_end <= row_begin || cols->n == 0) return;
+    SCCD_HIP(hipMemsetAsync(&d_cnt->tile_ticket, 0, sizeof(unsigned), c->stream));
+    if (c->sweep_algo == 1) {
+        const int n = row_end - row_begin;
+        hipLaunchKernelGGL(sweep_sap_k, dim3((n + 255) / 256), dim3(256), 0, c->stream, rows->box.as<sccd_aabb>(),
+                           ranges, row_begin, row_end, cols->box.as<sccd_aabb>(), emit, out, (long long)capacity,
+                           d_cnt);
+    } else {
+        const int num_tiles = (row_end - row_begin + 63) / 64;
+        const int grid = std::max(1, std::min((num_tiles + SW_WAVES - 1) / SW_WAVES, c->num_cus * 4));
+        hipLaunchKernelGGL(sweep_stq_k, dim3(grid), dim3(SW_THREADS), 0, c->stream, rows->filt.as<float4>(),
+                           rows->box.as<sccd_aabb>(), ranges, row_begin, row_end, cols->filt.as<float4>(),
+                           cols->box.as<sccd_aabb>(), emit, out, (long long)capacity, d_cnt);
+    }
+    SCCD_HIP(hipGetLastError());
+}

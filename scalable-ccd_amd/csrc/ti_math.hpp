@@ -1,0 +1,266 @@
+// ti_math.hpp -- Tight-Inclusion arithmetic shared by the narrow-phase kernels.
+//
+// Restates, operation for operation, src/scalable_ccd/cuda/narrow_phase/root_finder.cu:21-254
+// and narrow_phase.cu:24-74 of the reference.  Compiled with -ffp-contract=off: the only fused
+// multiply-adds are the explicit __builtin_fma calls of ARITH == 1 (DESIGN.md "Arithmetic
+// contract"); ARITH == 0 rounds every product and sum separately in source order.
+#pragma once
+#include "common.hpp"
+
+#define TI_DBL_MAX 1.7976931348623157e308
+#define TI_DBL_EPS 2.220446049250313e-16
+
+// v[0..3] = v0s..v3s (t = 0), v[4..7] = v0e..v3e (t = 1)        (ccd_data.cuh:8-26)
+struct TIQuery {
+    double v[8][3];
+    double err[3];
+    double tol[3];
+};
+
+__device__ __forceinline__ double ti_min(double a, double b) { return (b < a) ? b : a; }
+__device__ __forceinline__ double ti_max(double a, double b) { return (a < b) ? b : a; }
+
+// add_data<is_vf> (narrow_phase.cu:24-74) on the packed mesh: one 64-byte record per vertex
+template <bool VF>
+__device__ __forceinline__ void ti_gather(const double* __restrict__ V, const int2* __restrict__ E,
+                                          const int4* __restrict__ F, int2 pr, double v[8][3])
+{
+    int id[4];
+    if (VF) { // :41-53  v0 = vertex, v1..v3 = face corners
+        const int4 f = F[pr.y];
+        id[0] = pr.x;
+        id[1] = f.x;
+        id[2] = f.y;
+        id[3] = f.z;
+    } else { // :54-66  v0,v1 = edge a, v2,v3 = edge b
+        const int2 ea = E[pr.x], eb = E[pr.y];
+        id[0] = ea.x;
+        id[1] = ea.y;
+        id[2] = eb.x;
+        id[3] = eb.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double4* rec = reinterpret_cast<const double4*>(V) + 2 * (size_t)id[k];
+        const double4 a = rec[0], b = rec[1];
+        v[k][0] = a.x;
+        v[k][1] = a.y;
+        v[k][2] = a.z;
+        v[k + 4][0] = b.x;
+        v[k + 4][1] = b.y;
+        v[k + 4][2] = b.z;
+    }
+}
+
+__device__ __forceinline__ double ti_linf(const double a[3], const double b[3])
+{
+    double m = fabs(b[0] - a[0]);
+    m = ti_max(m, fabs(b[1] - a[1]));
+    m = ti_max(m, fabs(b[2] - a[2]));
+    return m;
+}
+// max_Linf_4 (root_finder.cu:31-46)
+__device__ __forceinline__ double ti_max_linf_4(const double* p1, const double* p2, const double* p3,
+                                                const double* p4, const double* p1e, const double* p2e,
+                                                const double* p3e, const double* p4e)
+{
+    return ti_max(ti_max(ti_linf(p1, p1e), ti_linf(p2, p2e)), ti_max(ti_linf(p3, p3e), ti_linf(p4, p4e)));
+}
+
+// compute_face_vertex_tolerance / compute_edge_edge_tolerance (root_finder.cu:48-88)
+template <bool VF> __device__ __forceinline__ void ti_tolerance(const double v[8][3], double co_domain_tol, double tol[3])
+{
+    double p000[3], p001[3], p011[3], p010[3], p100[3], p101[3], p111[3], p110[3];
+    if (VF) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            p000[k] = v[0][k] - v[1][k];
+            p001[k] = v[0][k] - v[3][k];
+            p011[k] = v[0][k] - (v[2][k] + v[3][k] - v[1][k]);
+            p010[k] = v[0][k] - v[2][k];
+            p100[k] = v[4][k] - v[5][k];
+            p101[k] = v[4][k] - v[7][k];
+            p111[k] = v[4][k] - (v[6][k] + v[7][k] - v[5][k]);
+            p110[k] = v[4][k] - v[6][k];
+        }
+        tol[0] = co_domain_tol / (3 * ti_max_linf_4(p000, p001, p011, p010, p100, p101, p111, p110));
+        tol[1] = co_domain_tol / (3 * ti_max_linf_4(p000, p100, p101, p001, p010, p110, p111, p011));
+        tol[2] = co_domain_tol / (3 * ti_max_linf_4(p000, p100, p110, p010, p001, p101, p111, p011));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            p000[k] = v[0][k] - v[2][k];
+            p001[k] = v[0][k] - v[3][k];
+            p010[k] = v[1][k] - v[2][k];
+            p011[k] = v[1][k] - v[3][k];
+            p100[k] = v[4][k] - v[6][k];
+            p101[k] = v[4][k] - v[7][k];
+            p110[k] = v[5][k] - v[6][k];
+            p111[k] = v[5][k] - v[7][k];
+        }
+        // :82-87 -- tol[1] repeats the tol[0] pairing in the reference ("differs from
+        // Tight-Inclusion", :71-72); reproduced as is.
+        tol[0] = co_domain_tol / (3 * ti_max_linf_4(p000, p001, p011, p010, p100, p101, p111, p110));
+        tol[1] = tol[0];
+        tol[2] = co_domain_tol / (3 * ti_max_linf_4(p000, p100, p101, p001, p010, p110, p111, p011));
+    }
+}
+
+// get_numerical_error (root_finder.cu:90-135), double constants
+template <bool VF> __device__ __forceinline__ void ti_error(const double v[8][3], bool use_ms, double err[3])
+{
+    double filter;
+    if (!use_ms) filter = VF ? 6.661338147750939e-15 : 6.217248937900877e-15;
+    else filter = VF ? 7.549516567451064e-15 : 7.105427357601002e-15;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double m = fabs(v[0][k]);
+#pragma unroll
+        for (int j = 1; j < 8; j++) m = ti_max(m, fabs(v[j][k]));
+        m = ti_max(m, 1.0);
+        err[k] = m * m * m * filter;
+    }
+}
+
+// origin_in_inclusion_function (root_finder.cu:157-198) with calculate_vf / calculate_ee
+// (:137-155).  The reference evaluates all eight corners from scratch; the values that do not
+// depend on u or v are computed once per t here -- the same operations on the same operands,
+// hence the same bits.
+template <bool VF, int ARITH>
+__device__ __forceinline__ bool ti_inclusion(const double v[8][3], const double lo[3], const double hi[3],
+                                             const double err[3], double ms, double& true_tol, bool& box_in)
+{
+    double cmin[3], cmax[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double mn = TI_DBL_MAX, mx = -TI_DBL_MAX;
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const double t = it ? hi[0] : lo[0];
+            double a0, a1, a2, a3; // the four vertices at time t
+            if (ARITH == 1) {
+                a0 = __builtin_fma(v[4][k] - v[0][k], t, v[0][k]);
+                a1 = __builtin_fma(v[5][k] - v[1][k], t, v[1][k]);
+                a2 = __builtin_fma(v[6][k] - v[2][k], t, v[2][k]);
+                a3 = __builtin_fma(v[7][k] - v[3][k], t, v[3][k]);
+            } else {
+                a0 = (v[4][k] - v[0][k]) * t + v[0][k];
+                a1 = (v[5][k] - v[1][k]) * t + v[1][k];
+                a2 = (v[6][k] - v[2][k]) * t + v[2][k];
+                a3 = (v[7][k] - v[3][k]) * t + v[3][k];
+            }
+            if (VF) { // v - (t1 - t0)*u - (t2 - t0)*v - t0   with v=a0, t0=a1, t1=a2, t2=a3
+                const double d1 = a2 - a1, d2 = a3 - a1;
+#pragma unroll
+                for (int iu = 0; iu < 2; iu++) {
+                    const double u = iu ? hi[1] : lo[1];
+                    const double r1 = (ARITH == 1) ? __builtin_fma(-d1, u, a0) : a0 - d1 * u;
+#pragma unroll
+                    for (int iw = 0; iw < 2; iw++) {
+                        const double w = iw ? hi[2] : lo[2];
+                        const double r2 = (ARITH == 1) ? __builtin_fma(-d2, w, r1) : r1 - d2 * w;
+                        const double c = r2 - a1;
+                        mn = ti_min(mn, c);
+                        mx = ti_max(mx, c);
+                    }
+                }
+            } else { // ((ea1 - ea0)*u + ea0) - ((eb1 - eb0)*v + eb0)
+                const double da = a1 - a0, db = a3 - a2;
+                double x[2], y[2];
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const double u = i ? hi[1] : lo[1];
+                    const double w = i ? hi[2] : lo[2];
+                    x[i] = (ARITH == 1) ? __builtin_fma(da, u, a0) : da * u + a0;
+                    y[i] = (ARITH == 1) ? __builtin_fma(db, w, a2) : db * w + a2;
+                }
+#pragma unroll
+                for (int iu = 0; iu < 2; iu++)
+#pragma unroll
+                    for (int iw = 0; iw < 2; iw++) {
+                        const double c = x[iu] - y[iw];
+                        mn = ti_min(mn, c);
+                        mx = ti_max(mx, c);
+                    }
+            }
+        }
+        cmin[k] = mn;
+        cmax[k] = mx;
+    }
+    double wdt = cmax[0] - cmin[0];
+    wdt = ti_max(wdt, cmax[1] - cmin[1]);
+    wdt = ti_max(wdt, cmax[2] - cmin[2]);
+    true_tol = ti_max(0.0, wdt); // :183
+    box_in = true;
+    bool out = false, notin = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        out = out || (cmin[k] - ms > err[k]) || (cmax[k] + ms < -err[k]);   // :187-190
+        notin = notin || (cmin[k] + ms < -err[k]) || (cmax[k] - ms > err[k]); // :192-195
+    }
+    if (out) return false;
+    box_in = !notin;
+    return true;
+}
+
+// One ccd_kernel invocation (root_finder.cu:277-370) without the queue mechanics.
+// Returns true if the domain is accepted (min_t is a TOI candidate).  nk = 0,1,2 children:
+// child 0 = first half, child 1 = second half of dimension `split` at `mid`.
+struct TIStep {
+    bool accept;
+    int nk;
+    int split;
+    double mid;
+    bool checked;
+};
+template <bool VF, int ARITH>
+__device__ __forceinline__ TIStep ti_step(const TIQuery& q, const double lo[3], const double hi[3], double ms,
+                                          double co_domain_tol, bool allow_zero_toi, double prune_toi)
+{
+    TIStep r;
+    r.accept = false;
+    r.nk = 0;
+    r.split = 0;
+    r.mid = 0;
+    r.checked = false;
+    const double min_t = lo[0];
+    if (min_t >= prune_toi) return r; // :295
+    double true_tol;
+    bool box_in;
+    r.checked = true;
+    if (!ti_inclusion<VF, ARITH>(q.v, lo, hi, q.err, ms, true_tol, box_in)) return r;
+    const double w0 = hi[0] - lo[0], w1 = hi[1] - lo[1], w2 = hi[2] - lo[2];
+    const bool zero_ok = allow_zero_toi || min_t > 0;
+    if ((w0 <= q.tol[0] && w1 <= q.tol[1] && w2 <= q.tol[2])   // Condition 1 :322
+        || (box_in && zero_ok)                                 // Condition 2 :331
+        || (true_tol <= co_domain_tol && zero_ok)) {           // Condition 3 :340
+        r.accept = true;
+        return r;
+    }
+    // split_dimension :200-211
+    const double r0 = w0 / q.tol[0], r1 = w1 / q.tol[1], r2 = w2 / q.tol[2];
+    int split;
+    if (r0 >= r1 && r0 >= r2) split = 0;
+    else if (r1 >= r0 && r1 >= r2) split = 1;
+    else split = 2;
+    // bisect :213-254, SplitInterval interval.cuh:18-28
+    const double slo = split == 0 ? lo[0] : (split == 1 ? lo[1] : lo[2]);
+    const double shi = split == 0 ? hi[0] : (split == 1 ? hi[1] : hi[2]);
+    const double mid = (slo + shi) / 2;
+    if (slo >= mid || mid >= shi) { // Condition 4 :222-225, :362
+        r.accept = true;
+        return r;
+    }
+    r.split = split;
+    r.mid = mid;
+    r.nk = 1;
+    bool second;
+    if (split == 0) second = mid <= prune_toi; // :229-232
+    else if (VF) {
+        // sum_less_than_one (:21-29): u + v <= 1 / (1 - DBL_EPSILON)
+        const double other = (split == 1) ? lo[2] : lo[1];
+        second = (mid + other) <= 1 / (1 - TI_DBL_EPS);
+    } else second = true; // :248-250
+    if (second) r.nk = 2;
+    return r;
+}

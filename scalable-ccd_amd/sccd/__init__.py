@@ -1,0 +1,419 @@
+"""sccd -- Python host binding of libsccd_hip.so (the C ABI of include/sccd.h).
+
+Mirrors the reference's host API for the CCD hot path (names and argument meaning follow
+src/scalable_ccd/cuda/{ccd.cuh, broad_phase/broad_phase.cuh, broad_phase/aabb.cuh,
+narrow_phase/narrow_phase.cuh, ipc_ccd_strategy.hpp}):
+
+    toi = sccd.ccd(V0, V1, E, F, min_distance, max_iterations, tolerance, allow_zero_toi)
+    vb = sccd.build_vertex_boxes(V0, V1, inflation); eb = sccd.build_edge_boxes(vb, E); ...
+    bp = sccd.BroadPhase(); bp.build(sccd.DeviceAABBs(vb), sccd.DeviceAABBs(fb))
+    overlaps = bp.detect_overlaps()
+    toi = sccd.narrow_phase(mesh, overlaps, is_vf, max_iter, tol, ms, allow_zero_toi, toi)
+
+Errors raise RuntimeError like the reference's std::runtime_error.  There is no CPU fallback:
+importing works anywhere, but creating a Context without the HIP extension or without a GPU
+raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsccd_hip.so")
+_lib = None
+
+AABB_DTYPE = np.dtype(
+    [("min", "<f8", (3,)), ("max", "<f8", (3,)), ("vertex_ids", "<i4", (3,)), ("element_id", "<i4")],
+    align=True,
+)
+COLLISION_DTYPE = np.dtype([("aid", "<i4"), ("bid", "<i4"), ("toi", "<f8")], align=True)
+assert AABB_DTYPE.itemsize == 64 and COLLISION_DTYPE.itemsize == 16
+
+# sccd.h option ids
+OPT_ARITH, OPT_NARROW_ALGO, OPT_SWEEP_ALGO, OPT_SORT_AXIS = 1, 2, 3, 4
+OPT_SHARD_RANK, OPT_SHARD_COUNT, OPT_OVERLAP_CAPACITY, OPT_PROFILE, OPT_MAX_OVERLAP_CUTOFF = 5, 6, 7, 8, 9
+PROF_NAMES = ["boxes", "sort", "ranges", "sweep", "narrow"]
+
+# every symbol include/sccd.h declares (tests check that the library exports all of them)
+ABI_SYMBOLS = [
+    "sccd_create", "sccd_destroy", "sccd_last_error", "sccd_version", "sccd_set_stream", "sccd_synchronize",
+    "sccd_set_option", "sccd_get_option", "sccd_mesh_create", "sccd_mesh_update_vertices", "sccd_mesh_destroy",
+    "sccd_build_vertex_boxes", "sccd_build_edge_boxes", "sccd_build_face_boxes", "sccd_boxes_create",
+    "sccd_boxes_from_mesh", "sccd_boxes_size", "sccd_boxes_download", "sccd_boxes_destroy",
+    "sccd_broad_phase_create", "sccd_broad_phase_destroy", "sccd_broad_phase_build",
+    "sccd_broad_phase_detect_overlaps_partial", "sccd_broad_phase_detect_overlaps", "sccd_broad_phase_is_complete",
+    "sccd_broad_phase_num_boxes", "sccd_broad_phase_candidates", "sccd_free", "sccd_narrow_phase", "sccd_ccd",
+    "sccd_ccd_mesh", "sccd_ccd_mesh_prepare", "sccd_ccd_mesh_pass", "sccd_ipc_ccd_strategy", "sccd_get_profile", "sccd_reset_profile", "sccd_sort_pairs_u32",
+]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_vf_pairs", C.c_int64), ("n_ee_pairs", C.c_int64),
+        ("n_vf_candidates", C.c_int64), ("n_ee_candidates", C.c_int64),
+        ("n_vf_checks", C.c_int64), ("n_ee_checks", C.c_int64),
+        ("ms_boxes", C.c_double), ("ms_sort", C.c_double), ("ms_sweep", C.c_double),
+        ("ms_narrow", C.c_double), ("ms_total", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def lib():
+    """Load libsccd_hip.so; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"{_LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                "g.build()' or make).  There is no CPU fallback."
+            )
+        L = C.CDLL(_LIB_PATH)
+        L.sccd_last_error.restype = C.c_char_p
+        L.sccd_version.restype = C.c_char_p
+        L.sccd_get_option.restype = C.c_int64
+        L.sccd_broad_phase_num_boxes.restype = C.c_int64
+        L.sccd_broad_phase_candidates.restype = C.c_int64
+        L.sccd_destroy.restype = None
+        L.sccd_mesh_destroy.restype = None
+        L.sccd_boxes_destroy.restype = None
+        L.sccd_broad_phase_destroy.restype = None
+        L.sccd_free.restype = None
+        L.sccd_free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64cm(M):
+    return np.asfortranarray(np.asarray(M, dtype=np.float64))
+
+
+def _i32cm(M):
+    return np.asfortranarray(np.asarray(M, dtype=np.int32))
+
+
+class Context:
+    """One HIP device + stream + scratch memory (sccd_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib().sccd_create(C.c_int(device), C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError("sccd_create failed: " + lib().sccd_last_error(None).decode())
+
+    def close(self):
+        if self._h:
+            lib().sccd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"sccd error {rc}: " + lib().sccd_last_error(self._h).decode())
+
+    def set_option(self, opt, value):
+        self._check(lib().sccd_set_option(self._h, C.c_int(opt), C.c_int64(int(value))))
+
+    def get_option(self, opt):
+        return int(lib().sccd_get_option(self._h, C.c_int(opt)))
+
+    def set_stream(self, hip_stream):
+        self._check(lib().sccd_set_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else 0)))
+
+    def synchronize(self):
+        self._check(lib().sccd_synchronize(self._h))
+
+    def profile(self):
+        ms = (C.c_double * len(PROF_NAMES))()
+        n = (C.c_int64 * len(PROF_NAMES))()
+        self._check(lib().sccd_get_profile(self._h, ms, n))
+        return {k: (ms[i], int(n[i])) for i, k in enumerate(PROF_NAMES)}
+
+    def reset_profile(self):
+        self._check(lib().sccd_reset_profile(self._h))
+
+    def sort_pairs_u32(self, d_keys, d_vals, n):
+        """in-place radix sort of device arrays (raw device pointers)"""
+        self._check(lib().sccd_sort_pairs_u32(self._h, C.c_void_p(int(d_keys)), C.c_void_p(int(d_vals)), C.c_int64(n)))
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class Mesh:
+    """Device-resident V0, V1, E, F (the four DeviceMatrix objects of ccd.cu:103-106).
+
+    Host numpy arrays, or raw device pointers (ints, column-major) with on_device=True and
+    explicit sizes.
+    """
+
+    def __init__(self, V0, V1, E, F, ctx=None, on_device=False, nV=None, nE=None, nF=None):
+        self.ctx = ctx or default_context()
+        self._h = C.c_void_p()
+        if on_device:
+            self.nV, self.nE, self.nF = int(nV), int(nE), int(nF)
+            args = (_ptr(int(V0)), _ptr(int(V1)), C.c_int(self.nV), _ptr(int(E)), C.c_int(self.nE), _ptr(int(F)), C.c_int(self.nF))
+        else:
+            V0c, V1c, Ec, Fc = _f64cm(V0), _f64cm(V1), _i32cm(E), _i32cm(F)
+            if V0c.ndim != 2 or V0c.shape[1] != 3 or V0c.shape != V1c.shape:
+                raise RuntimeError("V0, V1 must both be n x 3")  # ccd.cu:94-96
+            if Ec.size and (Ec.ndim != 2 or Ec.shape[1] != 2):
+                raise RuntimeError("E must be m x 2")  # ccd.cu:97
+            if Fc.size and (Fc.ndim != 2 or Fc.shape[1] != 3):
+                raise RuntimeError("F must be k x 3")  # ccd.cu:98
+            self.nV, self.nE, self.nF = V0c.shape[0], Ec.shape[0] if Ec.size else 0, Fc.shape[0] if Fc.size else 0
+            if self.nE and (Ec.min() < 0 or Ec.max() >= self.nV):
+                raise RuntimeError("edge index out of range")
+            if self.nF and (Fc.min() < 0 or Fc.max() >= self.nV):
+                raise RuntimeError("face index out of range")
+            self._keep = (V0c, V1c, Ec, Fc)
+            args = (_ptr(V0c), _ptr(V1c), C.c_int(self.nV), _ptr(Ec), C.c_int(self.nE), _ptr(Fc), C.c_int(self.nF))
+        self.ctx._check(lib().sccd_mesh_create(self.ctx._h, *args, C.c_int(int(on_device)), C.byref(self._h)))
+        self._keep = None
+
+    def update_vertices(self, V0, V1, on_device=False):
+        if on_device:
+            self.ctx._check(lib().sccd_mesh_update_vertices(self._h, _ptr(int(V0)), _ptr(int(V1)), C.c_int(1)))
+        else:
+            V0c, V1c = _f64cm(V0), _f64cm(V1)
+            if V0c.shape != (self.nV, 3) or V1c.shape != (self.nV, 3):
+                raise RuntimeError("vertex matrices must keep their shape")
+            self.ctx._check(lib().sccd_mesh_update_vertices(self._h, _ptr(V0c), _ptr(V1c), C.c_int(0)))
+
+    def close(self):
+        if self._h:
+            lib().sccd_mesh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- boxes: build_*_boxes of aabb.cuh:156-188 ----------------------------------------------
+def build_vertex_boxes(V0, V1=None, inflation_radius=0.0, ctx=None):
+    ctx = ctx or default_context()
+    V0c = _f64cm(V0)
+    V1c = V0c if V1 is None else _f64cm(V1)
+    if V0c.ndim != 2 or V0c.shape[1] != 3 or V0c.shape != V1c.shape:
+        raise RuntimeError("vertices must be n x 3")
+    out = np.zeros(V0c.shape[0], AABB_DTYPE)
+    ctx._check(lib().sccd_build_vertex_boxes(ctx._h, _ptr(V0c), _ptr(V1c), C.c_int(V0c.shape[0]), C.c_double(inflation_radius), _ptr(out)))
+    return out
+
+
+def build_edge_boxes(vertex_boxes, E, ctx=None):
+    ctx = ctx or default_context()
+    vb = np.ascontiguousarray(vertex_boxes)
+    Ec = _i32cm(E).reshape(-1, 2, order="F") if np.size(E) else np.zeros((0, 2), np.int32, order="F")
+    out = np.zeros(Ec.shape[0], AABB_DTYPE)
+    ctx._check(lib().sccd_build_edge_boxes(ctx._h, _ptr(vb), C.c_int(len(vb)), _ptr(Ec), C.c_int(Ec.shape[0]), _ptr(out)))
+    return out
+
+
+def build_face_boxes(vertex_boxes, F, ctx=None):
+    ctx = ctx or default_context()
+    vb = np.ascontiguousarray(vertex_boxes)
+    Fc = _i32cm(F).reshape(-1, 3, order="F") if np.size(F) else np.zeros((0, 3), np.int32, order="F")
+    out = np.zeros(Fc.shape[0], AABB_DTYPE)
+    ctx._check(lib().sccd_build_face_boxes(ctx._h, _ptr(vb), C.c_int(len(vb)), _ptr(Fc), C.c_int(Fc.shape[0]), _ptr(out)))
+    return out
+
+
+class DeviceAABBs:
+    """Sorted device boxes (DeviceAABBs of aabb.cuh:122-150)."""
+
+    def __init__(self, boxes=None, ctx=None, _handle=None):
+        self.ctx = ctx or default_context()
+        self._h = C.c_void_p()
+        if _handle is not None:
+            self._h = _handle
+            return
+        b = np.ascontiguousarray(boxes, dtype=AABB_DTYPE)
+        self.ctx._check(lib().sccd_boxes_create(self.ctx._h, _ptr(b), C.c_int(len(b)), C.c_int(0), C.byref(self._h)))
+
+    @staticmethod
+    def from_mesh(mesh, inflation_radius=0.0):
+        """(vertex, edge, face) boxes built and sorted on the device (ccd.cu:112-121)."""
+        v, e, f = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        mesh.ctx._check(lib().sccd_boxes_from_mesh(mesh.ctx._h, mesh._h, C.c_double(inflation_radius), C.byref(v), C.byref(e), C.byref(f)))
+        return tuple(DeviceAABBs(ctx=mesh.ctx, _handle=h) for h in (v, e, f))
+
+    def size(self):
+        return int(lib().sccd_boxes_size(self._h))
+
+    def __len__(self):
+        return self.size()
+
+    def download(self):
+        out = np.zeros(self.size(), AABB_DTYPE)
+        self.ctx._check(lib().sccd_boxes_download(self._h, _ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().sccd_boxes_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BroadPhase:
+    """class BroadPhase of broad_phase.cuh:15-92."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+        self._h = C.c_void_p()
+        self.ctx._check(lib().sccd_broad_phase_create(self.ctx._h, C.byref(self._h)))
+        self._boxes = ()
+
+    def build(self, boxes_a, boxes_b=None):
+        self._boxes = (boxes_a, boxes_b)  # shared ownership, like the reference's shared_ptr
+        self.ctx._check(lib().sccd_broad_phase_build(self._h, boxes_a._h, boxes_b._h if boxes_b is not None else None))
+
+    def detect_overlaps_partial(self):
+        """-> (device pointer, n): valid until the next call (broad_phase.cuh:41-44)."""
+        p = C.c_void_p()
+        n = C.c_int64()
+        self.ctx._check(lib().sccd_broad_phase_detect_overlaps_partial(self._h, C.byref(p), C.byref(n)))
+        return (p.value or 0), n.value
+
+    def detect_overlaps(self):
+        """-> int32[n, 2] host array (std::vector<std::pair<int,int>> of broad_phase.cuh:50)."""
+        p = C.c_void_p()
+        n = C.c_int64()
+        self.ctx._check(lib().sccd_broad_phase_detect_overlaps(self._h, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            lib().sccd_free(p)
+            return np.zeros((0, 2), np.int32)
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), shape=(n.value, 2)).copy()
+        lib().sccd_free(p)
+        return arr
+
+    def is_complete(self):
+        return bool(lib().sccd_broad_phase_is_complete(self._h))
+
+    def num_boxes(self):
+        return int(lib().sccd_broad_phase_num_boxes(self._h))
+
+    def candidates(self):
+        return int(lib().sccd_broad_phase_candidates(self._h))
+
+    def close(self):
+        if self._h:
+            lib().sccd_broad_phase_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def narrow_phase(mesh, overlaps, is_vf, max_iter=-1, tol=1e-6, ms=0.0, allow_zero_toi=True, toi=1.0,
+                 want_collisions=False, n=None):
+    """narrow_phase<is_vf>() of narrow_phase.cuh:30-46.  overlaps: int32[n,2] host array, or a
+    raw device pointer with n given.  Returns toi, or (toi, collisions) with want_collisions."""
+    ctx = mesh.ctx
+    t = C.c_double(toi)
+    cp = C.c_void_p()
+    cn = C.c_int64()
+    if isinstance(overlaps, int):
+        args = (C.c_void_p(overlaps), C.c_int64(int(n)), C.c_int(1))
+    else:
+        ov = np.ascontiguousarray(overlaps, dtype=np.int32).reshape(-1, 2)
+        args = (_ptr(ov), C.c_int64(len(ov)), C.c_int(0))
+    ctx._check(lib().sccd_narrow_phase(
+        ctx._h, mesh._h, *args, C.c_int(int(is_vf)), C.c_int(max_iter), C.c_double(tol), C.c_double(ms),
+        C.c_int(int(allow_zero_toi)), C.byref(t), C.byref(cp) if want_collisions else None,
+        C.byref(cn) if want_collisions else None))
+    if not want_collisions:
+        return t.value
+    if cn.value:
+        col = np.frombuffer(C.string_at(cp, cn.value * COLLISION_DTYPE.itemsize), dtype=COLLISION_DTYPE).copy()
+    else:
+        col = np.zeros(0, COLLISION_DTYPE)
+    lib().sccd_free(cp)
+    return t.value, col
+
+
+def ccd(V0, V1, E, F, min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow_zero_toi=True, memory_limit_GB=0, ctx=None):
+    """scalable_ccd::cuda::ccd() of ccd.cuh:26-38: earliest time of impact in [0,1] (1 = none)."""
+    ctx = ctx or default_context()
+    V0c, V1c, Ec, Fc = _f64cm(V0), _f64cm(V1), _i32cm(E), _i32cm(F)
+    if V0c.ndim != 2 or V0c.shape[1] != 3 or V0c.shape != V1c.shape:
+        raise RuntimeError("V0, V1 must both be n x 3")
+    nE = Ec.shape[0] if Ec.size else 0
+    nF = Fc.shape[0] if Fc.size else 0
+    if (nE and Ec.shape[1] != 2) or (nF and Fc.shape[1] != 3):
+        raise RuntimeError("E must be m x 2 and F k x 3")
+    t = C.c_double(1.0)
+    ctx._check(lib().sccd_ccd(
+        ctx._h, _ptr(V0c), _ptr(V1c), C.c_int(V0c.shape[0]), _ptr(Ec) if nE else None, C.c_int(nE),
+        _ptr(Fc) if nF else None, C.c_int(nF), C.c_double(min_distance), C.c_int(max_iterations),
+        C.c_double(tolerance), C.c_int(int(allow_zero_toi)), C.c_int(memory_limit_GB), C.byref(t)))
+    return t.value
+
+
+def ccd_mesh(mesh, min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow_zero_toi=True, want_stats=False):
+    """ccd() on a device-resident mesh (what bench.py times).  -> toi or (toi, stats dict)."""
+    t = C.c_double(1.0)
+    st = Stats()
+    mesh.ctx._check(lib().sccd_ccd_mesh(
+        mesh.ctx._h, mesh._h, C.c_double(min_distance), C.c_int(max_iterations), C.c_double(tolerance),
+        C.c_int(int(allow_zero_toi)), C.byref(t), C.byref(st) if want_stats else None))
+    return (t.value, st.as_dict()) if want_stats else t.value
+
+
+def ccd_mesh_prepare(mesh, min_distance=0.0):
+    mesh.ctx._check(lib().sccd_ccd_mesh_prepare(mesh.ctx._h, mesh._h, C.c_double(min_distance)))
+
+
+def ccd_mesh_pass(mesh, is_vf, toi, min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow_zero_toi=True):
+    """One half of ccd() on this rank's shard.  -> (toi, stats dict)."""
+    t = C.c_double(toi)
+    st = Stats()
+    mesh.ctx._check(lib().sccd_ccd_mesh_pass(
+        mesh.ctx._h, mesh._h, C.c_int(int(is_vf)), C.c_double(min_distance), C.c_int(max_iterations),
+        C.c_double(tolerance), C.c_int(int(allow_zero_toi)), C.byref(t), C.byref(st)))
+    return t.value, st.as_dict()
+
+
+def ipc_ccd_strategy(V0, V1, E, F, min_distance=0.0, max_iterations=-1, tolerance=1e-6, ctx=None):
+    """ipc_ccd_strategy() of ipc_ccd_strategy.hpp:17-24."""
+    ctx = ctx or default_context()
+    V0c, V1c, Ec, Fc = _f64cm(V0), _f64cm(V1), _i32cm(E), _i32cm(F)
+    t = C.c_double(1.0)
+    ctx._check(lib().sccd_ipc_ccd_strategy(
+        ctx._h, _ptr(V0c), _ptr(V1c), C.c_int(V0c.shape[0]), _ptr(Ec), C.c_int(Ec.shape[0]), _ptr(Fc),
+        C.c_int(Fc.shape[0]), C.c_double(min_distance), C.c_int(max_iterations), C.c_double(tolerance), C.byref(t)))
+    return t.value

@@ -1,0 +1,320 @@
+"""GPU parity tests proper: the HIP path through the C ABI against the CPU oracle on the same
+seeded inputs.  Bars: boxes and overlap-pair sets bit-identical (compared as sorted sets);
+time of impact bit-equal (the stated tolerance of north_star is |dTOI| <= 1e-6; both arithmetic
+contracts are expected to agree exactly with the oracle run under the same contract)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from sccd import scenes
+
+pytestmark = pytest.mark.gpu
+TOI_TOL = 1e-6
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "golden.json")
+
+
+def _sorted(p):
+    p = np.ascontiguousarray(p, dtype=np.int32).reshape(-1, 2)
+    if len(p) == 0:
+        return p
+    return p[np.lexsort((p[:, 1], p[:, 0]))]
+
+
+def _scene(name):
+    return {
+        "cloth_ball_10k": lambda: scenes.cloth_ball(),
+        "cloth_ball_small": lambda: scenes.cloth_ball(20, 1, seed=3),
+        "soup_400": lambda: scenes.triangle_soup(400, seed=11),
+        "soup_dense": lambda: scenes.triangle_soup(1500, seed=5, size=0.08, motion=0.2),
+        "folded_120": lambda: scenes.folded_cloth(120),
+    }[name]()
+
+
+# ---- boxes ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("inflation", [0.0, 1e-3, 0.25])
+def test_build_boxes_bit_exact(sccd, ctx, orc, inflation):
+    V0, V1, E, F = scenes.cloth_ball(30, 2, seed=5)
+    # awkward coordinates: zeros, negatives, tiny and huge magnitudes
+    V0[0] = [0.0, -0.0, 1e-310]
+    V1[0] = [-1e-308, 0.0, -1e-310]
+    V0[1] = [1e300, -1e300, 5e-324]
+    V1[1] = [1e300, -1e300, 0.0]
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F, inflation)
+    g_vb = sccd.build_vertex_boxes(V0, V1, inflation, ctx=ctx)
+    g_eb = sccd.build_edge_boxes(g_vb, E, ctx=ctx)
+    g_fb = sccd.build_face_boxes(g_vb, F, ctx=ctx)
+    assert g_vb.tobytes() == vb.tobytes()
+    assert g_eb.tobytes() == eb.tobytes()
+    assert g_fb.tobytes() == fb.tobytes()
+
+
+def test_device_boxes_sorted_and_complete(sccd, ctx, orc):
+    V0, V1, E, F = _scene("cloth_ball_small")
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F)
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    for dev, ref in zip(sccd.DeviceAABBs.from_mesh(mesh, 0.0), (vb, eb, fb)):
+        got = dev.download()
+        assert len(got) == len(ref)
+        assert np.all(np.diff(got["min"][:, 0]) >= -1e-6)  # sorted on x up to the 32-bit key resolution
+        order = np.argsort(got["element_id"], kind="stable")
+        assert got[order].tobytes() == ref.tobytes()  # same multiset of boxes, bit for bit
+
+
+# ---- broad phase ------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["cloth_ball_10k", "soup_400", "soup_dense", "folded_120"])
+@pytest.mark.parametrize("algo", [0, 1])
+def test_overlap_pairs_identical(sccd, ctx, orc, name, algo):
+    V0, V1, E, F = _scene(name)
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F)
+    want_vf, _, _ = orc.sort_and_sweep(vb, fb, nthreads=8)
+    want_ee, _, _ = orc.sort_and_sweep(eb, nthreads=8)
+    ctx.set_option(sccd.OPT_SWEEP_ALGO, algo)
+    try:
+        bp = sccd.BroadPhase(ctx)
+        bp.build(sccd.DeviceAABBs(vb, ctx), sccd.DeviceAABBs(fb, ctx))
+        got_vf = bp.detect_overlaps()
+        assert bp.is_complete()
+        bp.build(sccd.DeviceAABBs(eb, ctx))
+        got_ee = bp.detect_overlaps()
+    finally:
+        ctx.set_option(sccd.OPT_SWEEP_ALGO, 0)
+    assert np.array_equal(_sorted(got_vf), want_vf)
+    assert np.array_equal(_sorted(got_ee), want_ee)
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_pair_set_independent_of_sort_axis(sccd, ctx, orc, axis):
+    boxes = scenes.random_boxes(20000, seed=3, max_extent=0.06)
+    want, _, _ = orc.sort_and_sweep(boxes, nthreads=8)
+    ctx.set_option(sccd.OPT_SORT_AXIS, axis)
+    try:
+        bp = sccd.BroadPhase(ctx)
+        bp.build(sccd.DeviceAABBs(boxes, ctx))
+        got = bp.detect_overlaps()
+    finally:
+        ctx.set_option(sccd.OPT_SORT_AXIS, 0)
+    assert np.array_equal(_sorted(got), want)
+
+
+def test_broad_phase_edge_cases(sccd, ctx, orc):
+    empty = np.zeros(0, sccd.AABB_DTYPE)
+    one = scenes.random_boxes(1)
+    bp = sccd.BroadPhase(ctx)
+    with pytest.raises(RuntimeError):  # broad_phase.cu:123-126
+        bp.detect_overlaps()
+    for a, b in ((empty, None), (one, None), (empty, one), (one, empty)):
+        bp.build(sccd.DeviceAABBs(a, ctx), sccd.DeviceAABBs(b, ctx) if b is not None else None)
+        assert len(bp.detect_overlaps()) == 0 and bp.is_complete()
+    # ties on the sort key, touching faces (inclusive test), identical boxes, shared vertices
+    b = np.zeros(6, sccd.AABB_DTYPE)
+    b["min"] = [[0, 0, 0], [1, 0, 0], [0, 0, 0], [2.5, 0, 0], [0, 1, 1], [0, 0, 0]]
+    b["max"] = [[1, 1, 1], [2, 1, 1], [1, 1, 1], [3, 1, 1], [1, 2, 2], [1, 1, 1]]
+    b["vertex_ids"] = [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11], [12, 13, 14], [0, 20, 21]]
+    b["element_id"] = np.arange(6)
+    want, _, _ = orc.sort_and_sweep(b)
+    assert [0, 1] in want.tolist() and [0, 5] not in want.tolist()  # touching counts, shared vertex does not
+    bp.build(sccd.DeviceAABBs(b, ctx))
+    assert np.array_equal(_sorted(bp.detect_overlaps()), want)
+
+
+def test_crowded_boxes_overflow_retry(sccd, ctx, orc):
+    # everything overlaps everything: exercises the crowded-block path of the candidate queue and
+    # the overlap-buffer overflow -> exact-size rerun (broad_phase.cu:142-203)
+    n = 1500
+    b = scenes.random_boxes(n, seed=8, max_extent=0.9)
+    want, _, _ = orc.sort_and_sweep(b, nthreads=8)
+    assert len(want) > 0.4 * n * (n - 1) / 2
+    ctx.set_option(sccd.OPT_OVERLAP_CAPACITY, 1000)
+    try:
+        bp = sccd.BroadPhase(ctx)
+        bp.build(sccd.DeviceAABBs(b, ctx))
+        got = bp.detect_overlaps()
+    finally:
+        ctx.set_option(sccd.OPT_OVERLAP_CAPACITY, 0)
+    assert np.array_equal(_sorted(got), want)
+
+
+def test_partial_cursor_covers_everything_once(sccd, ctx, orc):
+    V0, V1, E, F = _scene("soup_400")
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F)
+    want, _, _ = orc.sort_and_sweep(vb, fb)
+    ctx.set_option(sccd.OPT_MAX_OVERLAP_CUTOFF, 333)
+    try:
+        bp = sccd.BroadPhase(ctx)
+        bp.build(sccd.DeviceAABBs(vb, ctx), sccd.DeviceAABBs(fb, ctx))
+        calls = 0
+        while not bp.is_complete():
+            bp.detect_overlaps_partial()
+            calls += 1
+        assert calls == -(-(len(vb) + len(fb)) // 333)
+        bp.build(sccd.DeviceAABBs(vb, ctx), sccd.DeviceAABBs(fb, ctx))
+        got = bp.detect_overlaps()
+    finally:
+        ctx.set_option(sccd.OPT_MAX_OVERLAP_CUTOFF, 0)
+    assert np.array_equal(_sorted(got), want)
+
+
+def test_sharded_sweeps_partition_the_pair_set(sccd, ctx, orc):
+    V0, V1, E, F = _scene("cloth_ball_small")
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F)
+    want, _, _ = orc.sort_and_sweep(eb)
+    parts = []
+    try:
+        for r in range(3):
+            ctx.set_option(sccd.OPT_SHARD_COUNT, 3)
+            ctx.set_option(sccd.OPT_SHARD_RANK, r)
+            bp = sccd.BroadPhase(ctx)
+            bp.build(sccd.DeviceAABBs(eb, ctx))
+            parts.append(bp.detect_overlaps())
+    finally:
+        ctx.set_option(sccd.OPT_SHARD_COUNT, 1)
+        ctx.set_option(sccd.OPT_SHARD_RANK, 0)
+    assert all(len(p) > 0 for p in parts)
+    assert np.array_equal(_sorted(np.concatenate(parts)), want)  # disjoint and complete
+
+
+def test_random_100k_matches_golden_hash(sccd, ctx):
+    G = json.load(open(GOLDEN))["random_100k"]
+    b = scenes.random_boxes(100_000, seed=42, max_extent=0.027)
+    bp = sccd.BroadPhase(ctx)
+    bp.build(sccd.DeviceAABBs(b, ctx))
+    got = _sorted(bp.detect_overlaps())
+    assert len(got) == G["n"]
+    assert hashlib.sha256(got.tobytes()).hexdigest() == G["sha256"]
+
+
+# ---- narrow phase -----------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["cloth_ball_small", "soup_400", "cloth_ball_10k"])
+@pytest.mark.parametrize("arith", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1])
+def test_toi_matches_oracle(sccd, ctx, orc, name, arith, algo):
+    V0, V1, E, F = _scene(name)
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F)
+    vf, _, _ = orc.sort_and_sweep(vb, fb, nthreads=8)
+    ee, _, _ = orc.sort_and_sweep(eb, nthreads=8)
+    want_vf, _ = orc.narrow_phase_mt(V0, V1, E, F, vf, True, arith=arith, nthreads=8)
+    want_ee, _ = orc.narrow_phase_mt(V0, V1, E, F, ee, False, arith=arith, toi=want_vf, nthreads=8)
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    ctx.set_option(sccd.OPT_ARITH, arith)
+    ctx.set_option(sccd.OPT_NARROW_ALGO, algo)
+    try:
+        got_vf = sccd.narrow_phase(mesh, vf, True)
+        got_ee = sccd.narrow_phase(mesh, ee, False, toi=got_vf)
+    finally:
+        ctx.set_option(sccd.OPT_ARITH, 0)
+        ctx.set_option(sccd.OPT_NARROW_ALGO, 0)
+    assert abs(got_vf - want_vf) <= TOI_TOL and abs(got_ee - want_ee) <= TOI_TOL
+    assert got_vf == want_vf and got_ee == want_ee  # bit-equal under the same arithmetic contract
+
+
+@pytest.mark.parametrize("ms", [0.0, 1e-3])
+@pytest.mark.parametrize("allow_zero", [True, False])
+def test_narrow_phase_parameters(sccd, ctx, orc, ms, allow_zero):
+    V0, V1, E, F = _scene("cloth_ball_small")
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F, ms)
+    ee, _, _ = orc.sort_and_sweep(eb)
+    want, _ = orc.narrow_phase_mt(V0, V1, E, F, ee, False, ms=ms, allow_zero_toi=allow_zero, nthreads=8)
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    assert sccd.narrow_phase(mesh, ee, False, ms=ms, allow_zero_toi=allow_zero) == want
+
+
+def test_narrow_phase_known_answers(sccd, ctx):
+    V0 = np.array([[0.25, 0.25, 1.0], [0, 0, 0], [1, 0, 0], [0, 1, 0]], float)
+    V1 = V0.copy()
+    V1[0, 2] = -1.0
+    E = np.array([[1, 2], [2, 3], [1, 3]], np.int32)
+    F = np.array([[1, 2, 3]], np.int32)
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    t = sccd.narrow_phase(mesh, [[0, 0]], True)
+    assert 0.5 - 1e-5 <= t <= 0.5
+    assert sccd.narrow_phase(mesh, [[0, 0]], True, toi=0.25) == 0.25  # in/out bound (narrow_phase.cu:124)
+    assert sccd.narrow_phase(mesh, [[0, 0]], True, toi=0.0) == 0.0    # loop guard toi > 0 (:136)
+    assert sccd.narrow_phase(mesh, np.zeros((0, 2), np.int32), True) == 1.0
+    with pytest.raises(RuntimeError):
+        sccd.narrow_phase(mesh, [[0, 0]], True, toi=-1.0)  # assert(toi >= 0), narrow_phase.cu:126
+    with pytest.raises(RuntimeError):
+        sccd.narrow_phase(mesh, [[7, 0]], True)
+    V1[0, 2] = 0.5  # never reaches the triangle
+    mesh.update_vertices(V0, V1)
+    assert sccd.narrow_phase(mesh, [[0, 0]], True) == 1.0
+
+
+def test_per_query_collisions(sccd, ctx, orc):
+    V0, V1, E, F = scenes.triangle_soup(120, seed=6)
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F)
+    vf, _, _ = orc.sort_and_sweep(vb, fb)
+    want_t, want_pq, _ = orc.narrow_phase(V0, V1, E, F, vf, True, per_query=True)
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    t, col = sccd.narrow_phase(mesh, vf, True, want_collisions=True)
+    assert t == want_t
+    hits = want_pq < 1
+    assert len(col) == hits.sum()
+    got = {(int(a), int(b)): float(x) for a, b, x in zip(col["aid"], col["bid"], col["toi"])}
+    for (a, b), x in zip(vf[hits], want_pq[hits]):
+        assert got[(int(a), int(b))] == x
+    assert all(t <= x for x in got.values())  # tests/test_narrow_phase.cu:60-62
+
+
+# ---- end to end ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["cloth_ball_10k", "cloth_ball_10k_ms", "soup_400", "cloth_ball_small"])
+@pytest.mark.parametrize("arith", [0, 1])
+def test_ccd_matches_golden(sccd, ctx, name, arith):
+    G = json.load(open(GOLDEN))[name]
+    V0, V1, E, F = _scene(name.replace("_ms", ""))
+    ms = 1e-3 if name.endswith("_ms") else 0.0
+    ctx.set_option(sccd.OPT_ARITH, arith)
+    try:
+        toi = sccd.ccd(V0, V1, E, F, ms, -1, 1e-6, True, ctx=ctx)
+        mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+        toi2, st = sccd.ccd_mesh(mesh, ms, want_stats=True)
+    finally:
+        ctx.set_option(sccd.OPT_ARITH, 0)
+    want = float.fromhex(G["toi_fma" if arith else "toi_strict"])
+    assert toi == want and toi2 == want
+    assert st["n_vf_pairs"] == G["n_vf"] and st["n_ee_pairs"] == G["n_ee"]
+
+
+def test_ccd_argument_errors(sccd, ctx):
+    V0, V1, E, F = _scene("cloth_ball_small")
+    with pytest.raises(RuntimeError):
+        sccd.ccd(V0, V1[:-1], E, F, ctx=ctx)  # ccd.cu:94-95
+    bad = F.copy()
+    bad[0, 0] = len(V0)
+    with pytest.raises(RuntimeError):
+        sccd.ccd(V0, V1, E, bad, ctx=ctx)
+    assert sccd.ccd(V0, V0, E, F, ctx=ctx) == 1.0  # nothing moves, nothing intersects
+
+
+def test_ipc_ccd_strategy(sccd, ctx, orc):
+    V0, V1, E, F = _scene("cloth_ball_small")
+    t = sccd.ipc_ccd_strategy(V0, V1, E, F, 0.0, -1, 1e-6, ctx=ctx)
+    want, _, _ = orc.ccd(V0, V1, E, F)
+    assert t == want  # toi >= 1e-6: no conservative re-run (ipc_ccd_strategy.cu:72)
+    # resting contact at t = 0 forces the re-run: ms = 0, no zero toi, result scaled by 0.8 (:72-91)
+    V0 = np.array([[0.25, 0.25, 0.0], [0, 0, 0], [1, 0, 0], [0, 1, 0]], float)
+    V1 = V0.copy()
+    V1[0, 2] = -1.0
+    E = np.array([[1, 2], [2, 3], [1, 3]], np.int32)
+    F = np.array([[1, 2, 3]], np.int32)
+    t = sccd.ipc_ccd_strategy(V0, V1, E, F, 0.0, -1, 1e-6, ctx=ctx)
+    assert 0.0 <= t <= 1e-5
+
+
+def test_sort_is_a_stable_permutation(sccd, ctx):
+    import torch
+
+    for n in (1, 63, 4097, 300_000):
+        g = torch.Generator().manual_seed(n)
+        keys = torch.randint(0, 2**31 - 1, (n,), generator=g, dtype=torch.int64)
+        keys[: n // 3] &= 0xFF00  # many ties
+        k = keys.to(torch.int32).cuda()
+        v = torch.arange(n, dtype=torch.int32).cuda()
+        torch.cuda.synchronize()
+        ctx.sort_pairs_u32(k.data_ptr(), v.data_ptr(), n)
+        ctx.synchronize()
+        want_k, want_v = torch.sort(keys, stable=True)
+        assert torch.equal(k.cpu().to(torch.int64), want_k)
+        assert torch.equal(v.cpu().to(torch.int64), want_v)
