@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- CCD queries/s (broad + narrow phase) on MI355X, BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W [--workload cloth1m|clothball10k|boxes1m|sort16m]
+
+A step = one full pass of the hot path over one batch of synthetic input already resident in
+HBM: box build -> radix sort -> candidate ranges -> STQ sweep -> Tight-Inclusion narrow phase,
+for the VF list pair then the EE list (scalable_ccd::cuda::ccd(), ccd.cu:80-146).  With N > 1
+(one process per GPU, launched by torch.distributed.run) every rank sweeps its share of the
+candidates and runs the narrow phase on the pairs it found; the only exchange is the
+all-reduce(min) of the time of impact after each pass (RCCL) -- total work is fixed: strong
+scaling.
+
+Prints ONE JSON line (rank 0) with the contract keys plus `roofline` (dominant kernel class,
+algorithmic bytes / measured device time) and `cpu_baseline` (the CPU oracle on this box's
+host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "scalable-ccd_amd"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+# algorithmic bytes per unit (SURVEY.md 8d / DESIGN.md "Roofline")
+BYTES_PER_QUERY = 220.0       # narrow phase: pair 8 + element indices 12/16 + 24 coords + toi
+BYTES_SWEEP_PER_BOX = 64.0    # sweep: sorted box record, + 8 B per emitted pair
+BYTES_SORT_PER_KEY_PASS = 16  # one radix pass over (u32 key, u32 index): read 8 + write 8
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cloth1m", choices=["cloth1m", "clothball10k", "boxes1m", "sort16m"])
+    ap.add_argument("--cloth-n", type=int, default=708, help="cloth grid side for cloth1m (708 -> 999,698 tris)")
+    ap.add_argument("--arith", type=int, default=0, help="0 strict, 1 fused multiply-add contract")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-n", type=int, default=0, help="cloth side of the CPU sample (0 = auto)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import sccd
+    from sccd import dist as sdist
+    from sccd import scenes
+
+    ctx = sccd.Context(dev.index)
+    ctx.set_option(sccd.OPT_ARITH, args.arith)
+    ctx.set_option(sccd.OPT_SHARD_RANK, rank)
+    ctx.set_option(sccd.OPT_SHARD_COUNT, world)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    result = None
+    if args.workload in ("cloth1m", "clothball10k"):
+        if args.workload == "cloth1m":
+            V0, V1, E, F = scenes.folded_cloth(args.cloth_n)
+            wl = {"workload": f"folded cloth self-collision {args.cloth_n}x{args.cloth_n} ({len(F)} tris), full broad+narrow (BASELINE configs[3]/[4])"}
+        else:
+            V0, V1, E, F = scenes.cloth_ball()
+            wl = {"workload": f"cloth-ball 10k-tri two-frame pair ({len(F)} tris), full broad+narrow (BASELINE configs[1])"}
+        # inputs resident in HBM before the timed region: upload through torch tensors (column-major)
+        tV0 = torch.from_numpy(np.asfortranarray(V0).T.copy()).to(dev)  # [3][nV] contiguous == column-major nV x 3
+        tV1 = torch.from_numpy(np.asfortranarray(V1).T.copy()).to(dev)
+        tE = torch.from_numpy(np.ascontiguousarray(E.T)).to(dev)
+        tF = torch.from_numpy(np.ascontiguousarray(F.T)).to(dev)
+        torch.cuda.synchronize()
+        mesh = sccd.Mesh(tV0.data_ptr(), tV1.data_ptr(), tE.data_ptr(), tF.data_ptr(), ctx=ctx, on_device=True,
+                         nV=len(V0), nE=len(E), nF=len(F))
+        params = dict(min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow_zero_toi=True)
+
+        def step():
+            return sdist.ccd_sharded(
+                lambda is_vf, toi: sccd.ccd_mesh_pass(mesh, is_vf, toi, **params),
+                rank, world, device=dev, prepare=lambda: sccd.ccd_mesh_prepare(mesh, 0.0))
+
+        for _ in range(args.warmup):
+            step()
+        ctx.set_option(sccd.OPT_PROFILE, 1)
+        ctx.reset_profile()
+        barrier()
+        t0 = time.perf_counter()
+        q_local = 0
+        stats = {}
+        toi = 1.0
+        for _ in range(args.steps):
+            toi, stats = step()
+            q_local += stats["n_vf_pairs"] + stats["n_ee_pairs"]
+        barrier()
+        dt = time.perf_counter() - t0
+        prof = ctx.profile()
+        ctx.set_option(sccd.OPT_PROFILE, 0)
+        # max over ranks of the elapsed time, sum over ranks of the queries
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        qq = torch.tensor([float(q_local), float(stats["n_vf_checks"] + stats["n_ee_checks"]),
+                           float(stats["n_vf_candidates"] + stats["n_ee_candidates"])], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(qq, op=dist.ReduceOp.SUM)
+        dt = float(tt.item())
+        queries_per_step = float(qq[0].item()) / args.steps
+        value = float(qq[0].item()) / dt
+
+        # roofline of the dominant kernel class of this rank (device time from hipEvents on the ctx stream)
+        units = {
+            "narrow": (BYTES_PER_QUERY * q_local, "Tight-Inclusion np_queue_k / np_level_k"),
+            "sweep": ((BYTES_SWEEP_PER_BOX * (len(V0) + len(F) + len(E)) + 8.0 * q_local / args.steps) * args.steps, "sweep_stq_k"),
+            "sort": (BYTES_SORT_PER_KEY_PASS * 4 * (len(V0) + len(F) + len(E)) * args.steps, "radix sort (4 passes)"),
+            "boxes": (124.0 * (len(V0) + len(F) + len(E)) * args.steps, "box build + key/gather"),
+            "ranges": (28.0 * (len(V0) + len(F) + len(E)) * args.steps, "candidate ranges"),
+        }
+        dom = max(prof, key=lambda k: prof[k][0])
+        ms_dom, launches = prof[dom]
+        achieved = units[dom][0] / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
+        roofline = {
+            "bound": "hbm", "kernel": units[dom][1], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "avg_launch_ms": round(ms_dom / max(1, launches), 4), "launches": launches,
+            "class_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items()},
+        }
+        result = {
+            "metric": "CCD queries/sec (broad+narrow)", "value": value, "unit": "queries/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": dict(wl, queries_per_step=queries_per_step, toi=toi, arith=["strict", "fma"][args.arith],
+                           checks_per_step=float(qq[1].item()), candidates_per_step=float(qq[2].item()),
+                           parallelism=f"pairs sharded over {world} GPU(s), RCCL min-reduce of TOI"),
+            "min_toi_latency_ms": dt / args.steps * 1e3,
+            "roofline": roofline,
+        }
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, scenes)
+    elif args.workload == "boxes1m":
+        result = bench_boxes(args, ctx, sccd, scenes, torch)
+    else:
+        result = bench_sort(args, ctx, sccd, torch)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_boxes(args, ctx, sccd, scenes, torch):
+    """BASELINE configs[2]: 1M random AABBs, broad phase only."""
+    n = 1_000_000
+    boxes = scenes.random_boxes(n, seed=42, max_extent=0.027)
+    dboxes = sccd.DeviceAABBs(boxes, ctx)
+    bp = sccd.BroadPhase(ctx)
+
+    def step():
+        bp.build(dboxes)
+        return bp.detect_overlaps_partial()[1]
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_option(sccd.OPT_PROFILE, 1)
+    ctx.reset_profile()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    pairs = 0
+    for _ in range(args.steps):
+        pairs = step()
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile()
+    ms_sweep, launches = prof["sweep"]
+    achieved = (BYTES_SWEEP_PER_BOX * n + 8.0 * pairs) * args.steps / (ms_sweep * 1e-3) / 1e9
+    return {
+        "metric": "broad-phase boxes/sec", "value": n * args.steps / dt, "unit": "boxes/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "1M random AABBs, one list, sweep only (BASELINE configs[2])", "pairs": pairs,
+                   "candidates": bp.candidates()},
+        "roofline": {"bound": "hbm", "kernel": "sweep_stq_k", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "avg_launch_ms": round(ms_sweep / max(1, launches), 4),
+                     "candidate_tests_per_s": bp.candidates() * args.steps / (ms_sweep * 1e-3)},
+    }
+
+
+def bench_sort(args, ctx, sccd, torch):
+    """radix sort of 16M (u32 key, u32 index) pairs: the HBM-bound kernel of the broad phase."""
+    n = 16_000_000
+    g = torch.Generator(device="cuda").manual_seed(1)
+    keys0 = torch.randint(0, 2**31 - 1, (n,), generator=g, dtype=torch.int32, device="cuda")
+    vals0 = torch.arange(n, dtype=torch.int32, device="cuda")
+    keys, vals = keys0.clone(), vals0.clone()
+
+    def step():
+        keys.copy_(keys0)
+        vals.copy_(vals0)
+        torch.cuda.synchronize()
+        ctx.sort_pairs_u32(keys.data_ptr(), vals.data_ptr(), n)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_option(sccd.OPT_PROFILE, 1)
+    ctx.reset_profile()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    prof = ctx.profile()
+    ms, launches = prof["sort"]
+    ok = bool((keys[1:] >= keys[:-1]).all().item())
+    achieved = BYTES_SORT_PER_KEY_PASS * 4 * n * args.steps / (ms * 1e-3) / 1e9
+    return {
+        "metric": "radix sort keys/sec", "value": n * args.steps / (ms * 1e-3), "unit": "keys/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms / args.steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "16M (u32 key, u32 index) pairs, 4 x 8-bit LSD passes", "sorted": ok},
+        "roofline": {"bound": "hbm", "kernel": "rs_count_k + rs_scan_k + rs_scatter_k x 4", "achieved": round(achieved, 2),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None},
+    }
+
+
+def cpu_baseline(args, scenes):
+    """The CPU oracle (kind 'port': the reference's CPU broad phase restated + the build's own
+    CPU Tight-Inclusion; the reference has no CPU narrow phase) on all host cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+
+    cores = os.cpu_count() or 1
+    if args.workload == "clothball10k":
+        V0, V1, E, F = scenes.cloth_ball()
+        sample = "the full 10k-tri cloth-ball scene"
+    else:
+        n = args.cpu_sample_n or args.cloth_n
+        V0, V1, E, F = scenes.folded_cloth(n)
+        sample = f"folded cloth {n}x{n} ({len(F)} tris): same generator as the GPU workload"
+    orc.ccd(V0[:64], V1[:64], E[:1], F[:1], nthreads=cores)  # warm the thread pool
+    t0 = time.perf_counter()
+    toi, n_vf, n_ee = orc.ccd(V0, V1, E, F, 0.0, -1, 1e-6, True, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": (n_vf + n_ee) / dt, "unit": "queries/s", "cores": cores, "kind": "port", "sample": sample,
+            "seconds": round(dt, 3), "toi": toi}
+
+
+if __name__ == "__main__":
+    main()

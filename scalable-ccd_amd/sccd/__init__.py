@@ -70,6 +70,14 @@ def lib():
                 f"{_LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
                 "g.build()' or make).  There is no CPU fallback."
             )
+        # PyTorch-ROCm bundles its own HIP runtime under the same soname (libamdhip64.so.7).  Two
+        # HIP runtimes in one process do not work, so when torch is installed it is imported
+        # FIRST and libsccd_hip.so binds to the runtime torch already loaded.
+        if os.environ.get("SCCD_NO_TORCH", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(_LIB_PATH)
         L.sccd_last_error.restype = C.c_char_p
         L.sccd_version.restype = C.c_char_p

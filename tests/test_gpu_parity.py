@@ -126,7 +126,7 @@ def test_crowded_boxes_overflow_retry(sccd, ctx, orc):
     n = 1500
     b = scenes.random_boxes(n, seed=8, max_extent=0.9)
     want, _, _ = orc.sort_and_sweep(b, nthreads=8)
-    assert len(want) > 0.4 * n * (n - 1) / 2
+    assert len(want) > 0.25 * n * (n - 1) / 2
     ctx.set_option(sccd.OPT_OVERLAP_CAPACITY, 1000)
     try:
         bp = sccd.BroadPhase(ctx)
@@ -285,7 +285,11 @@ def test_ccd_argument_errors(sccd, ctx):
     bad[0, 0] = len(V0)
     with pytest.raises(RuntimeError):
         sccd.ccd(V0, V1, E, bad, ctx=ctx)
-    assert sccd.ccd(V0, V0, E, F, ctx=ctx) == 1.0  # nothing moves, nothing intersects
+    # nothing moves: the reference's EE tol[1] quirk (root_finder.cu:82-85) makes coplanar static
+    # edges "collide" at t = 0; the restatement and the HIP path reproduce that
+    from orc import ccd as oracle_ccd
+
+    assert sccd.ccd(V0, V0, E, F, ctx=ctx) == oracle_ccd(V0, V0, E, F)[0] == 0.0
 
 
 def test_ipc_ccd_strategy(sccd, ctx, orc):
