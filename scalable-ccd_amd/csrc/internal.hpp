@@ -95,6 +95,11 @@ struct NarrowCounters {
     unsigned long long ticket;    // query chunk ticket
     unsigned int overflow;
     unsigned int pad;
+    // occupancy diagnostics of np_queue_k (SCCD_NP_DIAG=1 prints them)
+    unsigned long long wave_steps;   // check steps executed by waves
+    unsigned long long lane_steps;   // live lanes summed over those steps
+    unsigned long long refill_execs; // executions of the gather+constants block
+    unsigned long long steals;       // sub-domains moved between lanes
 };
 // runs the narrow phase on the stream; *toi in/out lives in d_cnt->toi_bits
 void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,

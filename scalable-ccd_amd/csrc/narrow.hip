@@ -214,6 +214,10 @@ void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
     }
     SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
     SCCD_HIP(hipStreamSynchronize(c->stream));
+    if (std::getenv("SCCD_NP_DIAG") && h.wave_steps)
+        std::fprintf(stderr, "[sccd np] n=%lld checks=%llu wave_steps=%llu lane_util=%.3f refill_execs=%llu steals=%llu\n",
+                     n, h.n_checks, h.wave_steps, (double)h.lane_steps / (64.0 * (double)h.wave_steps), h.refill_execs,
+                     h.steals);
     if (h.overflow) throw SccdError { SCCD_E_OVERFLOW, "narrow phase: work pool spill area exhausted" };
     std::memcpy(h_toi_inout, &h.toi_bits, 8);
     c->prof_launches[SCCD_PROF_NARROW] += 0;
