@@ -2,6 +2,7 @@
 // (ccd(), BroadPhase, narrow_phase, ipc_ccd_strategy of the reference, see sccd.h for the
 // file:line each entry point replaces).  Host code only; kernels live in the other .hip files.
 #include "internal.hpp"
+#include "grid.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -33,9 +34,7 @@ template <class Fn> static int guarded(sccd_ctx* c, Fn&& fn)
 
 // pipeline objects cached in the context so that repeated ccd() calls allocate nothing
 struct Pipeline {
-    DevBuf raw_v, raw_e, raw_f; // unsorted AoS boxes
-    DevBuf idx;                 // sort permutation
-    sccd_boxes vb, eb, fb;
+    sccd_boxes vb, eb, fb; // boxes in element order (raw)
     sccd_broad_phase bp;
 };
 static Pipeline* pipeline_of(sccd_ctx* c)
@@ -284,35 +283,6 @@ extern "C" void sccd_mesh_destroy(sccd_mesh* m)
 // ------------------------------------------------------------------------------------------
 // boxes
 
-// sort `raw` (device AoS, n boxes) into `b` along the configured axis
-static void boxes_sort_into(sccd_ctx* c, const sccd_aabb* raw, int n, DevBuf& idx, sccd_boxes* b)
-{
-    b->n = n;
-    int axis = c->sort_axis;
-    if (axis < 0) axis = pick_sort_axis(c, raw, n);
-    b->axis = axis;
-    const size_t pad = 64; // the sweep streams whole 32-column blocks
-    b->key.ensure(sizeof(uint32_t) * ((size_t)n + pad));
-    b->kmax.ensure(sizeof(uint32_t) * ((size_t)n + pad));
-    b->filt.ensure(sizeof(float4) * ((size_t)n + pad));
-    b->box.ensure(sizeof(sccd_aabb) * ((size_t)n + 1));
-    idx.ensure(sizeof(uint32_t) * ((size_t)n + pad));
-    if (n == 0) return;
-    {
-        ProfScope ps(c, SCCD_PROF_BOXES);
-        launch_box_keys(c, raw, n, axis, b->key.as<uint32_t>(), idx.as<uint32_t>());
-    }
-    {
-        ProfScope ps(c, SCCD_PROF_SORT);
-        radix_sort_pairs_u32(c, b->key.as<uint32_t>(), idx.as<uint32_t>(), n);
-    }
-    {
-        ProfScope ps(c, SCCD_PROF_BOXES);
-        launch_box_gather(c, raw, idx.as<uint32_t>(), n, axis, b->box.as<sccd_aabb>(), b->filt.as<float4>(),
-                          b->kmax.as<uint32_t>());
-    }
-}
-
 extern "C" int sccd_build_vertex_boxes(sccd_ctx* c, const double* V0, const double* V1, int nV, double r,
                                        sccd_aabb* out)
 {
@@ -382,39 +352,33 @@ extern "C" int sccd_boxes_create(sccd_ctx* c, const sccd_aabb* boxes, int n, int
         SCCD_REQUIRE(n >= 0 && (n == 0 || boxes), "boxes_create: bad arguments");
         std::unique_ptr<sccd_boxes> b(new sccd_boxes());
         b->ctx = c;
-        const sccd_aabb* raw = boxes;
-        if (!src_on_device && n > 0) {
-            c->np_scratch3.ensure(sizeof(sccd_aabb) * (size_t)n);
-            copy_in(c, c->np_scratch3.p, boxes, sizeof(sccd_aabb) * (size_t)n, 0);
-            raw = c->np_scratch3.as<sccd_aabb>();
-        }
-        DevBuf idx;
-        boxes_sort_into(c, raw, n, idx, b.get());
+        b->n = n;
+        b->raw.ensure(sizeof(sccd_aabb) * (size_t)std::max(n, 1));
+        copy_in(c, b->raw.p, boxes, sizeof(sccd_aabb) * (size_t)n, src_on_device);
         SCCD_HIP(hipStreamSynchronize(c->stream));
         *out = b.release();
     });
 }
 
-// vertex boxes -> (edge, face) boxes -> sorted lists, all on the device (ccd.cu:112-121)
+// vertex boxes -> (edge, face) boxes, all on the device (ccd.cu:112-121 without the host trip)
 static void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline* pl, bool want_v, bool want_e,
                             bool want_f)
 {
-    pl->raw_v.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nV, 1));
-    {
-        ProfScope ps(c, SCCD_PROF_BOXES);
-        launch_vertex_boxes(c, m->V.as<double>(), m->nV, r, pl->raw_v.as<sccd_aabb>());
-        if (want_e) {
-            pl->raw_e.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nE, 1));
-            launch_edge_boxes(c, pl->raw_v.as<sccd_aabb>(), m->E.as<int2>(), m->nE, pl->raw_e.as<sccd_aabb>());
-        }
-        if (want_f) {
-            pl->raw_f.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nF, 1));
-            launch_face_boxes(c, pl->raw_v.as<sccd_aabb>(), m->F.as<int4>(), m->nF, pl->raw_f.as<sccd_aabb>());
-        }
+    (void)want_v;
+    ProfScope ps(c, SCCD_PROF_BOXES);
+    pl->vb.n = m->nV;
+    pl->vb.raw.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nV, 1));
+    launch_vertex_boxes(c, m->V.as<double>(), m->nV, r, pl->vb.raw.as<sccd_aabb>());
+    if (want_e) {
+        pl->eb.n = m->nE;
+        pl->eb.raw.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nE, 1));
+        launch_edge_boxes(c, pl->vb.raw.as<sccd_aabb>(), m->E.as<int2>(), m->nE, pl->eb.raw.as<sccd_aabb>());
     }
-    if (want_v) boxes_sort_into(c, pl->raw_v.as<sccd_aabb>(), m->nV, pl->idx, &pl->vb);
-    if (want_e) boxes_sort_into(c, pl->raw_e.as<sccd_aabb>(), m->nE, pl->idx, &pl->eb);
-    if (want_f) boxes_sort_into(c, pl->raw_f.as<sccd_aabb>(), m->nF, pl->idx, &pl->fb);
+    if (want_f) {
+        pl->fb.n = m->nF;
+        pl->fb.raw.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nF, 1));
+        launch_face_boxes(c, pl->vb.raw.as<sccd_aabb>(), m->F.as<int4>(), m->nF, pl->fb.raw.as<sccd_aabb>());
+    }
 }
 
 static sccd_boxes* clone_boxes(sccd_ctx* c, const sccd_boxes& s)
@@ -422,18 +386,8 @@ static sccd_boxes* clone_boxes(sccd_ctx* c, const sccd_boxes& s)
     std::unique_ptr<sccd_boxes> b(new sccd_boxes());
     b->ctx = c;
     b->n = s.n;
-    b->axis = s.axis;
-    const size_t pad = 64, n = (size_t)s.n;
-    b->key.ensure(sizeof(uint32_t) * (n + pad));
-    b->kmax.ensure(sizeof(uint32_t) * (n + pad));
-    b->filt.ensure(sizeof(float4) * (n + pad));
-    b->box.ensure(sizeof(sccd_aabb) * (n + 1));
-    if (n) {
-        copy_in(c, b->key.p, s.key.p, sizeof(uint32_t) * n, 1);
-        copy_in(c, b->kmax.p, s.kmax.p, sizeof(uint32_t) * n, 1);
-        copy_in(c, b->filt.p, s.filt.p, sizeof(float4) * n, 1);
-        copy_in(c, b->box.p, s.box.p, sizeof(sccd_aabb) * n, 1);
-    }
+    b->raw.ensure(sizeof(sccd_aabb) * (size_t)std::max(s.n, 1));
+    copy_in(c, b->raw.p, s.raw.p, sizeof(sccd_aabb) * (size_t)s.n, 1);
     return b.release();
 }
 
@@ -443,7 +397,7 @@ extern "C" int sccd_boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, s
     if (!c || !m) return SCCD_E_INVALID;
     return guarded(c, [&] {
         Pipeline* pl = pipeline_of(c);
-        boxes_from_mesh(c, m, r, pl, vb != nullptr, eb != nullptr, fb != nullptr);
+        boxes_from_mesh(c, m, r, pl, true, eb != nullptr, fb != nullptr);
         if (vb) *vb = clone_boxes(c, pl->vb);
         if (eb) *eb = clone_boxes(c, pl->eb);
         if (fb) *fb = clone_boxes(c, pl->fb);
@@ -458,7 +412,7 @@ extern "C" int sccd_boxes_download(const sccd_boxes* b, sccd_aabb* out)
     if (!b || !out) return SCCD_E_INVALID;
     return guarded(b->ctx, [&] {
         if (b->n == 0) return;
-        SCCD_HIP(hipMemcpyAsync(out, b->box.p, sizeof(sccd_aabb) * (size_t)b->n, hipMemcpyDeviceToHost,
+        SCCD_HIP(hipMemcpyAsync(out, b->raw.p, sizeof(sccd_aabb) * (size_t)b->n, hipMemcpyDeviceToHost,
                                 b->ctx->stream));
         SCCD_HIP(hipStreamSynchronize(b->ctx->stream));
     });
@@ -490,18 +444,100 @@ extern "C" void sccd_broad_phase_destroy(sccd_broad_phase* bp)
     delete bp;
 }
 
+// cell size = SCCD_CELL_FACTOR x mean box extent per minor axis (grid_setup_k)
+static double cell_factor()
+{
+    const char* e = std::getenv("SCCD_CELL_FACTOR");
+    const double f = e ? std::atof(e) : 4.0;
+    return f > 0 ? f : 1e300; // <= 0 switches the grid off (one cell)
+}
+
+// count -> scan -> fill -> sort -> gather for one list.  Returns false when the replication
+// into cells exceeded the budget (the caller then coarsens the grid).
+static bool build_sorted_list(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, bool can_shrink, SortedList* L)
+{
+    const int n = b->n;
+    L->m = 0;
+    if (n == 0) return true;
+    uint32_t* d_total = reinterpret_cast<uint32_t*>(c->scalars.as<char>() + 1536);
+    c->tmp0.ensure(sizeof(uint32_t) * ((size_t)n + 64));
+    uint32_t* counts = c->tmp0.as<uint32_t>();
+    {
+        ProfScope ps(c, SCCD_PROF_BOXES);
+        launch_cell_count(c, b->raw.as<sccd_aabb>(), n, gp, counts);
+    }
+    uint32_t total = 0;
+    {
+        ProfScope ps(c, SCCD_PROF_SORT);
+        exclusive_scan_u32(c, counts, counts, n, d_total);
+        SCCD_HIP(hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+    }
+    if (can_shrink && (int64_t)total > std::max<int64_t>(3 * (int64_t)n, (int64_t)n + 4096)) return false;
+    SCCD_REQUIRE(total < (1u << 31), "broad phase: too many cell entries");
+    const size_t m = total, pad = 64; // the sweep streams whole 32-column blocks
+    L->m = (int)m;
+    L->key.ensure(sizeof(uint32_t) * (m + pad));
+    L->kmax.ensure(sizeof(uint32_t) * (m + pad));
+    L->filt.ensure(sizeof(float4) * (m + pad));
+    L->box.ensure(sizeof(sccd_aabb) * (m + 1));
+    L->idx.ensure(sizeof(uint32_t) * (m + pad));
+    {
+        ProfScope ps(c, SCCD_PROF_BOXES);
+        launch_cell_fill(c, b->raw.as<sccd_aabb>(), n, gp, counts, L->key.as<uint32_t>(), L->idx.as<uint32_t>());
+    }
+    {
+        ProfScope ps(c, SCCD_PROF_SORT);
+        radix_sort_pairs_u32(c, L->key.as<uint32_t>(), L->idx.as<uint32_t>(), (int64_t)m);
+    }
+    {
+        ProfScope ps(c, SCCD_PROF_BOXES);
+        launch_entry_gather(c, b->raw.as<sccd_aabb>(), L->key.as<uint32_t>(), L->idx.as<uint32_t>(), (int)m, gp,
+                            L->box.as<sccd_aabb>(), L->filt.as<float4>(), L->kmax.as<uint32_t>());
+    }
+    return true;
+}
+
+// BroadPhase::build (broad_phase.cu:29-101) together with the key split + sort the reference
+// does in the DeviceAABBs constructor (aabb.cu:75-111): the lists are sorted HERE because the
+// cell grid is derived from both lists of the build.
 static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes* B)
 {
+    sccd_ctx* c = bp->ctx;
     SCCD_REQUIRE(A != nullptr, "BroadPhase::build: boxes are null");
-    SCCD_REQUIRE(!B || A->axis == B->axis, "BroadPhase::build: lists sorted along different axes");
     bp->A = A;
     bp->B = B;
     bp->built = true;
     bp->cursor = 0;
     bp->n_overlaps = 0;
     bp->candidates = 0;
+    bp->la.m = bp->lb.m = 0;
+    bp->total_rows = 0;
     // two lists with an empty side produce nothing (sort_and_sweep.cpp:221-223)
-    bp->total_rows = B ? ((A->n == 0 || B->n == 0) ? 0 : (int64_t)A->n + B->n) : A->n;
+    if (A->n == 0 || (B && B->n == 0)) return;
+
+    bp->grid.ensure(1024);
+    GridStats* st = bp->grid.as<GridStats>();
+    GridParams* gp = reinterpret_cast<GridParams*>(bp->grid.as<char>() + 512);
+    int axis = c->sort_axis;
+    if (axis < 0) axis = pick_sort_axis(c, A->raw.as<sccd_aabb>(), A->n);
+    {
+        ProfScope ps(c, SCCD_PROF_BOXES);
+        SCCD_HIP(hipMemsetAsync(st, 0, sizeof(GridStats), c->stream));
+        SCCD_HIP(hipMemsetAsync(st->kmin, 0xFF, sizeof(st->kmin), c->stream));
+        launch_box_stats(c, A->raw.as<sccd_aabb>(), A->n, st);
+        if (B) launch_box_stats(c, B->raw.as<sccd_aabb>(), B->n, st);
+    }
+    const int n_total = A->n + (B ? B->n : 0);
+    const double cf = cell_factor();
+    for (int shrink = 0;; shrink++) {
+        launch_grid_setup(c, st, n_total, axis, cf, shrink, gp);
+        const bool can_shrink = shrink < 10;
+        if (!build_sorted_list(c, A, gp, can_shrink, &bp->la)) continue;
+        if (B && !build_sorted_list(c, B, gp, can_shrink, &bp->lb)) continue;
+        break;
+    }
+    bp->total_rows = (int64_t)bp->la.m + (B ? bp->lb.m : 0);
 }
 
 extern "C" int sccd_broad_phase_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes* B)
@@ -554,8 +590,9 @@ static void bp_detect_partial(sccd_broad_phase* bp)
     if (!bp->built) throw SccdError { SCCD_E_NOT_BUILT, "Must initialize build broad phase before detecting overlaps!" };
     bp->n_overlaps = 0;
     if (bp->cursor >= bp->total_rows) return;
-    const sccd_boxes* A = bp->A;
-    const sccd_boxes* B = bp->B;
+    const SortedList* A = &bp->la;
+    const SortedList* B = bp->B ? &bp->lb : nullptr;
+    const GridParams* gp = reinterpret_cast<const GridParams*>(bp->grid.as<char>() + 512);
     const int64_t cutoff = c->max_overlap_cutoff > 0 ? c->max_overlap_cutoff : bp->total_rows;
     const int64_t chunk_lo = bp->cursor, chunk_hi = std::min(bp->cursor + cutoff, bp->total_rows);
 
@@ -566,22 +603,22 @@ static void bp_detect_partial(sccd_broad_phase* bp)
     if (bp->cursor == 0) {
         SCCD_HIP(hipMemsetAsync(d_cnt, 0, sizeof(SweepCounters), c->stream));
         ProfScope ps(c, SCCD_PROF_RANGES);
-        bp->ranges_a.ensure(sizeof(uint2) * (size_t)std::max(A->n, 1));
+        bp->ranges_a.ensure(sizeof(uint2) * (size_t)std::max(A->m, 1));
         if (!B) {
             launch_ranges(c, A, A, 0, bp->ranges_a.as<uint2>(), d_cand);
         } else {
-            bp->ranges_b.ensure(sizeof(uint2) * (size_t)std::max(B->n, 1));
+            bp->ranges_b.ensure(sizeof(uint2) * (size_t)std::max(B->m, 1));
             launch_ranges(c, A, B, 1, bp->ranges_a.as<uint2>(), d_cand);
             launch_ranges(c, B, A, 2, bp->ranges_b.as<uint2>(), d_cand);
         }
     }
 
     // rows of this chunk per sweep class
-    int a_lo = (int)std::min<int64_t>(chunk_lo, A->n), a_hi = (int)std::min<int64_t>(chunk_hi, A->n);
+    int a_lo = (int)std::min<int64_t>(chunk_lo, A->m), a_hi = (int)std::min<int64_t>(chunk_hi, A->m);
     int b_lo = 0, b_hi = 0;
     if (B) {
-        b_lo = (int)std::max<int64_t>(0, chunk_lo - A->n);
-        b_hi = (int)std::max<int64_t>(0, chunk_hi - A->n);
+        b_lo = (int)std::max<int64_t>(0, chunk_lo - A->m);
+        b_hi = (int)std::max<int64_t>(0, chunk_hi - A->m);
     }
     shard_rows(c, bp->ranges_a.as<uint2>(), a_lo, a_hi, &a_lo, &a_hi);
     if (B) shard_rows(c, bp->ranges_b.as<uint2>(), b_lo, b_hi, &b_lo, &b_hi);
@@ -596,12 +633,12 @@ static void bp_detect_partial(sccd_broad_phase* bp)
         {
             ProfScope ps(c, SCCD_PROF_SWEEP);
             if (!B) {
-                launch_sweep(c, A, A, bp->ranges_a.as<uint2>(), a_lo, a_hi, EMIT_ONE_LIST, bp->overlaps.as<int2>(),
+                launch_sweep(c, A, A, gp, bp->ranges_a.as<uint2>(), a_lo, a_hi, EMIT_ONE_LIST, bp->overlaps.as<int2>(),
                              bp->capacity, d_cnt);
             } else {
-                launch_sweep(c, A, B, bp->ranges_a.as<uint2>(), a_lo, a_hi, EMIT_ROWS_A, bp->overlaps.as<int2>(),
+                launch_sweep(c, A, B, gp, bp->ranges_a.as<uint2>(), a_lo, a_hi, EMIT_ROWS_A, bp->overlaps.as<int2>(),
                              bp->capacity, d_cnt);
-                launch_sweep(c, B, A, bp->ranges_b.as<uint2>(), b_lo, b_hi, EMIT_ROWS_B, bp->overlaps.as<int2>(),
+                launch_sweep(c, B, A, gp, bp->ranges_b.as<uint2>(), b_lo, b_hi, EMIT_ROWS_B, bp->overlaps.as<int2>(),
                              bp->capacity, d_cnt);
             }
         }

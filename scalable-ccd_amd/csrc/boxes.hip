@@ -7,8 +7,11 @@
 // The reference builds boxes on the host and copies 64 B/box to the device; here the mesh is
 // already resident and the boxes never leave HBM.
 #include "internal.hpp"
+#include "grid.hpp"
 
 #include <algorithm>
+
+#define TI_INF __builtin_huge_val()
 
 namespace {
 
@@ -131,37 +134,179 @@ __global__ void face_boxes_k(const sccd_aabb* __restrict__ vb, const int4* __res
     store_box(out + i, lo, hi, f.x, f.y, f.z, i);
 }
 
-// split_boxes, key part (aabb.cu:40-72): 32-bit monotone key of min[axis] + identity index
-__global__ void box_keys_k(const sccd_aabb* __restrict__ raw, int n, int axis, uint32_t* __restrict__ key,
-                           uint32_t* __restrict__ idx)
+// ---- composite key: cell on the minor axes + quantised sort coordinate (grid.hpp) ------------
+
+// global bounds and summed extents of a box list (run once per list of a build)
+__global__ void box_stats_k(const sccd_aabb* __restrict__ raw, int n, GridStats* __restrict__ st)
+{
+    double lo[3] = { TI_INF, TI_INF, TI_INF }, hi[3] = { -TI_INF, -TI_INF, -TI_INF }, se[3] = { 0, 0, 0 };
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const BoxLoad b = load_box_geom(raw + i);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            lo[k] = fmin(lo[k], b.lo[k]);
+            hi[k] = fmax(hi[k], b.hi[k]);
+            se[k] += b.hi[k] - b.lo[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[k] = fmin(lo[k], __shfl_xor(lo[k], o, 64));
+            hi[k] = fmax(hi[k], __shfl_xor(hi[k], o, 64));
+            se[k] += __shfl_xor(se[k], o, 64);
+        }
+    }
+    // one set of global atomics per BLOCK: nine contended words shared by the whole grid
+    __shared__ double red[TPB / 64][9];
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            red[w][k] = lo[k];
+            red[w][3 + k] = hi[k];
+            red[w][6 + k] = se[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        double l = red[0][k], h = red[0][3 + k], s = red[0][6 + k];
+#pragma unroll
+        for (int j = 1; j < TPB / 64; j++) {
+            l = fmin(l, red[j][k]);
+            h = fmax(h, red[j][3 + k]);
+            s += red[j][6 + k];
+        }
+        atomicMin(&st->kmin[k], mono64(l));
+        atomicMax(&st->kmax[k], mono64(h));
+        atomicAdd(&st->sumext[k], s);
+    }
+}
+
+// cell size = cell_factor x mean box extent on that axis; at most 2^10 cells in total
+__global__ void grid_setup_k(const GridStats* __restrict__ st, int n_total, int axis, double cell_factor, int shrink,
+                             GridParams* __restrict__ g)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int aa = (axis == 0) ? 1 : 0, ab = (axis == 2) ? 1 : 2;
+    double lo[3], hi[3];
+    for (int k = 0; k < 3; k++) {
+        lo[k] = mono64_inv(st->kmin[k]);
+        hi[k] = mono64_inv(st->kmax[k]);
+    }
+    int S[2];
+    const int ax2[2] = { aa, ab };
+    for (int t = 0; t < 2; t++) {
+        const int k = ax2[t];
+        const double range = hi[k] - lo[k];
+        const double mean = n_total > 0 ? st->sumext[k] / (double)n_total : 0.0;
+        const double h = cell_factor * mean;
+        double s = (h > 0.0 && range > 0.0 && range < TI_INF) ? floor(range / h) : 1.0;
+        if (!(s >= 1.0)) s = 1.0;
+        if (s > 1024.0) s = 1024.0;
+        S[t] = (int)s;
+    }
+    while ((long long)S[0] * S[1] > 1024) { // keep 2^10 cells at most, shrinking the finer axis
+        if (S[0] >= S[1]) S[0] = (S[0] + 1) / 2;
+        else S[1] = (S[1] + 1) / 2;
+    }
+    for (int t = 0; t < shrink; t++) { // replication blew up: coarser cells
+        S[0] = (S[0] + 1) / 2;
+        S[1] = (S[1] + 1) / 2;
+    }
+    if (S[0] < 1) S[0] = 1;
+    if (S[1] < 1) S[1] = 1;
+    int cb = 0;
+    while ((1 << cb) < S[0] * S[1]) cb++;
+    g->axis = axis;
+    g->aa = aa;
+    g->ab = ab;
+    g->Sa = S[0];
+    g->Sb = S[1];
+    g->xb = 32 - cb;
+    g->n_cells = S[0] * S[1];
+    g->pad = 0;
+    const double xr = hi[axis] - lo[axis];
+    const double qmax = (double)((1ull << (32 - cb)) - 1ull);
+    g->x0 = lo[axis];
+    g->xscale = (xr > 0.0 && xr < TI_INF) ? qmax / xr : 0.0;
+    g->xqmax = qmax;
+    const double ra = hi[aa] - lo[aa], rb = hi[ab] - lo[ab];
+    g->a0 = lo[aa];
+    g->inv_ha = (S[0] > 1 && ra > 0.0) ? (double)S[0] / ra : 0.0;
+    g->b0 = lo[ab];
+    g->inv_hb = (S[1] > 1 && rb > 0.0) ? (double)S[1] / rb : 0.0;
+}
+
+struct CellSpan {
+    int a0, a1, b0, b1;
+};
+__device__ __forceinline__ CellSpan cell_span(const GridParams& g, const BoxLoad& b)
+{
+    CellSpan s;
+    s.a0 = grid_cell_a(g, b.lo[g.aa]);
+    s.a1 = grid_cell_a(g, b.hi[g.aa]);
+    s.b0 = grid_cell_b(g, b.lo[g.ab]);
+    s.b1 = grid_cell_b(g, b.hi[g.ab]);
+    return s;
+}
+
+// number of cells each box overlaps (the interval starts the prefix scan turns into offsets)
+__global__ void cell_count_k(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp,
+                             uint32_t* __restrict__ counts)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    key[i] = key32(raw[i].min[axis]);
-    idx[i] = (uint32_t)i;
+    const GridParams g = *gp;
+    const CellSpan s = cell_span(g, load_box_geom(raw + i));
+    counts[i] = (uint32_t)((s.a1 - s.a0 + 1) * (s.b1 - s.b0 + 1));
+}
+
+// split_boxes, key part (aabb.cu:40-72): one (key, box index) entry per overlapped cell
+__global__ void cell_fill_k(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp,
+                            const uint32_t* __restrict__ offsets, uint32_t* __restrict__ key,
+                            uint32_t* __restrict__ idx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const GridParams g = *gp;
+    const BoxLoad b = load_box_geom(raw + i);
+    const CellSpan s = cell_span(g, b);
+    const unsigned q = grid_qx(g, b.lo[g.axis]);
+    uint32_t at = offsets[i];
+    for (int ca = s.a0; ca <= s.a1; ca++)
+        for (int cb = s.b0; cb <= s.b1; cb++) {
+            key[at] = (uint32_t)(((unsigned long long)(ca * g.Sb + cb) << g.xb) | q); // xb may be 32
+            idx[at] = (uint32_t)i;
+            ++at;
+        }
 }
 
 // payload movement of thrust::sort_by_key (aabb.cu:107-109) as ONE gather after the index sort,
 // fused with the construction of the filter record and the max-key.
-__global__ void box_gather_k(const sccd_aabb* __restrict__ raw, const uint32_t* __restrict__ idx, int n, int axis,
-                             sccd_aabb* __restrict__ sorted, float4* __restrict__ filt, uint32_t* __restrict__ kmax)
+__global__ void entry_gather_k(const sccd_aabb* __restrict__ raw, const uint32_t* __restrict__ key,
+                               const uint32_t* __restrict__ idx, int m, const GridParams* __restrict__ gp,
+                               sccd_aabb* __restrict__ sorted, float4* __restrict__ filt,
+                               uint32_t* __restrict__ kmax)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const sccd_aabb* src = raw + idx[i];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m) return;
+    const GridParams g = *gp;
+    const sccd_aabb* src = raw + idx[e];
     const double4 q0 = reinterpret_cast<const double4*>(src)[0];
     const double4 q1 = reinterpret_cast<const double4*>(src)[1];
-    double4* dst = reinterpret_cast<double4*>(sorted + i);
+    double4* dst = reinterpret_cast<double4*>(sorted + e);
     dst[0] = q0;
     dst[1] = q1;
     const double lo[3] = { q0.x, q0.y, q0.z };
     const double hi[3] = { q0.w, q1.x, q1.y };
-    const int a = (axis == 0) ? 1 : 0;
-    const int b = (axis == 2) ? 1 : 2;
     // outward rounding keeps the filter conservative: filt.min <= min, filt.max >= max
-    filt[i] = make_float4(__double2float_rd(lo[a]), __double2float_ru(hi[a]), __double2float_rd(lo[b]),
-                          __double2float_ru(hi[b]));
-    kmax[i] = key32(hi[axis]);
+    filt[e] = make_float4(__double2float_rd(lo[g.aa]), __double2float_ru(hi[g.aa]), __double2float_rd(lo[g.ab]),
+                          __double2float_ru(hi[g.ab]));
+    const uint32_t cellbits = (uint32_t)((((unsigned long long)key[e]) >> g.xb) << g.xb);
+    kmax[e] = cellbits | grid_qx(g, hi[g.axis]);
 }
 
 // sum and sum of squares of the box centres per axis (sort_and_sweep.cpp:176-186)
@@ -232,17 +377,37 @@ void launch_face_boxes(sccd_ctx* c, const sccd_aabb* vb, const int4* F, int nF, 
     hipLaunchKernelGGL(face_boxes_k, dim3(grid_for(nF)), dim3(TPB), 0, c->stream, vb, F, nF, out);
     SCCD_HIP(hipGetLastError());
 }
-void launch_box_keys(sccd_ctx* c, const sccd_aabb* raw, int n, int axis, uint32_t* key, uint32_t* idx)
+void launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(box_keys_k, dim3(grid_for(n)), dim3(TPB), 0, c->stream, raw, n, axis, key, idx);
+    const int grid = std::min(grid_for(n), c->num_cus * 2);
+    hipLaunchKernelGGL(box_stats_k, dim3(grid), dim3(TPB), 0, c->stream, raw, n, st);
     SCCD_HIP(hipGetLastError());
 }
-void launch_box_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* idx, int n, int axis, sccd_aabb* sorted,
-                       float4* filt, uint32_t* kmax)
+void launch_grid_setup(sccd_ctx* c, const GridStats* st, int n_total, int axis, double cell_factor, int shrink,
+                       GridParams* g)
+{
+    hipLaunchKernelGGL(grid_setup_k, dim3(1), dim3(64), 0, c->stream, st, n_total, axis, cell_factor, shrink, g);
+    SCCD_HIP(hipGetLastError());
+}
+void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, uint32_t* counts)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(box_gather_k, dim3(grid_for(n)), dim3(TPB), 0, c->stream, raw, idx, n, axis, sorted, filt,
+    hipLaunchKernelGGL(cell_count_k, dim3(grid_for(n)), dim3(TPB), 0, c->stream, raw, n, g, counts);
+    SCCD_HIP(hipGetLastError());
+}
+void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, const uint32_t* offsets,
+                      uint32_t* key, uint32_t* idx)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(cell_fill_k, dim3(grid_for(n)), dim3(TPB), 0, c->stream, raw, n, g, offsets, key, idx);
+    SCCD_HIP(hipGetLastError());
+}
+void launch_entry_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,
+                         const GridParams* g, sccd_aabb* sorted, float4* filt, uint32_t* kmax)
+{
+    if (m == 0) return;
+    hipLaunchKernelGGL(entry_gather_k, dim3(grid_for(m)), dim3(TPB), 0, c->stream, raw, key, idx, m, g, sorted, filt,
                        kmax);
     SCCD_HIP(hipGetLastError());
 }

@@ -22,11 +22,19 @@ struct sccd_mesh {
     DevBuf V, E, F;
 };
 
+// DeviceAABBs: the boxes of one list, resident in HBM in element order.  The split into keys and
+// payload and the sort (aabb.cu:75-111 does them in the DeviceAABBs constructor) happen in
+// BroadPhase::build, where the cell grid of BOTH lists is known.
 struct sccd_boxes {
     sccd_ctx* ctx = nullptr;
     int n = 0;
-    int axis = 0;
-    DevBuf key, kmax, filt, box;
+    DevBuf raw; // sccd_aabb[n]
+};
+
+// one sweep list: an entry per (box, overlapped cell), sorted by the composite key of grid.hpp
+struct SortedList {
+    int m = 0; // entries (>= number of boxes)
+    DevBuf key, kmax, filt, box, idx;
 };
 
 struct sccd_broad_phase {
@@ -36,7 +44,9 @@ struct sccd_broad_phase {
     bool built = false;
     int64_t cursor = 0;     // thread_start_box_id of broad_phase.cuh:86 (in sorted rows)
     int64_t total_rows = 0; // rows of all sweep classes
-    DevBuf ranges_a, ranges_b; // uint2[n] (start,end) per row, per sweep class
+    SortedList la, lb;         // sorted entry lists of A and B
+    DevBuf grid;               // GridStats + GridParams
+    DevBuf ranges_a, ranges_b; // uint2[m] (start,end) per row, per sweep class
     DevBuf overlaps;           // int2[capacity]
     int64_t capacity = 0;
     int64_t n_overlaps = 0;
@@ -51,9 +61,19 @@ void launch_pack_faces(sccd_ctx* c, const int32_t* dF, int nF, int4* out);
 void launch_vertex_boxes(sccd_ctx* c, const double* dV, int nV, double inflation, sccd_aabb* out);
 void launch_edge_boxes(sccd_ctx* c, const sccd_aabb* vb, const int2* E, int nE, sccd_aabb* out);
 void launch_face_boxes(sccd_ctx* c, const sccd_aabb* vb, const int4* F, int nF, sccd_aabb* out);
-void launch_box_keys(sccd_ctx* c, const sccd_aabb* raw, int n, int axis, uint32_t* key, uint32_t* idx);
-void launch_box_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* idx, int n, int axis,
-                       sccd_aabb* sorted, float4* filt, uint32_t* kmax);
+struct GridStats;
+struct GridParams;
+void launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st);
+void launch_grid_setup(sccd_ctx* c, const GridStats* st, int n_total, int axis, double cell_factor, int shrink,
+                       GridParams* g);
+void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, uint32_t* counts);
+void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, const uint32_t* offsets,
+                      uint32_t* key, uint32_t* idx);
+void launch_entry_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,
+                         const GridParams* g, sccd_aabb* sorted, float4* filt, uint32_t* kmax);
+
+// scan.hip
+void exclusive_scan_u32(sccd_ctx* c, const uint32_t* in, uint32_t* out, int n, uint32_t* d_total);
 // variance of box centres per axis -> arg-max axis (sort_and_sweep.cpp:176-195); blocking
 int pick_sort_axis(sccd_ctx* c, const sccd_aabb* raw, int n);
 
@@ -69,10 +89,11 @@ struct SweepCounters { // lives in device memory (ctx->scalars)
     unsigned int pad;
 };
 // ranges for rows of `rows` against columns `cols` (see sweep.hip for the three modes)
-void launch_ranges(sccd_ctx* c, const sccd_boxes* rows, const sccd_boxes* cols, int mode, uint2* ranges,
+void launch_ranges(sccd_ctx* c, const SortedList* rows, const SortedList* cols, int mode, uint2* ranges,
                    unsigned long long* d_candidates);
-void launch_sweep(sccd_ctx* c, const sccd_boxes* rows, const sccd_boxes* cols, const uint2* ranges,
-                  int row_begin, int row_end, int emit, int2* out, int64_t capacity, SweepCounters* d_cnt);
+void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, const GridParams* gp,
+                  const uint2* ranges, int row_begin, int row_end, int emit, int2* out, int64_t capacity,
+                  SweepCounters* d_cnt);
 
 // narrow.hip
 struct NarrowParams {

@@ -6,7 +6,7 @@
 //
 // 4 passes x 8-bit digits.  Per pass:
 //   rs_count_k    per-tile digit histogram                     (read 4 B/key)
-//   rs_scan_k     exclusive scan of the [digit][tile] table     (tiny)
+//   scan.hip      exclusive scan of the [digit][tile] table     (tiny)
 //   rs_scatter_k  stable wave-level ranking + scatter           (read 8 B, write 8 B per pair)
 // Ranking is wave64-native: peers of a lane = lanes with the same digit, found with 8 ballots;
 // rank inside the row = popcount of the peers below the lane (mbcnt); one leader lane per
@@ -38,38 +38,6 @@ __global__ __launch_bounds__(RS_THREADS) void rs_count_k(const uint32_t* __restr
     }
     __syncthreads();
     counts[(size_t)threadIdx.x * num_tiles + blockIdx.x] = hist[threadIdx.x];
-}
-
-// exclusive scan of `total` uint32 entries in place, one block of 1024 threads
-__global__ __launch_bounds__(1024) void rs_scan_k(uint32_t* __restrict__ data, int total)
-{
-    __shared__ uint32_t wave_sums[16];
-    __shared__ uint32_t carry_s;
-    const int per = (total + 1023) / 1024;
-    const int beg = min(total, (int)threadIdx.x * per), end = min(total, beg + per);
-    uint32_t s = 0;
-    for (int i = beg; i < end; i++) s += data[i];
-    // block exclusive scan of s
-    const int lane = lane_id(), w = threadIdx.x >> 6;
-    uint32_t incl = (uint32_t)wave_incl_scan((int)s);
-    if (lane == 63) wave_sums[w] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int k = 0; k < 16; k++) {
-            const uint32_t t = wave_sums[k];
-            wave_sums[k] = run;
-            run += t;
-        }
-        carry_s = run;
-    }
-    __syncthreads();
-    uint32_t run = wave_sums[w] + incl - s;
-    for (int i = beg; i < end; i++) {
-        const uint32_t t = data[i];
-        data[i] = run;
-        run += t;
-    }
 }
 
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_k(const uint32_t* __restrict__ keys_in,
@@ -155,7 +123,7 @@ void radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
         const int shift = 8 * pass;
         hipLaunchKernelGGL(rs_count_k, dim3(num_tiles), dim3(RS_THREADS), 0, c->stream, k_in, (long long)n, shift,
                            num_tiles, counts);
-        hipLaunchKernelGGL(rs_scan_k, dim3(1), dim3(1024), 0, c->stream, counts, 256 * num_tiles);
+        exclusive_scan_u32(c, counts, counts, 256 * num_tiles, reinterpret_cast<uint32_t*>(c->scalars.as<char>() + 1024));
         hipLaunchKernelGGL(rs_scatter_k, dim3(num_tiles), dim3(RS_THREADS), 0, c->stream, k_in, v_in, k_out, v_out,
                            (long long)n, shift, num_tiles, counts);
         std::swap(k_in, k_out);

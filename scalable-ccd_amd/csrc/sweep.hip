@@ -20,6 +20,7 @@
 //            reserves space, then the pairs are written coalesced (the reference: two global
 //            atomics per pair, collision.cuh:45-54).
 #include "internal.hpp"
+#include "grid.hpp"
 
 #include <algorithm>
 
@@ -160,25 +161,43 @@ struct Emitter {
     }
 };
 
+__device__ __forceinline__ double sel3(const double v[3], int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
+
+// A box listed in several cells meets the same partner in each of them; the pair is reported
+// only from the cell (max of the two boxes' lowest cells per minor axis), which both boxes
+// share iff they overlap on that axis (grid.hpp).
+__device__ __forceinline__ bool owns_pair(const GridParams& g, uint32_t row_key, const ExactBox& a, const ExactBox& b)
+{
+    if (g.n_cells <= 1) return true;
+    const int cell = (int)((unsigned long long)row_key >> g.xb);
+    const int ca = cell / g.Sb, cb = cell - ca * g.Sb;
+    const int ma = max(grid_cell_a(g, sel3(a.lo, g.aa)), grid_cell_a(g, sel3(b.lo, g.aa)));
+    const int mb = max(grid_cell_b(g, sel3(a.lo, g.ab)), grid_cell_b(g, sel3(b.lo, g.ab)));
+    return ma == ca && mb == cb;
+}
+
 __device__ __forceinline__ void confirm(bool active, uint2 cand, const sccd_aabb* __restrict__ box_r,
-                                        const sccd_aabb* __restrict__ box_c, int emit, Emitter& em)
+                                        const uint32_t* __restrict__ key_r, const sccd_aabb* __restrict__ box_c,
+                                        const GridParams& g, int emit, Emitter& em)
 {
     bool ok = false;
     int2 pr = make_int2(0, 0);
     if (active) {
         const ExactBox a = load_exact(box_r + cand.x);
         const ExactBox b = load_exact(box_c + cand.y);
-        ok = exact_pair_ok(a, b);
+        ok = exact_pair_ok(a, b) && owns_pair(g, key_r[cand.x], a, b);
         pr = make_pair_out(emit, a.eid, b.eid);
     }
     em.push(ok, pr);
 }
 
 __global__ __launch_bounds__(SW_THREADS) void sweep_stq_k(
-    const float4* __restrict__ filt_r, const sccd_aabb* __restrict__ box_r, const uint2* __restrict__ ranges,
-    int row_begin, int row_end, const float4* __restrict__ filt_c, const sccd_aabb* __restrict__ box_c, int emit,
-    int2* __restrict__ out, long long capacity, SweepCounters* __restrict__ cnt)
+    const float4* __restrict__ filt_r, const sccd_aabb* __restrict__ box_r, const uint32_t* __restrict__ key_r,
+    const uint2* __restrict__ ranges, int row_begin, int row_end, const float4* __restrict__ filt_c,
+    const sccd_aabb* __restrict__ box_c, const GridParams* __restrict__ gp, int emit, int2* __restrict__ out,
+    long long capacity, SweepCounters* __restrict__ cnt)
 {
+    const GridParams g = *gp;
     __shared__ uint2 q_s[SW_WAVES][SW_QCAP];
     __shared__ int2 o_s[SW_WAVES][SW_OCAP];
     const int lane = lane_id(), w = threadIdx.x >> 6;
@@ -247,7 +266,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_stq_k(
                         wave_lds_fence();
                         const uint2 cand = q[qcount - 64 + lane];
                         qcount -= 64;
-                        confirm(true, cand, box_r, box_c, emit, em);
+                        confirm(true, cand, box_r, key_r, box_c, g, emit, em);
                     }
                     if (has) {
                         const int b = __ffs((int)m) - 1;
@@ -262,7 +281,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_stq_k(
                 wave_lds_fence();
                 const uint2 cand = q[qcount - 64 + lane];
                 qcount -= 64;
-                confirm(true, cand, box_r, box_c, emit, em);
+                confirm(true, cand, box_r, key_r, box_c, g, emit, em);
             }
         }
     }
@@ -271,7 +290,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_stq_k(
         wave_lds_fence();
         const bool act = lane < qcount;
         const uint2 cand = act ? q[lane] : make_uint2(0u, 0u);
-        confirm(act, cand, box_r, box_c, emit, em);
+        confirm(act, cand, box_r, key_r, box_c, g, emit, em);
     }
     em.flush();
 }
@@ -279,17 +298,20 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_stq_k(
 // Plain sweep-and-prune, one thread per row, exact boxes only (the reference's baseline
 // variant sweep_and_prune<>, sweep.cu:48-99).  Kept as an in-library cross-check of the STQ
 // kernel (SCCD_OPT_SWEEP_ALGO = 1); not tuned.
-__global__ void sweep_sap_k(const sccd_aabb* __restrict__ box_r, const uint2* __restrict__ ranges, int row_begin,
-                            int row_end, const sccd_aabb* __restrict__ box_c, int emit, int2* __restrict__ out,
-                            long long capacity, SweepCounters* __restrict__ cnt)
+__global__ void sweep_sap_k(const sccd_aabb* __restrict__ box_r, const uint32_t* __restrict__ key_r,
+                            const uint2* __restrict__ ranges, int row_begin, int row_end,
+                            const sccd_aabb* __restrict__ box_c, const GridParams* __restrict__ gp, int emit,
+                            int2* __restrict__ out, long long capacity, SweepCounters* __restrict__ cnt)
 {
     const int row = row_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= row_end) return;
+    const GridParams g = *gp;
     const uint2 rg = ranges[row];
     const ExactBox a = load_exact(box_r + row);
+    const uint32_t rk = key_r[row];
     for (unsigned j = rg.x; j < rg.y; j++) {
         const ExactBox b = load_exact(box_c + j);
-        if (exact_pair_ok(a, b)) {
+        if (exact_pair_ok(a, b) && owns_pair(g, rk, a, b)) {
             const unsigned long long dst = atomicAdd(&cnt->n_pairs, 1ull);
             if ((long long)dst < capacity) out[dst] = make_pair_out(emit, a.eid, b.eid);
         }
@@ -298,33 +320,35 @@ __global__ void sweep_sap_k(const sccd_aabb* __restrict__ box_r, const uint2* __
 
 } // namespace
 
-void launch_ranges(sccd_ctx* c, const sccd_boxes* rows, const sccd_boxes* cols, int mode, uint2* ranges,
+void launch_ranges(sccd_ctx* c, const SortedList* rows, const SortedList* cols, int mode, uint2* ranges,
                    unsigned long long* d_candidates)
 {
-    if (rows->n == 0) return;
-    const int grid = (rows->n + 255) / 256;
+    if (rows->m == 0) return;
+    const int grid = (rows->m + 255) / 256;
     hipLaunchKernelGGL(ranges_k, dim3(grid), dim3(256), 0, c->stream, rows->key.as<uint32_t>(),
-                       rows->kmax.as<uint32_t>(), rows->n, cols->key.as<uint32_t>(), cols->n, mode, ranges,
+                       rows->kmax.as<uint32_t>(), rows->m, cols->key.as<uint32_t>(), cols->m, mode, ranges,
                        d_candidates);
     SCCD_HIP(hipGetLastError());
 }
 
-void launch_sweep(sccd_ctx* c, const sccd_boxes* rows, const sccd_boxes* cols, const uint2* ranges, int row_begin,
-                  int row_end, int emit, int2* out, int64_t capacity, SweepCounters* d_cnt)
+void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, const GridParams* gp,
+                  const uint2* ranges, int row_begin, int row_end, int emit, int2* out, int64_t capacity,
+                  SweepCounters* d_cnt)
 {
-    if (row_end <= row_begin || cols->n == 0) return;
+    if (row_end <= row_begin || cols->m == 0) return;
     SCCD_HIP(hipMemsetAsync(&d_cnt->tile_ticket, 0, sizeof(unsigned), c->stream));
     if (c->sweep_algo == 1) {
         const int n = row_end - row_begin;
         hipLaunchKernelGGL(sweep_sap_k, dim3((n + 255) / 256), dim3(256), 0, c->stream, rows->box.as<sccd_aabb>(),
-                           ranges, row_begin, row_end, cols->box.as<sccd_aabb>(), emit, out, (long long)capacity,
-                           d_cnt);
+                           rows->key.as<uint32_t>(), ranges, row_begin, row_end, cols->box.as<sccd_aabb>(), gp, emit,
+                           out, (long long)capacity, d_cnt);
     } else {
         const int num_tiles = (row_end - row_begin + 63) / 64;
         const int grid = std::max(1, std::min((num_tiles + SW_WAVES - 1) / SW_WAVES, c->num_cus * 4));
         hipLaunchKernelGGL(sweep_stq_k, dim3(grid), dim3(SW_THREADS), 0, c->stream, rows->filt.as<float4>(),
-                           rows->box.as<sccd_aabb>(), ranges, row_begin, row_end, cols->filt.as<float4>(),
-                           cols->box.as<sccd_aabb>(), emit, out, (long long)capacity, d_cnt);
+                           rows->box.as<sccd_aabb>(), rows->key.as<uint32_t>(), ranges, row_begin, row_end,
+                           cols->filt.as<float4>(), cols->box.as<sccd_aabb>(), gp, emit, out, (long long)capacity,
+                           d_cnt);
     }
     SCCD_HIP(hipGetLastError());
 }

@@ -16,6 +16,7 @@ raises.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -115,12 +116,16 @@ class Context:
 
     def __init__(self, device=0):
         self._h = C.c_void_p()
+        self._children = weakref.WeakSet()  # meshes / boxes / broad phases living in this context
         rc = lib().sccd_create(C.c_int(device), C.byref(self._h))
         if rc != 0:
             raise RuntimeError("sccd_create failed: " + lib().sccd_last_error(None).decode())
 
     def close(self):
+        """Destroys the objects created in this context first, then the context."""
         if self._h:
+            for ch in list(self._children):
+                ch.close()
             lib().sccd_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -200,6 +205,7 @@ class Mesh:
             args = (_ptr(V0c), _ptr(V1c), C.c_int(self.nV), _ptr(Ec), C.c_int(self.nE), _ptr(Fc), C.c_int(self.nF))
         self.ctx._check(lib().sccd_mesh_create(self.ctx._h, *args, C.c_int(int(on_device)), C.byref(self._h)))
         self._keep = None
+        self.ctx._children.add(self)
 
     def update_vertices(self, V0, V1, on_device=False):
         if on_device:
@@ -258,6 +264,7 @@ class DeviceAABBs:
     def __init__(self, boxes=None, ctx=None, _handle=None):
         self.ctx = ctx or default_context()
         self._h = C.c_void_p()
+        self.ctx._children.add(self)
         if _handle is not None:
             self._h = _handle
             return
@@ -302,6 +309,7 @@ class BroadPhase:
         self._h = C.c_void_p()
         self.ctx._check(lib().sccd_broad_phase_create(self.ctx._h, C.byref(self._h)))
         self._boxes = ()
+        self.ctx._children.add(self)
 
     def build(self, boxes_a, boxes_b=None):
         self._boxes = (boxes_a, boxes_b)  # shared ownership, like the reference's shared_ptr
