@@ -597,7 +597,7 @@ static void bp_detect_partial(sccd_broad_phase* bp)
     const int64_t chunk_lo = bp->cursor, chunk_hi = std::min(bp->cursor + cutoff, bp->total_rows);
 
     SweepCounters* d_cnt = c->scalars.as<SweepCounters>();
-    unsigned long long* d_cand = &d_cnt->candidates;
+    unsigned long long* d_cand = d_cnt->cand_parts;
 
     // ranges are (re)computed on the first chunk of a build
     if (bp->cursor == 0) {
@@ -645,7 +645,11 @@ static void bp_detect_partial(sccd_broad_phase* bp)
         SweepCounters h;
         SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
         SCCD_HIP(hipStreamSynchronize(c->stream));
-        bp->candidates = (int64_t)h.candidates;
+        {
+            unsigned long long cs = 0;
+            for (int k = 0; k < 32; k++) cs += h.cand_parts[k];
+            bp->candidates = (int64_t)cs;
+        }
         if ((int64_t)h.n_pairs <= bp->capacity) {
             bp->n_overlaps = (int64_t)h.n_pairs;
             break;
@@ -702,7 +706,7 @@ extern "C" int sccd_broad_phase_detect_overlaps(sccd_broad_phase* bp, int32_t** 
 // narrow phase
 static NarrowCounters* narrow_counters(sccd_ctx* c)
 {
-    return reinterpret_cast<NarrowCounters*>(c->scalars.as<char>() + 256);
+    return reinterpret_cast<NarrowCounters*>(c->scalars.as<char>() + 2048);
 }
 
 struct NarrowResult {

@@ -167,12 +167,15 @@ __device__ __forceinline__ int mbcnt64(unsigned long long mask)
 
 __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
 
-// make LDS writes of this wave visible to its other lanes (single-wave producer/consumer)
+// Order LDS writes of this wave before later LDS reads by its other lanes (single-wave
+// producer/consumer).  The LDS executes one wave's instructions in issue order, so only the
+// COMPILER must not reorder: wavefront-scope fences emit no instruction.  (A workgroup-scope
+// fence here costs an s_waitcnt vmcnt(0), i.e. a wait for every global store/load in flight.)
 __device__ __forceinline__ void wave_lds_fence()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <class T> __device__ __forceinline__ T wave_bcast(T v, int src_lane)

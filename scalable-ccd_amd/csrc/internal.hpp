@@ -84,9 +84,10 @@ void radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
 enum SweepEmit { EMIT_ONE_LIST = 0, EMIT_ROWS_A = 1, EMIT_ROWS_B = 2 };
 struct SweepCounters { // lives in device memory (ctx->scalars)
     unsigned long long n_pairs;    // pairs found (may exceed capacity: overflow -> rerun)
-    unsigned long long candidates; // sum of (end-start) over the swept rows
+    unsigned long long candidates; // (host side: sum of cand_parts)
     unsigned int tile_ticket;      // persistent-wave tile counter
     unsigned int pad;
+    unsigned long long cand_parts[32]; // sum of (end-start) over the rows, spread to avoid one hot word
 };
 // ranges for rows of `rows` against columns `cols` (see sweep.hip for the three modes)
 void launch_ranges(sccd_ctx* c, const SortedList* rows, const SortedList* cols, int mode, uint2* ranges,
@@ -121,6 +122,9 @@ struct NarrowCounters {
     unsigned long long lane_steps;   // live lanes summed over those steps
     unsigned long long refill_execs; // executions of the gather+constants block
     unsigned long long steals;       // sub-domains moved between lanes
+    unsigned long long stamp[8];     // SCCD_NP_DIAG=2: shader cycles per loop section, summed over waves
+    unsigned long long stamp_ticket, stamp_comp;
+    unsigned long long pops_reg, pops_mem; // pops served by the register top / by the HBM stack
 };
 // runs the narrow phase on the stream; *toi in/out lives in d_cnt->toi_bits
 void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,

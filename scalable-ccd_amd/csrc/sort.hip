@@ -4,26 +4,204 @@
 // (src/scalable_ccd/cuda/broad_phase/aabb.cu:107-109): here only an 8-byte (key, index) pair
 // moves through the passes and the payload is gathered once afterwards (boxes.hip).
 //
-// 4 passes x 8-bit digits.  Per pass:
-//   rs_count_k    per-tile digit histogram                     (read 4 B/key)
-//   scan.hip      exclusive scan of the [digit][tile] table     (tiny)
-//   rs_scatter_k  stable wave-level ranking + scatter           (read 8 B, write 8 B per pair)
-// Ranking is wave64-native: peers of a lane = lanes with the same digit, found with 8 ballots;
-// rank inside the row = popcount of the peers below the lane (mbcnt); one leader lane per
-// digit bumps the wave's LDS counter.  Order inside a tile is (wave, row, lane) = index order,
-// so the sort is stable.
+// Default: ONESWEEP -- 4 passes x 8-bit digits, 6 launches in total:
+//   os_hist_k   digit histograms of all four passes in one read of the keys (4 B/key)
+//   os_bases_k  reduction of the per-block histograms + exclusive scan over the digits
+//   os_pass_k   x4: each 4096-key tile ranks its keys, publishes its per-digit counts and
+//               obtains its global offsets by DECOUPLED LOOK-BACK over the preceding tiles
+//               (one relaxed agent-scope 32-bit word per (tile, digit): flag + count in the same
+//               word, so no separate payload needs ordering), then scatters through LDS so that
+//               each digit's run leaves the CU as consecutive addresses.
+//               Per pass: 8 B read + 8 B written per pair -- the algorithmic minimum for LSD.
+// Ranking is wave64-native: the peers of a lane (same digit) are found with 8 ballots, the rank
+// inside the 64-key row is the popcount of the peers below the lane (mbcnt), one leader lane
+// per digit bumps the wave's LDS counter.  Order inside a tile is (wave, row, lane) = index
+// order, so the sort is stable.  Tiles take their index from an atomic ticket, so a tile only
+// ever waits for tiles that already run (no dependence on the dispatch order).
+//
+// SCCD_SORT=classic selects the simple count / scan / scatter pipeline (5 launches per pass),
+// kept as an in-library cross-check.
 #include "internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
-constexpr int RS_ITEMS = 16;                           // rows of 64 keys per wave
-constexpr int RS_TILE = RS_THREADS * RS_ITEMS;         // 4096 keys per tile
-constexpr int RS_WAVE_SPAN = RS_ITEMS * 64;            // keys owned by one wave
+constexpr int RS_ITEMS = 16;                   // rows of 64 keys per wave
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS; // 4096 keys per tile
+constexpr int RS_WAVE_SPAN = RS_ITEMS * 64;    // keys owned by one wave
 
+constexpr uint32_t OS_FLAG_AGG = 1u << 30;    // word holds the tile's own count
+constexpr uint32_t OS_FLAG_PREFIX = 1u << 31; // word holds the inclusive prefix up to this tile
+constexpr uint32_t OS_VALUE_MASK = (1u << 30) - 1u;
+
+// stable rank of every key of this wave's rows among the keys of the wave with the same digit;
+// wcnt[digit] (LDS, zeroed) ends up as the wave's digit counts
+__device__ __forceinline__ void wave_rank_rows(const uint32_t (&key)[RS_ITEMS], const bool (&valid)[RS_ITEMS],
+                                               int shift, uint32_t* wcnt, uint32_t (&rank)[RS_ITEMS])
+{
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const uint32_t d = (key[r] >> shift) & 255u;
+        unsigned long long peers = __ballot(valid[r]);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const int below = mbcnt64(peers);
+        const int leader = (int)__builtin_ctzll(peers | (1ull << 63)); // lowest peer lane
+        uint32_t old = 0;
+        if (valid[r] && below == 0) { // the leader of this digit group
+            old = wcnt[d];
+            wcnt[d] = old + (uint32_t)popc64(peers);
+        }
+        wave_lds_fence();
+        old = (uint32_t)__shfl((int)old, leader, 64);
+        rank[r] = old + (uint32_t)below;
+    }
+}
+
+// ---- onesweep ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(RS_THREADS) void os_hist_k(const uint32_t* __restrict__ keys, long long n, int num_tiles,
+                                                        uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t h[4][256];
+#pragma unroll
+    for (int p = 0; p < 4; p++) h[p][threadIdx.x] = 0;
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+        const long long base = (long long)tile * RS_TILE;
+#pragma unroll 4
+        for (int r = 0; r < RS_ITEMS; r++) {
+            const long long i = base + (long long)r * RS_THREADS + threadIdx.x;
+            if (i < n) {
+                const uint32_t k = keys[i];
+                atomicAdd(&h[0][k & 255u], 1u);
+                atomicAdd(&h[1][(k >> 8) & 255u], 1u);
+                atomicAdd(&h[2][(k >> 16) & 255u], 1u);
+                atomicAdd(&h[3][k >> 24], 1u);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; p++) partial[(size_t)blockIdx.x * 1024 + p * 256 + threadIdx.x] = h[p][threadIdx.x];
+}
+
+// bases[p][d] = number of keys whose digit p is < d
+__global__ __launch_bounds__(1024) void os_bases_k(const uint32_t* __restrict__ partial, int n_blocks,
+                                                   uint32_t* __restrict__ bases)
+{
+    __shared__ uint32_t wsum[16];
+    const int t = threadIdx.x; // (pass, digit) = (t >> 8, t & 255)
+    uint32_t s = 0;
+    for (int b = 0; b < n_blocks; b++) s += partial[(size_t)b * 1024 + t];
+    const int lane = lane_id(), w = t >> 6;
+    const uint32_t incl = (uint32_t)wave_incl_scan((int)s);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t base = 0; // waves of the same pass that precede this one (4 waves per pass)
+    for (int k = (w & ~3); k < w; k++) base += wsum[k];
+    bases[t] = base + incl - s;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restrict__ keys_in,
+                                                        const uint32_t* __restrict__ vals_in,
+                                                        uint32_t* __restrict__ keys_out,
+                                                        uint32_t* __restrict__ vals_out, long long n, int shift,
+                                                        const uint32_t* __restrict__ bases, uint32_t* status,
+                                                        uint32_t* ticket)
+{
+    __shared__ uint32_t wcnt[RS_WAVES][256]; // per-wave digit counts -> per-wave local offsets
+    __shared__ uint32_t dig_excl[256];       // exclusive offset of the digit inside the tile
+    __shared__ uint32_t dig_gbase[256];      // global position of the digit's first key of the tile
+    __shared__ uint32_t s_keys[RS_TILE];
+    __shared__ uint32_t s_vals[RS_TILE];
+    __shared__ uint32_t s_tile;
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+    for (int k = 0; k < RS_WAVES; k++) wcnt[k][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const long long tile_base = (long long)tile * RS_TILE;
+    const long long wave_base = tile_base + (long long)w * RS_WAVE_SPAN;
+    const int tile_count = (int)min((long long)RS_TILE, n - tile_base);
+
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+    bool valid[RS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const long long i = wave_base + r * 64 + lane;
+        valid[r] = i < n;
+        key[r] = valid[r] ? keys_in[i] : 0xFFFFFFFFu;
+        val[r] = valid[r] ? vals_in[i] : 0u;
+    }
+    wave_rank_rows(key, valid, shift, wcnt[w], rank);
+    __syncthreads();
+
+    // thread d owns digit d: tile count, publish, look back, local layout
+    {
+        const int d = threadIdx.x;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; k++) {
+            const uint32_t t = wcnt[k][d];
+            wcnt[k][d] = cnt; // offset of wave k inside the digit's run
+            cnt += t;
+        }
+        uint32_t* my = status + (size_t)tile * 256 + d;
+        __hip_atomic_store(my, cnt | OS_FLAG_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        for (long long t = (long long)tile - 1; t >= 0; t--) {
+            const uint32_t* p = status + (size_t)t * 256 + d;
+            uint32_t v;
+            do {
+                v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while (v == 0u); // the tile has a smaller ticket, so it is running and will publish
+            excl += v & OS_VALUE_MASK;
+            if (v & OS_FLAG_PREFIX) break;
+        }
+        __hip_atomic_store(my, (excl + cnt) | OS_FLAG_PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dig_gbase[d] = bases[d] + excl;
+        // exclusive scan of cnt over the 256 digits -> position of the digit's run inside the tile
+        const uint32_t incl = (uint32_t)wave_incl_scan((int)cnt);
+        if (lane == 63) s_keys[w] = incl; // scratch: s_keys is not in use yet
+        __syncthreads();
+        uint32_t base = 0;
+        for (int k = 0; k < w; k++) base += s_keys[k];
+        dig_excl[d] = base + incl - cnt;
+    }
+    __syncthreads();
+    // stage the tile in LDS in sorted order
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        if (valid[r]) {
+            const uint32_t d = (key[r] >> shift) & 255u;
+            const uint32_t pos = dig_excl[d] + wcnt[w][d] + rank[r];
+            s_keys[pos] = key[r];
+            s_vals[pos] = val[r];
+        }
+    }
+    __syncthreads();
+    // consecutive threads write consecutive addresses of each digit's run
+    for (int i = threadIdx.x; i < tile_count; i += RS_THREADS) {
+        const uint32_t k = s_keys[i];
+        const uint32_t d = (k >> shift) & 255u;
+        const uint32_t dst = dig_gbase[d] + ((uint32_t)i - dig_excl[d]);
+        keys_out[dst] = k;
+        vals_out[dst] = s_vals[i];
+    }
+}
+
+// ---- classic count / scan / scatter -------------------------------------------------------------
 __global__ __launch_bounds__(RS_THREADS) void rs_count_k(const uint32_t* __restrict__ keys, long long n, int shift,
                                                          int num_tiles, uint32_t* __restrict__ counts)
 {
@@ -46,41 +224,22 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_k(const uint32_t* __res
                                                            uint32_t* __restrict__ vals_out, long long n, int shift,
                                                            int num_tiles, const uint32_t* __restrict__ offsets)
 {
-    __shared__ uint32_t wcnt[RS_WAVES][256]; // per-wave digit counts, then per-wave bases
+    __shared__ uint32_t wcnt[RS_WAVES][256];
     const int lane = lane_id(), w = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < RS_WAVES; k++) wcnt[k][threadIdx.x] = 0;
     __syncthreads();
-
     const long long wave_base = (long long)blockIdx.x * RS_TILE + (long long)w * RS_WAVE_SPAN;
-    uint32_t key[RS_ITEMS];
-    uint32_t rank[RS_ITEMS];
+    uint32_t key[RS_ITEMS], rank[RS_ITEMS];
+    bool valid[RS_ITEMS];
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         const long long i = wave_base + r * 64 + lane;
-        const bool valid = i < n;
-        key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
-        const uint32_t d = (key[r] >> shift) & 255u;
-        unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        const int below = mbcnt64(peers);
-        const int leader = (int)__builtin_ctzll(peers | (1ull << 63)); // lowest peer lane
-        uint32_t old = 0;
-        if (valid && below == 0) { // the leader of this digit group
-            old = wcnt[w][d];
-            wcnt[w][d] = old + (uint32_t)popc64(peers);
-        }
-        wave_lds_fence();
-        old = (uint32_t)__shfl((int)old, leader, 64);
-        rank[r] = old + (uint32_t)below;
+        valid[r] = i < n;
+        key[r] = valid[r] ? keys_in[i] : 0xFFFFFFFFu;
     }
+    wave_rank_rows(key, valid, shift, wcnt[w], rank);
     __syncthreads();
-    // thread t owns digit t: turn per-wave counts into per-wave global bases
     {
         const int d = threadIdx.x;
         uint32_t run = offsets[(size_t)d * num_tiles + blockIdx.x];
@@ -95,7 +254,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_k(const uint32_t* __res
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         const long long i = wave_base + r * 64 + lane;
-        if (i < n) {
+        if (valid[r]) {
             const uint32_t d = (key[r] >> shift) & 255u;
             const uint32_t pos = wcnt[w][d] + rank[r];
             keys_out[pos] = key[r];
@@ -109,23 +268,55 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_k(const uint32_t* __res
 void radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n)
 {
     if (n <= 1) return;
-    SCCD_REQUIRE(n < (1ll << 31), "radix sort: at most 2^31-1 elements");
+    SCCD_REQUIRE(n < (1ll << 30), "radix sort: at most 2^30-1 elements");
     const int num_tiles = (int)((n + RS_TILE - 1) / RS_TILE);
     c->sort_tmp_keys.ensure(sizeof(uint32_t) * (size_t)n);
     c->sort_tmp_vals.ensure(sizeof(uint32_t) * (size_t)n);
-    c->sort_hist.ensure(sizeof(uint32_t) * 256 * (size_t)num_tiles);
     uint32_t* k_in = keys;
     uint32_t* v_in = vals;
     uint32_t* k_out = c->sort_tmp_keys.as<uint32_t>();
     uint32_t* v_out = c->sort_tmp_vals.as<uint32_t>();
-    uint32_t* counts = c->sort_hist.as<uint32_t>();
+    static const bool classic = [] {
+        const char* e = std::getenv("SCCD_SORT");
+        return e && std::strcmp(e, "classic") == 0;
+    }();
+    if (classic) {
+        c->sort_hist.ensure(sizeof(uint32_t) * 256 * (size_t)num_tiles);
+        uint32_t* counts = c->sort_hist.as<uint32_t>();
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = 8 * pass;
+            hipLaunchKernelGGL(rs_count_k, dim3(num_tiles), dim3(RS_THREADS), 0, c->stream, k_in, (long long)n, shift,
+                               num_tiles, counts);
+            exclusive_scan_u32(c, counts, counts, 256 * num_tiles,
+                               reinterpret_cast<uint32_t*>(c->scalars.as<char>() + 1024));
+            hipLaunchKernelGGL(rs_scatter_k, dim3(num_tiles), dim3(RS_THREADS), 0, c->stream, k_in, v_in, k_out, v_out,
+                               (long long)n, shift, num_tiles, counts);
+            std::swap(k_in, k_out);
+            std::swap(v_in, v_out);
+        }
+        SCCD_HIP(hipGetLastError());
+        return; // 4 passes: the result is back in (keys, vals)
+    }
+    // onesweep: [4 tickets (padded to 64 B)] [bases 4x256] [partial hist blocks x 1024] [status 4 x tiles x 256]
+    const int hist_blocks = std::min(num_tiles, c->num_cus);
+    const size_t off_bases = 64, off_partial = off_bases + 4096, off_status = off_partial + (size_t)hist_blocks * 4096;
+    const size_t status_bytes = (size_t)4 * num_tiles * 256 * sizeof(uint32_t);
+    c->sort_hist.ensure(off_status + status_bytes);
+    char* base = c->sort_hist.as<char>();
+    uint32_t* tickets = reinterpret_cast<uint32_t*>(base);
+    uint32_t* bases = reinterpret_cast<uint32_t*>(base + off_bases);
+    uint32_t* partial = reinterpret_cast<uint32_t*>(base + off_partial);
+    uint32_t* status = reinterpret_cast<uint32_t*>(base + off_status);
+    // every polled word is zeroed before the launches of this call (tickets and status)
+    SCCD_HIP(hipMemsetAsync(tickets, 0, 64, c->stream));
+    SCCD_HIP(hipMemsetAsync(status, 0, status_bytes, c->stream));
+    hipLaunchKernelGGL(os_hist_k, dim3(hist_blocks), dim3(RS_THREADS), 0, c->stream, k_in, (long long)n, num_tiles,
+                       partial);
+    hipLaunchKernelGGL(os_bases_k, dim3(1), dim3(1024), 0, c->stream, partial, hist_blocks, bases);
     for (int pass = 0; pass < 4; pass++) {
-        const int shift = 8 * pass;
-        hipLaunchKernelGGL(rs_count_k, dim3(num_tiles), dim3(RS_THREADS), 0, c->stream, k_in, (long long)n, shift,
-                           num_tiles, counts);
-        exclusive_scan_u32(c, counts, counts, 256 * num_tiles, reinterpret_cast<uint32_t*>(c->scalars.as<char>() + 1024));
-        hipLaunchKernelGGL(rs_scatter_k, dim3(num_tiles), dim3(RS_THREADS), 0, c->stream, k_in, v_in, k_out, v_out,
-                           (long long)n, shift, num_tiles, counts);
+        hipLaunchKernelGGL(os_pass_k, dim3(num_tiles), dim3(RS_THREADS), 0, c->stream, k_in, v_in, k_out, v_out,
+                           (long long)n, 8 * pass, bases + 256 * pass, status + (size_t)pass * num_tiles * 256,
+                           tickets + pass);
         std::swap(k_in, k_out);
         std::swap(v_in, v_out);
     }

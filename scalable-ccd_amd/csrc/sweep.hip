@@ -60,32 +60,79 @@ __device__ __forceinline__ unsigned upper_bound_u32(const uint32_t* __restrict__
     return lo;
 }
 
-__global__ void ranges_k(const uint32_t* __restrict__ key_r, const uint32_t* __restrict__ kmax_r, int n_rows,
-                         const uint32_t* __restrict__ key_c, int n_cols, int mode, uint2* __restrict__ ranges,
-                         unsigned long long* __restrict__ candidates)
+// One block = 256 consecutive sorted rows.  Their candidate ranges all lie inside one window of
+// the column list ([lb(first row's key), ub(largest max-key of the block))), found with two
+// full binary searches by one lane; every row then searches only inside the window, which is a
+// few hundred entries that stay in this CU's L1.
+__device__ __forceinline__ unsigned lower_bound_in(const uint32_t* __restrict__ a, unsigned lo, unsigned hi, uint32_t v)
 {
+    while (lo < hi) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ unsigned upper_bound_in(const uint32_t* __restrict__ a, unsigned lo, unsigned hi, uint32_t v)
+{
+    while (lo < hi) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void ranges_k(const uint32_t* __restrict__ key_r, const uint32_t* __restrict__ kmax_r,
+                                                int n_rows, const uint32_t* __restrict__ key_c, int n_cols, int mode,
+                                                uint2* __restrict__ ranges, unsigned long long* __restrict__ candidates)
+{
+    __shared__ uint32_t s_kmax[4];
+    __shared__ unsigned s_win[2];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n_rows;
+    const uint32_t k_lo = valid ? key_r[i] : 0xFFFFFFFFu;
+    const uint32_t k_hi = valid ? kmax_r[i] : 0u;
+    const uint32_t wmax = wave_max_u32(k_hi);
+    if (lane_id() == 0) s_kmax[threadIdx.x >> 6] = wmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t bmax = max(max(s_kmax[0], s_kmax[1]), max(s_kmax[2], s_kmax[3]));
+        // rows are sorted: the first row of the block has the smallest key
+        s_win[0] = (mode == 0) ? (unsigned)i + 1u : lower_bound_u32(key_c, (unsigned)n_cols, k_lo);
+        s_win[1] = upper_bound_u32(key_c, (unsigned)n_cols, bmax);
+        if (s_win[1] < s_win[0]) s_win[1] = s_win[0];
+    }
+    __syncthreads();
+    const unsigned w0 = s_win[0], w1 = s_win[1];
     unsigned long long cnt = 0;
-    if (i < n_rows) {
+    if (valid) {
         unsigned s, e;
         if (mode == 0) {
             s = (unsigned)i + 1;
-            e = upper_bound_u32(key_c, (unsigned)n_cols, kmax_r[i]);
-            if (e < s) e = s;
+            e = upper_bound_in(key_c, max(s, w0), w1, k_hi);
         } else if (mode == 1) {
-            s = lower_bound_u32(key_c, (unsigned)n_cols, key_r[i]);
-            e = upper_bound_u32(key_c, (unsigned)n_cols, kmax_r[i]);
+            s = lower_bound_in(key_c, w0, w1, k_lo);
+            e = upper_bound_in(key_c, s, w1, k_hi);
         } else {
-            s = upper_bound_u32(key_c, (unsigned)n_cols, key_r[i]);
-            e = upper_bound_u32(key_c, (unsigned)n_cols, kmax_r[i]);
+            s = upper_bound_in(key_c, w0, w1, k_lo);
+            e = upper_bound_in(key_c, s, w1, k_hi);
         }
         if (e < s) e = s;
         ranges[i] = make_uint2(s, e);
         cnt = e - s;
     }
+    // work metric only: one atomic per BLOCK, spread over 32 words (a single word serialises
+    // at ~90 atomics/us chip-wide, which used to cost more than the searches)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if (lane_id() == 0 && cnt) atomicAdd(candidates, cnt);
+    __shared__ unsigned long long s_cnt[4];
+    if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (tot) atomicAdd(candidates + (blockIdx.x & 31), tot);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
