@@ -9,9 +9,10 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-f
             -Wall -Wextra -Wno-unused-parameter -Wno-unused-function -Wno-missing-field-initializers
 SRCS    := $(CSRC)/api.hip $(CSRC)/boxes.hip $(CSRC)/scan.hip $(CSRC)/sort.hip $(CSRC)/sweep.hip $(CSRC)/narrow.hip
 OBJS    := $(SRCS:.hip=.o)
+CPPTEST := tests/cpp/test_ccd_api
 HDRS    := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inc) include/sccd.h
 
-all: $(OUT) oracle
+all: $(OUT) oracle $(CPPTEST)
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -27,3 +28,11 @@ clean:
 	$(MAKE) -s -C oracle clean
 
 .PHONY: all oracle clean
+
+# C++ parity test of include/scalable_ccd/hip/ccd.hpp (compiles without a GPU, runs on one)
+$(CPPTEST): tests/cpp/test_ccd_api.cpp include/scalable_ccd/hip/ccd.hpp include/sccd.h $(OUT) oracle
+	g++ -std=c++17 -O1 -Wall -Wextra -Iinclude tests/cpp/test_ccd_api.cpp -o $@ \
+	    -Lscalable-ccd_amd/sccd -lsccd_hip -Loracle -lsccd_oracle \
+	    -Wl,-rpath,'$$ORIGIN/../../scalable-ccd_amd/sccd' -Wl,-rpath,'$$ORIGIN/../../oracle' -Wl,-rpath,/opt/rocm/lib
+cpptest: $(CPPTEST)
+.PHONY: cpptest

@@ -1,0 +1,175 @@
+// C++ parity test of the host API mirror (include/scalable_ccd/hip/ccd.hpp), shaped like the
+// reference's own Catch2 tests (tests/test_broad_phase.cu:89-121, tests/test_narrow_phase.cu:41-65):
+// load a two-frame mesh, build the boxes, run BroadPhase::detect_overlaps for vertex-face and
+// edge-edge, run ccd(), and compare with the CPU oracle (oracle/sccd_oracle.h) instead of the
+// absent sample-data ground truth.  Exit code 0 = all checks passed.
+#include <scalable_ccd/hip/ccd.hpp>
+
+#include "../../oracle/sccd_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <array>
+#include <set>
+
+using namespace scalable_ccd::hip;
+
+static int g_fail = 0;
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        if (!(cond)) {                                                           \
+            std::printf("CHECK failed: %s (%s:%d)\n", #cond, __FILE__, __LINE__); \
+            g_fail++;                                                            \
+        }                                                                        \
+    } while (0)
+
+static uint64_t g_state = 12345;
+static double urand()
+{ // splitmix64
+    uint64_t z = (g_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * 0x1.0p-53;
+}
+
+// n x n cloth dropping through a second, tilted cloth: column-major V, E, F like Eigen
+static void make_scene(int n, std::vector<double>& V0, std::vector<double>& V1, std::vector<int32_t>& E,
+                       std::vector<int32_t>& F, int& nV, int& nE, int& nF)
+{
+    const int per = n * n;
+    nV = 2 * per;
+    V0.assign((size_t)3 * nV, 0.0);
+    V1.assign((size_t)3 * nV, 0.0);
+    std::vector<std::array<int, 3>> faces;
+    for (int s = 0; s < 2; s++)
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) {
+                const int v = s * per + i * n + j;
+                const double x = j / double(n - 1), y = i / double(n - 1);
+                const double z0 = s == 0 ? 0.5 : 0.2 + 0.15 * x, dz = s == 0 ? -0.5 : 0.0;
+                V0[v] = x;
+                V0[v + nV] = y;
+                V0[v + 2 * nV] = z0;
+                V1[v] = x + (urand() - 0.5) * 0.01;
+                V1[v + nV] = y + (urand() - 0.5) * 0.01;
+                V1[v + 2 * nV] = z0 + dz + (urand() - 0.5) * 0.01;
+                if (i + 1 < n && j + 1 < n) {
+                    faces.push_back({ v, v + 1, v + n + 1 });
+                    faces.push_back({ v, v + n + 1, v + n });
+                }
+            }
+    nF = (int)faces.size();
+    F.resize((size_t)3 * nF);
+    std::set<std::pair<int, int>> es;
+    for (int f = 0; f < nF; f++)
+        for (int k = 0; k < 3; k++) {
+            F[f + (size_t)k * nF] = faces[f][k];
+            const int a = faces[f][k], b = faces[f][(k + 1) % 3];
+            es.insert({ std::min(a, b), std::max(a, b) });
+        }
+    nE = (int)es.size();
+    E.resize((size_t)2 * nE);
+    int e = 0;
+    for (auto& pr : es) {
+        E[e] = pr.first;
+        E[e + nE] = pr.second;
+        e++;
+    }
+}
+
+static std::vector<std::pair<int, int>> sorted_pairs(const int32_t* p, int64_t n)
+{
+    std::vector<std::pair<int, int>> v((size_t)n);
+    for (int64_t i = 0; i < n; i++) v[(size_t)i] = { p[2 * i], p[2 * i + 1] };
+    std::sort(v.begin(), v.end());
+    return v;
+}
+
+int main()
+{
+    std::vector<double> V0, V1;
+    std::vector<int32_t> E, F;
+    int nV, nE, nF;
+    make_scene(24, V0, V1, E, F, nV, nE, nF);
+    const MatrixXdView vertices_t0(V0.data(), nV, 3), vertices_t1(V1.data(), nV, 3);
+    const MatrixXiView edges(E.data(), nE, 2), faces(F.data(), nF, 3);
+
+    // ---- boxes: bit-identical to the CPU builders (tests/io.cpp:26-38 uses the same three calls)
+    std::vector<AABB> vertex_boxes, edge_boxes, face_boxes;
+    build_vertex_boxes(vertices_t0, vertices_t1, vertex_boxes);
+    build_edge_boxes(vertex_boxes, edges, edge_boxes);
+    build_face_boxes(vertex_boxes, faces, face_boxes);
+    CHECK((int)vertex_boxes.size() == nV && (int)edge_boxes.size() == nE && (int)face_boxes.size() == nF);
+    std::vector<orc_aabb> ovb((size_t)nV), oeb((size_t)nE), ofb((size_t)nF);
+    orc_build_vertex_boxes(V0.data(), V1.data(), nV, 0.0, ovb.data());
+    orc_build_edge_boxes(ovb.data(), E.data(), nE, oeb.data());
+    orc_build_face_boxes(ovb.data(), F.data(), nF, ofb.data());
+    static_assert(sizeof(orc_aabb) == sizeof(AABB), "box layouts must agree");
+    CHECK(std::memcmp(ovb.data(), vertex_boxes.data(), sizeof(AABB) * (size_t)nV) == 0);
+    CHECK(std::memcmp(oeb.data(), edge_boxes.data(), sizeof(AABB) * (size_t)nE) == 0);
+    CHECK(std::memcmp(ofb.data(), face_boxes.data(), sizeof(AABB) * (size_t)nF) == 0);
+
+    // ---- broad phase (tests/test_broad_phase.cu:94-104)
+    BroadPhase broad_phase;
+    bool threw = false;
+    try {
+        broad_phase.detect_overlaps();
+    } catch (const std::runtime_error&) {
+        threw = true; // broad_phase.cu:123-126
+    }
+    CHECK(threw);
+    broad_phase.build(std::make_shared<DeviceAABBs>(vertex_boxes), std::make_shared<DeviceAABBs>(face_boxes));
+    std::vector<std::pair<int, int>> vf_overlaps = broad_phase.detect_overlaps();
+    CHECK(broad_phase.is_complete());
+    broad_phase.build(std::make_shared<DeviceAABBs>(edge_boxes));
+    std::vector<std::pair<int, int>> ee_overlaps = broad_phase.detect_overlaps();
+
+    int axis = 0;
+    int32_t* op = nullptr;
+    int64_t on = orc_sort_and_sweep_two_lists(ovb.data(), nV, ofb.data(), nF, &axis, &op, 4);
+    auto want_vf = sorted_pairs(op, on);
+    orc_free(op);
+    axis = 0;
+    on = orc_sort_and_sweep(oeb.data(), nE, &axis, &op, 4);
+    auto want_ee = sorted_pairs(op, on);
+    orc_free(op);
+    std::sort(vf_overlaps.begin(), vf_overlaps.end());
+    std::sort(ee_overlaps.begin(), ee_overlaps.end());
+    CHECK(vf_overlaps == want_vf);
+    CHECK(ee_overlaps == want_ee);
+    CHECK(!want_vf.empty() && !want_ee.empty());
+
+    // ---- narrow phase + ccd (tests/test_narrow_phase.cu:41-65)
+    constexpr bool allow_zero_toi = true;
+    constexpr Scalar min_distance = 0;
+    constexpr int max_iterations = -1;
+    constexpr Scalar tolerance = 1e-6;
+    const Scalar toi = ccd(vertices_t0, vertices_t1, edges, faces, min_distance, max_iterations, tolerance, allow_zero_toi);
+    double want_toi = 1;
+    orc_ccd(V0.data(), V1.data(), nV, E.data(), nE, F.data(), nF, min_distance, max_iterations, tolerance, 1,
+            ORC_ARITH_STRICT, 4, &want_toi, nullptr, nullptr);
+    CHECK(toi == want_toi);
+    CHECK(toi < 1 && toi > 0);
+
+    DeviceMesh mesh(vertices_t0, vertices_t1, edges, faces);
+    Scalar t2 = 1;
+    std::vector<std::tuple<int, int, Scalar>> collisions;
+    narrow_phase<true>(mesh, vf_overlaps, max_iterations, tolerance, min_distance, allow_zero_toi, t2, &collisions);
+    for (const auto& [i, j, _toi] : collisions) CHECK(t2 <= _toi); // tests/test_narrow_phase.cu:60-62
+    narrow_phase<false>(mesh, ee_overlaps, max_iterations, tolerance, min_distance, allow_zero_toi, t2);
+    CHECK(t2 == toi);
+
+    threw = false;
+    try {
+        ccd(MatrixXdView(V0.data(), nV, 3), MatrixXdView(V1.data(), nV - 1, 3), edges, faces, 0, -1, 1e-6, true);
+    } catch (const std::runtime_error&) {
+        threw = true; // ccd.cu:94-95
+    }
+    CHECK(threw);
+
+    std::printf("test_ccd_api: %d failure(s); toi=%.17g vf=%zu ee=%zu\n", g_fail, toi, vf_overlaps.size(), ee_overlaps.size());
+    return g_fail ? 1 : 0;
+}

@@ -1,0 +1,99 @@
+"""Multi-GPU host logic on CPU: one process per rank over gloo (world_size 2), exactly the code
+path bench.py uses with RCCL -- candidate-balanced row shards, per-rank VF/EE passes, one
+all-reduce(min) of the time of impact per pass.  The per-rank compute is stubbed with the CPU
+oracle here (tests may use it); the GPU version of the same flow is tests/test_gpu_parity.py::
+test_sharded_sweeps_partition_the_pair_set and bench.py --gpus N."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_balanced_bounds_cover_and_balance():
+    from sccd import dist as sdist
+
+    rng = np.random.default_rng(0)
+    w = rng.integers(0, 1000, size=5000)
+    for parts in (1, 2, 3, 8):
+        b = sdist.balanced_bounds(w, parts)
+        assert b[0] == 0 and b[-1] == len(w) and all(x <= y for x, y in zip(b, b[1:]))
+        sums = [int((w[b[i]:b[i + 1]] + 1).sum()) for i in range(parts)]
+        assert sum(sums) == int((w + 1).sum())
+        assert max(sums) - min(sums) <= 2 * 1001  # within one row's weight of the ideal split
+    assert sdist.balanced_bounds([], 4) == [0, 0, 0, 0, 0]
+    # one huge row cannot be split: it lands in exactly one shard
+    b = sdist.balanced_bounds([10**9, 1, 1, 1], 2)
+    assert b[0] == 0 and b[-1] == 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "scalable-ccd_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+
+    import orc
+    from sccd import dist as sdist
+    from sccd import scenes
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        V0, V1, E, F = scenes.triangle_soup(150, seed=21)
+        vb, eb, fb = orc.build_boxes(V0, V1, E, F)
+        vf, _, _ = orc.sort_and_sweep(vb, fb)
+        ee, _, _ = orc.sort_and_sweep(eb)
+        checked = {"n": 0}
+
+        def run_pass(is_vf, toi):
+            pairs = vf if is_vf else ee
+            # this rank's candidate-balanced share (weights = 1 per pair here)
+            b = sdist.balanced_bounds(np.zeros(len(pairs), np.int64), world)
+            mine = pairs[b[rank]:b[rank + 1]]
+            checked["n"] += len(mine)
+            t, _ = orc.narrow_phase_mt(V0, V1, E, F, mine, is_vf, toi=toi, nthreads=2)
+            return t, {"n_pairs": len(mine)}
+
+        toi, stats = sdist.ccd_sharded(run_pass, rank, world)
+        want, n_vf, n_ee = orc.ccd(V0, V1, E, F)
+        q.put((rank, toi, want, checked["n"], n_vf + n_ee, sdist.allreduce_min(float(rank + 5))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_ccd_two_ranks_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out.sort()
+    (r0, toi0, want0, n0, tot0, m0), (r1, toi1, want1, n1, tot1, m1) = out
+    assert toi0 == toi1 == want0 == want1 and toi0 < 1  # every rank ends with the global minimum
+    assert n0 + n1 == tot0 == tot1                      # the shards partition the queries
+    assert m0 == m1 == 5.0                               # all-reduce(min) really reduces over ranks
+
+
+def test_single_rank_needs_no_process_group():
+    from sccd import dist as sdist
+
+    assert sdist.allreduce_min(0.25) == 0.25
+    toi, st = sdist.ccd_sharded(lambda is_vf, toi: (min(toi, 0.5 if is_vf else 0.75), {"x": 1}), 0, 1)
+    assert toi == 0.5 and st == {"x": 2}
