@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--workload", default="cloth1m", choices=["cloth1m", "clothball10k", "boxes1m", "sort16m"])
     ap.add_argument("--cloth-n", type=int, default=708, help="cloth grid side for cloth1m (708 -> 999,698 tris)")
     ap.add_argument("--arith", type=int, default=0, help="0 strict, 1 fused multiply-add contract")
+    ap.add_argument("--sweep-algo", type=int, default=0, help="0 auto, 1 plain SAP, 2 filter/queue/confirm, 3 direct")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="cloth side of the CPU sample (0 = auto)")
     return ap.parse_args()
@@ -68,6 +69,7 @@ def main():
 
     ctx = sccd.Context(dev.index)
     ctx.set_option(sccd.OPT_ARITH, args.arith)
+    ctx.set_option(sccd.OPT_SWEEP_ALGO, args.sweep_algo)
     ctx.set_option(sccd.OPT_SHARD_RANK, rank)
     ctx.set_option(sccd.OPT_SHARD_COUNT, world)
 

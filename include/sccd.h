@@ -69,7 +69,7 @@ int sccd_synchronize(sccd_ctx* ctx);
 /* options (sccd_set_option) */
 #define SCCD_OPT_ARITH 1            /* 0 strict (default): *, +/- rounded separately; 1: a*b+c fused (nvcc -fmad form) */
 #define SCCD_OPT_NARROW_ALGO 2      /* 0 per-wave work queues (default); 1 level-synchronous BFS (root_finder.cu:431-447) */
-#define SCCD_OPT_SWEEP_ALGO 3       /* 0 filter/queue/confirm STQ (default); 1 plain sweep-and-prune (sweep.cu:48-99)    */
+#define SCCD_OPT_SWEEP_ALGO 3       /* 0 = 2 filter/queue/confirm STQ (default); 1 plain sweep-and-prune (sweep.cu:48-99); 3 direct exact sweep */
 #define SCCD_OPT_SORT_AXIS 4        /* 0/1/2 = x/y/z (reference device path: x, aabb.cu:85-86); -1 = arg-max variance   */
 #define SCCD_OPT_SHARD_RANK 5       /* multi-GPU: this rank's index ...                                                  */
 #define SCCD_OPT_SHARD_COUNT 6      /* ... of this many ranks; the sweep emits only this rank's share of the candidates   */

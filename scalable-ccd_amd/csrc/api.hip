@@ -140,7 +140,10 @@ int sccd_set_option(sccd_ctx* c, int opt, int64_t v)
     switch (opt) {
     case SCCD_OPT_ARITH: c->arith = v ? 1 : 0; break;
     case SCCD_OPT_NARROW_ALGO: c->narrow_algo = v ? 1 : 0; break;
-    case SCCD_OPT_SWEEP_ALGO: c->sweep_algo = v ? 1 : 0; break;
+    case SCCD_OPT_SWEEP_ALGO:
+        if (v < 0 || v > 3) return SCCD_E_INVALID;
+        c->sweep_algo = (int)v;
+        break;
     case SCCD_OPT_SORT_AXIS:
         if (v < -1 || v > 2) return SCCD_E_INVALID;
         c->sort_axis = (int)v;
@@ -467,10 +470,12 @@ static bool build_sorted_list(sccd_ctx* c, const sccd_boxes* b, const GridParams
         launch_cell_count(c, b->raw.as<sccd_aabb>(), n, gp, counts);
     }
     uint32_t total = 0;
+    GridParams hgp;
     {
         ProfScope ps(c, SCCD_PROF_SORT);
         exclusive_scan_u32(c, counts, counts, n, d_total);
         SCCD_HIP(hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+        SCCD_HIP(hipMemcpyAsync(&hgp, gp, sizeof hgp, hipMemcpyDeviceToHost, c->stream));
         SCCD_HIP(hipStreamSynchronize(c->stream));
     }
     if (can_shrink && (int64_t)total > std::max<int64_t>(3 * (int64_t)n, (int64_t)n + 4096)) return false;
@@ -480,20 +485,30 @@ static bool build_sorted_list(sccd_ctx* c, const sccd_boxes* b, const GridParams
     L->key.ensure(sizeof(uint32_t) * (m + pad));
     L->kmax.ensure(sizeof(uint32_t) * (m + pad));
     L->filt.ensure(sizeof(float4) * (m + pad));
-    L->box.ensure(sizeof(sccd_aabb) * (m + 1));
+    L->box.ensure(sizeof(sccd_aabb) * (m + 8));
     L->idx.ensure(sizeof(uint32_t) * (m + pad));
+    L->lowcell.ensure(sizeof(uint32_t) * (m + pad));
     {
         ProfScope ps(c, SCCD_PROF_BOXES);
         launch_cell_fill(c, b->raw.as<sccd_aabb>(), n, gp, counts, L->key.as<uint32_t>(), L->idx.as<uint32_t>());
     }
     {
         ProfScope ps(c, SCCD_PROF_SORT);
-        radix_sort_pairs_u32(c, L->key.as<uint32_t>(), L->idx.as<uint32_t>(), (int64_t)m);
+        c->sort_tmp_keys.ensure(sizeof(uint32_t) * (m + pad));
+        c->sort_tmp_vals.ensure(sizeof(uint32_t) * (m + pad));
+        if (radix_sort_pairs_u32(c, L->key.as<uint32_t>(), L->idx.as<uint32_t>(), (int64_t)m, hgp.key_bits)) {
+            // odd number of passes: the sorted pairs sit in the ping-pong buffers -- swap, no copy
+            std::swap(L->key.p, c->sort_tmp_keys.p);
+            std::swap(L->key.cap, c->sort_tmp_keys.cap);
+            std::swap(L->idx.p, c->sort_tmp_vals.p);
+            std::swap(L->idx.cap, c->sort_tmp_vals.cap);
+        }
     }
     {
         ProfScope ps(c, SCCD_PROF_BOXES);
         launch_entry_gather(c, b->raw.as<sccd_aabb>(), L->key.as<uint32_t>(), L->idx.as<uint32_t>(), (int)m, gp,
-                            L->box.as<sccd_aabb>(), L->filt.as<float4>(), L->kmax.as<uint32_t>());
+                            L->box.as<sccd_aabb>(), L->filt.as<float4>(), L->kmax.as<uint32_t>(),
+                            L->lowcell.as<uint32_t>());
     }
     return true;
 }
@@ -613,6 +628,9 @@ static void bp_detect_partial(sccd_broad_phase* bp)
         }
     }
 
+    // SCCD_OPT_SWEEP_ALGO: 0/2 filter-queue-confirm STQ (default: measured faster on every workload
+    // once its tiles are dealt without tickets), 1 plain SAP cross-check, 3 direct exact sweep.
+    const bool direct = c->sweep_algo == 3;
     // rows of this chunk per sweep class
     int a_lo = (int)std::min<int64_t>(chunk_lo, A->m), a_hi = (int)std::min<int64_t>(chunk_hi, A->m);
     int b_lo = 0, b_hi = 0;
@@ -634,12 +652,12 @@ static void bp_detect_partial(sccd_broad_phase* bp)
             ProfScope ps(c, SCCD_PROF_SWEEP);
             if (!B) {
                 launch_sweep(c, A, A, gp, bp->ranges_a.as<uint2>(), a_lo, a_hi, EMIT_ONE_LIST, bp->overlaps.as<int2>(),
-                             bp->capacity, d_cnt);
+                             bp->capacity, d_cnt, direct);
             } else {
                 launch_sweep(c, A, B, gp, bp->ranges_a.as<uint2>(), a_lo, a_hi, EMIT_ROWS_A, bp->overlaps.as<int2>(),
-                             bp->capacity, d_cnt);
+                             bp->capacity, d_cnt, direct);
                 launch_sweep(c, B, A, gp, bp->ranges_b.as<uint2>(), b_lo, b_hi, EMIT_ROWS_B, bp->overlaps.as<int2>(),
-                             bp->capacity, d_cnt);
+                             bp->capacity, d_cnt, direct);
             }
         }
         SweepCounters h;
@@ -953,6 +971,6 @@ extern "C" int sccd_sort_pairs_u32(sccd_ctx* c, uint32_t* d_keys, uint32_t* d_va
     if (!c) return SCCD_E_INVALID;
     return guarded(c, [&] {
         ProfScope ps(c, SCCD_PROF_SORT);
-        radix_sort_pairs_u32(c, d_keys, d_vals, n);
+        radix_sort_pairs_u32(c, d_keys, d_vals, n, 32);
     });
 }

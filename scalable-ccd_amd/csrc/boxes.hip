@@ -225,11 +225,25 @@ __global__ void grid_setup_k(const GridStats* __restrict__ st, int n_total, int 
     g->ab = ab;
     g->Sa = S[0];
     g->Sb = S[1];
-    g->xb = 32 - cb;
-    g->n_cells = S[0] * S[1];
-    g->pad = 0;
+    // bits of the quantised sort coordinate: 16 quanta per mean box extent keep the candidate
+    // ranges tight; the total key width is rounded up to whole 8-bit radix passes (<= 32 bits)
     const double xr = hi[axis] - lo[axis];
-    const double qmax = (double)((1ull << (32 - cb)) - 1ull);
+    const double xmean = n_total > 0 ? st->sumext[axis] / (double)n_total : 0.0;
+    int need = 32;
+    if (xr > 0.0 && xr < TI_INF && xmean > 0.0) {
+        double ratio = 16.0 * xr / xmean;
+        need = 1;
+        while (need < 32 && (double)(1ull << need) < ratio) need++;
+    }
+    int total = cb + need;
+    total = ((total + 7) / 8) * 8;
+    if (total > 32) total = 32;
+    if (total < 8) total = 8;
+    const int xb = total - cb;
+    g->xb = xb;
+    g->n_cells = S[0] * S[1];
+    g->key_bits = total;
+    const double qmax = (double)((1ull << xb) - 1ull);
     g->x0 = lo[axis];
     g->xscale = (xr > 0.0 && xr < TI_INF) ? qmax / xr : 0.0;
     g->xqmax = qmax;
@@ -289,7 +303,7 @@ __global__ void cell_fill_k(const sccd_aabb* __restrict__ raw, int n, const Grid
 __global__ void entry_gather_k(const sccd_aabb* __restrict__ raw, const uint32_t* __restrict__ key,
                                const uint32_t* __restrict__ idx, int m, const GridParams* __restrict__ gp,
                                sccd_aabb* __restrict__ sorted, float4* __restrict__ filt,
-                               uint32_t* __restrict__ kmax)
+                               uint32_t* __restrict__ kmax, uint32_t* __restrict__ lowcell)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= m) return;
@@ -307,6 +321,7 @@ __global__ void entry_gather_k(const sccd_aabb* __restrict__ raw, const uint32_t
                           __double2float_ru(hi[g.ab]));
     const uint32_t cellbits = (uint32_t)((((unsigned long long)key[e]) >> g.xb) << g.xb);
     kmax[e] = cellbits | grid_qx(g, hi[g.axis]);
+    lowcell[e] = (uint32_t)grid_cell_a(g, lo[g.aa]) | ((uint32_t)grid_cell_b(g, lo[g.ab]) << 16);
 }
 
 // sum and sum of squares of the box centres per axis (sort_and_sweep.cpp:176-186)
@@ -404,11 +419,11 @@ void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams
     SCCD_HIP(hipGetLastError());
 }
 void launch_entry_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,
-                         const GridParams* g, sccd_aabb* sorted, float4* filt, uint32_t* kmax)
+                         const GridParams* g, sccd_aabb* sorted, float4* filt, uint32_t* kmax, uint32_t* lowcell)
 {
     if (m == 0) return;
     hipLaunchKernelGGL(entry_gather_k, dim3(grid_for(m)), dim3(TPB), 0, c->stream, raw, key, idx, m, g, sorted, filt,
-                       kmax);
+                       kmax, lowcell);
     SCCD_HIP(hipGetLastError());
 }
 

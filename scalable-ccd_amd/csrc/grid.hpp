@@ -21,9 +21,9 @@ struct GridStats { // device, filled by box_stats_k
 struct GridParams { // device, written by grid_setup_k
     int axis, aa, ab; // sort axis and the two minor axes
     int Sa, Sb;       // cells along aa and ab (>= 1)
-    int xb;           // bits of the quantised sort coordinate (32 - cell bits)
+    int xb;           // bits of the quantised sort coordinate (sized from range / mean extent)
     int n_cells;
-    int pad;
+    int key_bits;     // cell bits + xb, a multiple of 8: the radix sort runs key_bits / 8 passes
     double x0, xscale, xqmax;
     double a0, inv_ha, b0, inv_hb;
 };

@@ -35,6 +35,7 @@ struct sccd_boxes {
 struct SortedList {
     int m = 0; // entries (>= number of boxes)
     DevBuf key, kmax, filt, box, idx;
+    DevBuf lowcell; // uint32[m]: lowest cell of the entry's box on the two minor axes (a | b << 16)
 };
 
 struct sccd_broad_phase {
@@ -70,7 +71,7 @@ void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParam
 void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, const uint32_t* offsets,
                       uint32_t* key, uint32_t* idx);
 void launch_entry_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,
-                         const GridParams* g, sccd_aabb* sorted, float4* filt, uint32_t* kmax);
+                         const GridParams* g, sccd_aabb* sorted, float4* filt, uint32_t* kmax, uint32_t* lowcell);
 
 // scan.hip
 void exclusive_scan_u32(sccd_ctx* c, const uint32_t* in, uint32_t* out, int n, uint32_t* d_total);
@@ -78,7 +79,7 @@ void exclusive_scan_u32(sccd_ctx* c, const uint32_t* in, uint32_t* out, int n, u
 int pick_sort_axis(sccd_ctx* c, const sccd_aabb* raw, int n);
 
 // sort.hip: in-place LSD radix sort of (key, value) pairs by key, ascending, stable
-void radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n);
+bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n, int key_bits = 32);
 
 // sweep.hip
 enum SweepEmit { EMIT_ONE_LIST = 0, EMIT_ROWS_A = 1, EMIT_ROWS_B = 2 };
@@ -94,7 +95,7 @@ void launch_ranges(sccd_ctx* c, const SortedList* rows, const SortedList* cols, 
                    unsigned long long* d_candidates);
 void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, const GridParams* gp,
                   const uint2* ranges, int row_begin, int row_end, int emit, int2* out, int64_t capacity,
-                  SweepCounters* d_cnt);
+                  SweepCounters* d_cnt, bool direct);
 
 // narrow.hip
 struct NarrowParams {

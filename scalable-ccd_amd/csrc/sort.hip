@@ -77,11 +77,24 @@ __global__ __launch_bounds__(RS_THREADS) void os_hist_k(const uint32_t* __restri
     __syncthreads();
     for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
         const long long base = (long long)tile * RS_TILE;
-#pragma unroll 4
-        for (int r = 0; r < RS_ITEMS; r++) {
-            const long long i = base + (long long)r * RS_THREADS + threadIdx.x;
-            if (i < n) {
-                const uint32_t k = keys[i];
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS / 4; r++) {
+            const long long i = base + ((long long)r * RS_THREADS + threadIdx.x) * 4;
+            uint32_t kk[4];
+            int cntk = 0;
+            if (i + 3 < n) {
+                const uint4 k4 = *reinterpret_cast<const uint4*>(keys + i);
+                kk[0] = k4.x;
+                kk[1] = k4.y;
+                kk[2] = k4.z;
+                kk[3] = k4.w;
+                cntk = 4;
+            } else {
+                for (int j = 0; j < 4; j++)
+                    if (i + j < n) kk[cntk++] = keys[i + j];
+            }
+            for (int j = 0; j < cntk; j++) {
+                const uint32_t k = kk[j];
                 atomicAdd(&h[0][k & 255u], 1u);
                 atomicAdd(&h[1][(k >> 8) & 255u], 1u);
                 atomicAdd(&h[2][(k >> 16) & 255u], 1u);
@@ -94,110 +107,194 @@ __global__ __launch_bounds__(RS_THREADS) void os_hist_k(const uint32_t* __restri
     for (int p = 0; p < 4; p++) partial[(size_t)blockIdx.x * 1024 + p * 256 + threadIdx.x] = h[p][threadIdx.x];
 }
 
-// bases[p][d] = number of keys whose digit p is < d
-__global__ __launch_bounds__(1024) void os_bases_k(const uint32_t* __restrict__ partial, int n_blocks,
-                                                   uint32_t* __restrict__ bases)
+// bases[p][d] = number of keys whose digit p is < d.  One block per pass; thread d sums its
+// bin over the per-block partial histograms (coalesced across d), then a block scan over d.
+__global__ __launch_bounds__(256) void os_bases_k(const uint32_t* __restrict__ partial, int n_blocks,
+                                                  uint32_t* __restrict__ bases)
 {
-    __shared__ uint32_t wsum[16];
-    const int t = threadIdx.x; // (pass, digit) = (t >> 8, t & 255)
+    __shared__ uint32_t wsum[4];
+    const int p = blockIdx.x, d = threadIdx.x;
     uint32_t s = 0;
-    for (int b = 0; b < n_blocks; b++) s += partial[(size_t)b * 1024 + t];
-    const int lane = lane_id(), w = t >> 6;
+    for (int b = 0; b < n_blocks; b++) s += partial[(size_t)b * 1024 + p * 256 + d];
+    const int lane = lane_id(), w = d >> 6;
     const uint32_t incl = (uint32_t)wave_incl_scan((int)s);
     if (lane == 63) wsum[w] = incl;
     __syncthreads();
-    uint32_t base = 0; // waves of the same pass that precede this one (4 waves per pass)
-    for (int k = (w & ~3); k < w; k++) base += wsum[k];
-    bases[t] = base + incl - s;
+    uint32_t base = 0;
+    for (int k = 0; k < w; k++) base += wsum[k];
+    bases[p * 256 + d] = base + incl - s;
 }
 
+// blocked 16-byte loads of one wave's share of a tile (4 x uint4 of keys, 4 x uint4 of values)
+struct TileRegs {
+    uint4 k[RS_ITEMS / 4], v[RS_ITEMS / 4];
+};
+__device__ __forceinline__ void tile_load(TileRegs& t, const uint32_t* __restrict__ keys_in,
+                                          const uint32_t* __restrict__ vals_in, long long wave_base, int lane,
+                                          long long n)
+{
+#pragma unroll
+    for (int sgm = 0; sgm < RS_ITEMS / 4; sgm++) {
+        const long long i = wave_base + sgm * 256 + lane * 4;
+        uint4 k4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu), v4 = make_uint4(0u, 0u, 0u, 0u);
+        if (i + 3 < n) {
+            k4 = *reinterpret_cast<const uint4*>(keys_in + i);
+            v4 = *reinterpret_cast<const uint4*>(vals_in + i);
+        } else {
+            if (i < n) { k4.x = keys_in[i]; v4.x = vals_in[i]; }
+            if (i + 1 < n) { k4.y = keys_in[i + 1]; v4.y = vals_in[i + 1]; }
+            if (i + 2 < n) { k4.z = keys_in[i + 2]; v4.z = vals_in[i + 2]; }
+        }
+        t.k[sgm] = k4;
+        t.v[sgm] = v4;
+    }
+}
+
+// Persistent blocks; tiles are taken by atomic ticket (a tile only ever waits for tiles that
+// already run), TWO tickets ahead, and the next tile's loads are issued before the current tile
+// is ranked, so the ticket and HBM latencies are off the critical path.
 __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restrict__ keys_in,
                                                         const uint32_t* __restrict__ vals_in,
                                                         uint32_t* __restrict__ keys_out,
                                                         uint32_t* __restrict__ vals_out, long long n, int shift,
-                                                        const uint32_t* __restrict__ bases, uint32_t* status,
-                                                        uint32_t* ticket)
+                                                        int num_tiles, const uint32_t* __restrict__ bases,
+                                                        uint32_t* status, uint32_t* ticket, int dbg)
 {
-    __shared__ uint32_t wcnt[RS_WAVES][256]; // per-wave digit counts -> per-wave local offsets
+    __shared__ uint32_t wtot[RS_WAVES][256]; // per-wave digit totals -> offset of the wave inside the digit's run
+    __shared__ uint32_t wrun[RS_WAVES][256]; // running per-wave counters of the ranking
     __shared__ uint32_t dig_excl[256];       // exclusive offset of the digit inside the tile
     __shared__ uint32_t dig_gbase[256];      // global position of the digit's first key of the tile
     __shared__ uint32_t s_keys[RS_TILE];
     __shared__ uint32_t s_vals[RS_TILE];
-    __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_tk[2];
     const int lane = lane_id(), w = threadIdx.x >> 6;
+    uint32_t* wk = s_keys + w * RS_WAVE_SPAN;
+    uint32_t* wv = s_vals + w * RS_WAVE_SPAN;
 
-    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-#pragma unroll
-    for (int k = 0; k < RS_WAVES; k++) wcnt[k][threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    const long long tile_base = (long long)tile * RS_TILE;
-    const long long wave_base = tile_base + (long long)w * RS_WAVE_SPAN;
-    const int tile_count = (int)min((long long)RS_TILE, n - tile_base);
-
-    uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
-    bool valid[RS_ITEMS];
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-        const long long i = wave_base + r * 64 + lane;
-        valid[r] = i < n;
-        key[r] = valid[r] ? keys_in[i] : 0xFFFFFFFFu;
-        val[r] = valid[r] ? vals_in[i] : 0u;
+    if (threadIdx.x == 0) {
+        s_tk[0] = atomicAdd(ticket, 1u);
+        s_tk[1] = atomicAdd(ticket, 1u);
     }
-    wave_rank_rows(key, valid, shift, wcnt[w], rank);
     __syncthreads();
+    uint32_t t0 = s_tk[0], t1 = s_tk[1];
+    TileRegs pre;
+    if ((int)t0 < num_tiles) tile_load(pre, keys_in, vals_in, (long long)t0 * RS_TILE + (long long)w * RS_WAVE_SPAN, lane, n);
 
-    // thread d owns digit d: tile count, publish, look back, local layout
-    {
-        const int d = threadIdx.x;
-        uint32_t cnt = 0;
+    while ((int)t0 < num_tiles) {
+        const uint32_t tile = t0;
+        const long long tile_base = (long long)tile * RS_TILE;
+        const long long wave_base = tile_base + (long long)w * RS_WAVE_SPAN;
+        const int tile_count = (int)min((long long)RS_TILE, n - tile_base);
+        // 0. the prefetched blocked registers -> LDS -> striped registers (row r, lane l <-> index 64 r + l)
+#pragma unroll
+        for (int sgm = 0; sgm < RS_ITEMS / 4; sgm++) {
+            *reinterpret_cast<uint4*>(wk + sgm * 256 + lane * 4) = pre.k[sgm];
+            *reinterpret_cast<uint4*>(wv + sgm * 256 + lane * 4) = pre.v[sgm];
+        }
 #pragma unroll
         for (int k = 0; k < RS_WAVES; k++) {
-            const uint32_t t = wcnt[k][d];
-            wcnt[k][d] = cnt; // offset of wave k inside the digit's run
-            cnt += t;
+            wtot[k][threadIdx.x] = 0;
+            wrun[k][threadIdx.x] = 0;
         }
-        uint32_t* my = status + (size_t)tile * 256 + d;
-        __hip_atomic_store(my, cnt | OS_FLAG_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t excl = 0;
-        for (long long t = (long long)tile - 1; t >= 0; t--) {
-            const uint32_t* p = status + (size_t)t * 256 + d;
-            uint32_t v;
-            do {
-                v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } while (v == 0u); // the tile has a smaller ticket, so it is running and will publish
-            excl += v & OS_VALUE_MASK;
-            if (v & OS_FLAG_PREFIX) break;
-        }
-        __hip_atomic_store(my, (excl + cnt) | OS_FLAG_PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        dig_gbase[d] = bases[d] + excl;
-        // exclusive scan of cnt over the 256 digits -> position of the digit's run inside the tile
-        const uint32_t incl = (uint32_t)wave_incl_scan((int)cnt);
-        if (lane == 63) s_keys[w] = incl; // scratch: s_keys is not in use yet
-        __syncthreads();
-        uint32_t base = 0;
-        for (int k = 0; k < w; k++) base += s_keys[k];
-        dig_excl[d] = base + incl - cnt;
-    }
-    __syncthreads();
-    // stage the tile in LDS in sorted order
+        // request the ticket after next, start the next tile's loads
+        uint32_t t2_req = 0;
+        if (threadIdx.x == 0) t2_req = atomicAdd(ticket, 1u);
+        if ((int)t1 < num_tiles) tile_load(pre, keys_in, vals_in, (long long)t1 * RS_TILE + (long long)w * RS_WAVE_SPAN, lane, n);
+        wave_lds_fence();
+        uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+        bool valid[RS_ITEMS];
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-        if (valid[r]) {
-            const uint32_t d = (key[r] >> shift) & 255u;
-            const uint32_t pos = dig_excl[d] + wcnt[w][d] + rank[r];
-            s_keys[pos] = key[r];
-            s_vals[pos] = val[r];
+        for (int r = 0; r < RS_ITEMS; r++) {
+            valid[r] = wave_base + r * 64 + lane < n;
+            key[r] = wk[r * 64 + lane];
+            val[r] = wv[r * 64 + lane];
         }
-    }
-    __syncthreads();
-    // consecutive threads write consecutive addresses of each digit's run
-    for (int i = threadIdx.x; i < tile_count; i += RS_THREADS) {
-        const uint32_t k = s_keys[i];
-        const uint32_t d = (k >> shift) & 255u;
-        const uint32_t dst = dig_gbase[d] + ((uint32_t)i - dig_excl[d]);
-        keys_out[dst] = k;
-        vals_out[dst] = s_vals[i];
+        __syncthreads(); // counters zeroed by all, LDS tile buffers read by all
+        // 1. digit counts first (LDS atomics) so the tile can publish them before the ranking
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; r++)
+            if (valid[r]) atomicAdd(&wtot[w][(key[r] >> shift) & 255u], 1u);
+        __syncthreads();
+        uint32_t cnt = 0;
+        uint32_t* my = status + (size_t)tile * 256 + threadIdx.x;
+        {
+            const int d = threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < RS_WAVES; k++) {
+                const uint32_t t = wtot[k][d];
+                wtot[k][d] = cnt; // offset of wave k inside the digit's run
+                cnt += t;
+            }
+            __hip_atomic_store(my, cnt | OS_FLAG_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // exclusive scan of cnt over the 256 digits -> position of the digit's run inside the tile
+            const uint32_t incl = (uint32_t)wave_incl_scan((int)cnt);
+            if (lane == 63) dig_gbase[w] = incl; // scratch
+            __syncthreads();
+            uint32_t base = 0;
+            for (int k = 0; k < w; k++) base += dig_gbase[k];
+            dig_excl[d] = base + incl - cnt;
+        }
+        // 2. ranking (the predecessors' words propagate meanwhile)
+        if (dbg & 2) {
+#pragma unroll
+            for (int r = 0; r < RS_ITEMS; r++) rank[r] = 0;
+        } else {
+            wave_rank_rows(key, valid, shift, wrun[w], rank);
+        }
+        __syncthreads(); // dig_gbase scratch consumed before it is overwritten below
+        // 3. decoupled look-back, thread d = digit d, eight predecessor tiles probed per round
+        {
+            const int d = threadIdx.x;
+            uint32_t excl = 0;
+            long long t = (long long)tile - 1;
+            bool done = t < 0 || (dbg & 4);
+            while (!done) {
+                uint32_t v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    v[j] = (t - j >= 0) ? __hip_atomic_load(status + (size_t)(t - j) * 256 + d, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT)
+                                        : OS_FLAG_PREFIX;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (done) break;
+                    if (v[j] == 0u) break; // not published yet: probe again from this tile
+                    excl += v[j] & OS_VALUE_MASK;
+                    if (v[j] & OS_FLAG_PREFIX) done = true;
+                    --t;
+                }
+            }
+            __hip_atomic_store(my, (excl + cnt) | OS_FLAG_PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dig_gbase[d] = bases[d] + excl;
+            if (d == 0) s_tk[0] = t2_req;
+        }
+        // 4. stage the tile in LDS in sorted order (the striped copies were consumed before step 1)
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; r++) {
+            if (valid[r]) {
+                const uint32_t d = (key[r] >> shift) & 255u;
+                const uint32_t pos = dig_excl[d] + wtot[w][d] + rank[r];
+                s_keys[pos] = key[r];
+                s_vals[pos] = val[r];
+            }
+        }
+        __syncthreads();
+        // 5. consecutive threads write consecutive addresses of each digit's run
+        for (int i = threadIdx.x; i < tile_count; i += RS_THREADS) {
+            const uint32_t k = s_keys[i];
+            const uint32_t d = (k >> shift) & 255u;
+            const uint32_t dst = dig_gbase[d] + ((uint32_t)i - dig_excl[d]);
+            if (dbg & 1) {
+                if (dst == 0xFFFFFFFFu) keys_out[0] = k + s_vals[i];
+            } else {
+                keys_out[dst] = k;
+                vals_out[dst] = s_vals[i];
+            }
+        }
+        const uint32_t t2 = s_tk[0];
+        __syncthreads(); // LDS tile buffers and s_tk free for the next tile
+        t0 = t1;
+        t1 = t2;
     }
 }
 
@@ -265,9 +362,12 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_k(const uint32_t* __res
 
 } // namespace
 
-void radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n)
+// Sorts by the low `key_bits` bits (a multiple of 8).  Returns true when the result ended in the
+// context's ping-pong buffers (odd number of passes) instead of (keys, vals).
+bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n, int key_bits)
 {
-    if (n <= 1) return;
+    if (n <= 1) return false;
+    const int passes = std::max(1, std::min(4, (key_bits + 7) / 8));
     SCCD_REQUIRE(n < (1ll << 30), "radix sort: at most 2^30-1 elements");
     const int num_tiles = (int)((n + RS_TILE - 1) / RS_TILE);
     c->sort_tmp_keys.ensure(sizeof(uint32_t) * (size_t)n);
@@ -283,7 +383,7 @@ void radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
     if (classic) {
         c->sort_hist.ensure(sizeof(uint32_t) * 256 * (size_t)num_tiles);
         uint32_t* counts = c->sort_hist.as<uint32_t>();
-        for (int pass = 0; pass < 4; pass++) {
+        for (int pass = 0; pass < passes; pass++) {
             const int shift = 8 * pass;
             hipLaunchKernelGGL(rs_count_k, dim3(num_tiles), dim3(RS_THREADS), 0, c->stream, k_in, (long long)n, shift,
                                num_tiles, counts);
@@ -295,10 +395,11 @@ void radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
             std::swap(v_in, v_out);
         }
         SCCD_HIP(hipGetLastError());
-        return; // 4 passes: the result is back in (keys, vals)
+        return (passes & 1) != 0;
     }
     // onesweep: [4 tickets (padded to 64 B)] [bases 4x256] [partial hist blocks x 1024] [status 4 x tiles x 256]
     const int hist_blocks = std::min(num_tiles, c->num_cus);
+    const int dbg = std::getenv("SCCD_SORT_DBG") ? std::atoi(std::getenv("SCCD_SORT_DBG")) : 0; // timing ablations only
     const size_t off_bases = 64, off_partial = off_bases + 4096, off_status = off_partial + (size_t)hist_blocks * 4096;
     const size_t status_bytes = (size_t)4 * num_tiles * 256 * sizeof(uint32_t);
     c->sort_hist.ensure(off_status + status_bytes);
@@ -312,14 +413,14 @@ void radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
     SCCD_HIP(hipMemsetAsync(status, 0, status_bytes, c->stream));
     hipLaunchKernelGGL(os_hist_k, dim3(hist_blocks), dim3(RS_THREADS), 0, c->stream, k_in, (long long)n, num_tiles,
                        partial);
-    hipLaunchKernelGGL(os_bases_k, dim3(1), dim3(1024), 0, c->stream, partial, hist_blocks, bases);
-    for (int pass = 0; pass < 4; pass++) {
-        hipLaunchKernelGGL(os_pass_k, dim3(num_tiles), dim3(RS_THREADS), 0, c->stream, k_in, v_in, k_out, v_out,
-                           (long long)n, 8 * pass, bases + 256 * pass, status + (size_t)pass * num_tiles * 256,
-                           tickets + pass);
+    hipLaunchKernelGGL(os_bases_k, dim3(4), dim3(256), 0, c->stream, partial, hist_blocks, bases);
+    for (int pass = 0; pass < passes; pass++) {
+        hipLaunchKernelGGL(os_pass_k, dim3(std::min(num_tiles, c->num_cus * 3)), dim3(RS_THREADS), 0, c->stream, k_in,
+                           v_in, k_out, v_out, (long long)n, 8 * pass, num_tiles, bases + 256 * pass,
+                           status + (size_t)pass * num_tiles * 256, tickets + pass, dbg);
         std::swap(k_in, k_out);
         std::swap(v_in, v_out);
     }
     SCCD_HIP(hipGetLastError());
-    // 4 passes: the result is back in (keys, vals)
+    return (passes & 1) != 0;
 }

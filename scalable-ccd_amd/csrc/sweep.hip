@@ -253,13 +253,12 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_stq_k(
     int qcount = 0;
     const int num_tiles = (row_end - row_begin + 63) / 64;
 
-    for (;;) {
-        unsigned tile = 0;
-        if (lane == 0) tile = atomicAdd(&cnt->tile_ticket, 1u);
-        tile = readfirst_u32(tile);
-        if ((int)tile >= num_tiles) break;
-
-        const int row = row_begin + (int)tile * 64 + lane;
+    // Tiles are dealt round-robin to the waves of the grid.  (A ticket per tile made the whole
+    // sweep ticket-bound: one hot word serves ~90 atomics/us chip-wide, and a launch has ~27k
+    // tiles that each take only a few microseconds.)
+    const int n_waves = (int)gridDim.x * SW_WAVES;
+    for (int tile = (int)blockIdx.x * SW_WAVES + w; tile < num_tiles; tile += n_waves) {
+        const int row = row_begin + tile * 64 + lane;
         const bool valid = row < row_end;
         uint2 rg = make_uint2(0u, 0u);
         float4 fr = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -342,6 +341,74 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_stq_k(
     em.flush();
 }
 
+// Direct exact sweep: the kernel of choice once the cell grid has cut the candidates down to a
+// few per emitted pair.  Lane = row with its EXACT box, ids and lowest cell in registers; the
+// column records (64-byte box + lowest cell) are wave-uniform, i.e. scalar loads; the exact
+// inclusive test, the vertex-id test and the owner-cell test run in the loop and survivors go
+// straight to the staged emitter.  No candidate queue, no dependent gathers.
+__global__ __launch_bounds__(SW_THREADS) void sweep_direct_k(
+    const sccd_aabb* __restrict__ box_r, const uint32_t* __restrict__ key_r, const uint32_t* __restrict__ low_r,
+    const uint2* __restrict__ ranges, int row_begin, int row_end, const sccd_aabb* __restrict__ box_c,
+    const uint32_t* __restrict__ low_c, const GridParams* __restrict__ gp, int emit, int2* __restrict__ out,
+    long long capacity, SweepCounters* __restrict__ cnt)
+{
+    __shared__ int2 o_s[SW_WAVES][SW_OCAP];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    Emitter em { o_s[w], 0, out, capacity, &cnt->n_pairs };
+    const int xb = gp->xb, Sb = gp->Sb;
+    const bool one_cell = gp->n_cells <= 1;
+    const int num_tiles = (row_end - row_begin + 63) / 64;
+    // Tiles are dealt round-robin to the waves of the grid.  (A ticket per tile made the whole
+    // sweep ticket-bound: one hot word serves ~90 atomics/us chip-wide, and a launch has ~27k
+    // tiles that each take only a few microseconds.)
+    const int n_waves = (int)gridDim.x * SW_WAVES;
+    for (int tile = (int)blockIdx.x * SW_WAVES + w; tile < num_tiles; tile += n_waves) {
+        const int row = row_begin + tile * 64 + lane;
+        const bool valid = row < row_end;
+        uint2 rg = make_uint2(0u, 0u);
+        ExactBox a;
+        int ca = 0, cb = 0, la = 0, lb = 0;
+        if (valid) {
+            rg = ranges[row];
+            a = load_exact(box_r + row);
+            const int cell = (int)((unsigned long long)key_r[row] >> xb);
+            ca = cell / Sb;
+            cb = cell - ca * Sb;
+            const uint32_t lw = low_r[row];
+            la = (int)(lw & 0xFFFFu);
+            lb = (int)(lw >> 16);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                a.lo[k] = 1.0; // empty box: never intersects
+                a.hi[k] = -1.0;
+                a.v[k] = 0;
+            }
+            a.eid = 0;
+        }
+        const bool nonempty = valid && rg.y > rg.x;
+        const unsigned jmin = readfirst_u32(wave_min_u32(nonempty ? rg.x : 0xFFFFFFFFu));
+        const unsigned jmax = readfirst_u32(wave_max_u32(nonempty ? rg.y : 0u));
+        for (unsigned j0 = jmin; j0 < jmax; j0 += 4) { // wave-uniform columns, 4 scalar records per wait
+            ExactBox b[4];
+            uint32_t lw[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { // the arrays are padded: reading past the last column is harmless
+                b[u] = load_exact(box_c + j0 + u);
+                lw[u] = low_c[j0 + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned j = j0 + (unsigned)u;
+                bool ok = j >= rg.x && j < rg.y && exact_pair_ok(a, b[u]);
+                if (!one_cell) ok = ok && max(la, (int)(lw[u] & 0xFFFFu)) == ca && max(lb, (int)(lw[u] >> 16)) == cb;
+                em.push(ok, make_pair_out(emit, a.eid, b[u].eid));
+            }
+        }
+    }
+    em.flush();
+}
+
 // Plain sweep-and-prune, one thread per row, exact boxes only (the reference's baseline
 // variant sweep_and_prune<>, sweep.cu:48-99).  Kept as an in-library cross-check of the STQ
 // kernel (SCCD_OPT_SWEEP_ALGO = 1); not tuned.
@@ -380,7 +447,7 @@ void launch_ranges(sccd_ctx* c, const SortedList* rows, const SortedList* cols, 
 
 void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, const GridParams* gp,
                   const uint2* ranges, int row_begin, int row_end, int emit, int2* out, int64_t capacity,
-                  SweepCounters* d_cnt)
+                  SweepCounters* d_cnt, bool direct)
 {
     if (row_end <= row_begin || cols->m == 0) return;
     SCCD_HIP(hipMemsetAsync(&d_cnt->tile_ticket, 0, sizeof(unsigned), c->stream));
@@ -389,6 +456,13 @@ void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, c
         hipLaunchKernelGGL(sweep_sap_k, dim3((n + 255) / 256), dim3(256), 0, c->stream, rows->box.as<sccd_aabb>(),
                            rows->key.as<uint32_t>(), ranges, row_begin, row_end, cols->box.as<sccd_aabb>(), gp, emit,
                            out, (long long)capacity, d_cnt);
+    } else if (direct) {
+        const int num_tiles = (row_end - row_begin + 63) / 64;
+        const int grid = std::max(1, std::min((num_tiles + SW_WAVES - 1) / SW_WAVES, c->num_cus * 4));
+        hipLaunchKernelGGL(sweep_direct_k, dim3(grid), dim3(SW_THREADS), 0, c->stream, rows->box.as<sccd_aabb>(),
+                           rows->key.as<uint32_t>(), rows->lowcell.as<uint32_t>(), ranges, row_begin, row_end,
+                           cols->box.as<sccd_aabb>(), cols->lowcell.as<uint32_t>(), gp, emit, out,
+                           (long long)capacity, d_cnt);
     } else {
         const int num_tiles = (row_end - row_begin + 63) / 64;
         const int grid = std::max(1, std::min((num_tiles + SW_WAVES - 1) / SW_WAVES, c->num_cus * 4));

@@ -62,7 +62,7 @@ def test_device_boxes_from_mesh(sccd, ctx, orc):
 
 # ---- broad phase ------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["cloth_ball_10k", "soup_400", "soup_dense", "folded_120"])
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3])  # auto, plain SAP, filter/queue/confirm STQ, direct exact sweep
 def test_overlap_pairs_identical(sccd, ctx, orc, name, algo):
     V0, V1, E, F = _scene(name)
     vb, eb, fb = orc.build_boxes(V0, V1, E, F)
@@ -141,7 +141,8 @@ def test_broad_phase_edge_cases(sccd, ctx, orc):
     assert np.array_equal(_sorted(bp.detect_overlaps()), want)
 
 
-def test_crowded_boxes_overflow_retry(sccd, ctx, orc):
+@pytest.mark.parametrize("algo", [0, 2, 3])
+def test_crowded_boxes_overflow_retry(sccd, ctx, orc, algo):
     # everything overlaps everything: exercises the crowded-block path of the candidate queue and
     # the overlap-buffer overflow -> exact-size rerun (broad_phase.cu:142-203)
     n = 1500
@@ -149,12 +150,14 @@ def test_crowded_boxes_overflow_retry(sccd, ctx, orc):
     want, _, _ = orc.sort_and_sweep(b, nthreads=8)
     assert len(want) > 0.25 * n * (n - 1) / 2
     ctx.set_option(sccd.OPT_OVERLAP_CAPACITY, 1000)
+    ctx.set_option(sccd.OPT_SWEEP_ALGO, algo)
     try:
         bp = sccd.BroadPhase(ctx)
         bp.build(sccd.DeviceAABBs(b, ctx))
         got = bp.detect_overlaps()
     finally:
         ctx.set_option(sccd.OPT_OVERLAP_CAPACITY, 0)
+        ctx.set_option(sccd.OPT_SWEEP_ALGO, 0)
     assert np.array_equal(_sorted(got), want)
 
 
