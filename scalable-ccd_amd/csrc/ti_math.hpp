@@ -15,30 +15,49 @@ struct TIQuery {
     double v[8][3];
     double err[3];
     double tol[3];
+    // np_queue_k only: fl(1 / tol[k]) and whether the reciprocal shortcut below is exact for it
+    double inv_tol[3];
+    bool inv_ok;
 };
+
+// split_dimension compares w_k / tol_k (root_finder.cu:202).  For a bisected interval w_k is a
+// power of two, and scaling by a power of two never changes a rounding:
+//   fl(w_k / tol_k) == w_k * fl(1 / tol_k)      (no overflow/underflow)
+// so the three divisions per check become three multiplications by per-query constants, with
+// the same bits.  Guard: every reciprocal is 0, +inf or within [2^-500, 2^500].
+__device__ __forceinline__ void ti_prepare_inv_tol(TIQuery& q)
+{
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double r = 1.0 / q.tol[k];
+        q.inv_tol[k] = r;
+        const double a = fabs(r);
+        ok = ok && (a == 0.0 || a == __builtin_huge_val() || (a >= 0x1p-500 && a <= 0x1p500));
+    }
+    q.inv_ok = ok;
+}
 
 __device__ __forceinline__ double ti_min(double a, double b) { return (b < a) ? b : a; }
 __device__ __forceinline__ double ti_max(double a, double b) { return (a < b) ? b : a; }
 
-// add_data<is_vf> (narrow_phase.cu:24-74) on the packed mesh: one 64-byte record per vertex
+// add_data<is_vf> (narrow_phase.cu:24-74) on the packed mesh, in two steps so that the narrow-phase
+// kernel can software-pipeline them: the four vertex ids of a query ...
 template <bool VF>
-__device__ __forceinline__ void ti_gather(const double* __restrict__ V, const int2* __restrict__ E,
-                                          const int4* __restrict__ F, int2 pr, double v[8][3])
+__device__ __forceinline__ int4 ti_indices(const int2* __restrict__ E, const int4* __restrict__ F, int2 pr)
 {
-    int id[4];
     if (VF) { // :41-53  v0 = vertex, v1..v3 = face corners
         const int4 f = F[pr.y];
-        id[0] = pr.x;
-        id[1] = f.x;
-        id[2] = f.y;
-        id[3] = f.z;
+        return make_int4(pr.x, f.x, f.y, f.z);
     } else { // :54-66  v0,v1 = edge a, v2,v3 = edge b
         const int2 ea = E[pr.x], eb = E[pr.y];
-        id[0] = ea.x;
-        id[1] = ea.y;
-        id[2] = eb.x;
-        id[3] = eb.y;
+        return make_int4(ea.x, ea.y, eb.x, eb.y);
     }
+}
+// ... and the gather of their 64-byte records {x0,y0,z0,0,x1,y1,z1,0}
+__device__ __forceinline__ void ti_gather_ids(const double* __restrict__ V, int4 ids, double v[8][3])
+{
+    const int id[4] = { ids.x, ids.y, ids.z, ids.w };
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const double4* rec = reinterpret_cast<const double4*>(V) + 2 * (size_t)id[k];
@@ -50,6 +69,12 @@ __device__ __forceinline__ void ti_gather(const double* __restrict__ V, const in
         v[k + 4][1] = b.y;
         v[k + 4][2] = b.z;
     }
+}
+template <bool VF>
+__device__ __forceinline__ void ti_gather(const double* __restrict__ V, const int2* __restrict__ E,
+                                          const int4* __restrict__ F, int2 pr, double v[8][3])
+{
+    ti_gather_ids(V, ti_indices<VF>(E, F, pr), v);
 }
 
 __device__ __forceinline__ double ti_linf(const double a[3], const double b[3])
@@ -213,7 +238,7 @@ struct TIStep {
     double mid;
     bool checked;
 };
-template <bool VF, int ARITH>
+template <bool VF, int ARITH, bool INVTOL = false>
 __device__ __forceinline__ TIStep ti_step(const TIQuery& q, const double lo[3], const double hi[3], double ms,
                                           double co_domain_tol, bool allow_zero_toi, double prune_toi)
 {
@@ -238,7 +263,24 @@ __device__ __forceinline__ TIStep ti_step(const TIQuery& q, const double lo[3], 
         return r;
     }
     // split_dimension :200-211
-    const double r0 = w0 / q.tol[0], r1 = w1 / q.tol[1], r2 = w2 / q.tol[2];
+    double r0, r1, r2;
+    bool fast = false;
+    if (INVTOL) { // all widths exact powers of two >= 2^-200 (mantissa bits zero, biased exponent >= 823)
+        const unsigned long long b0 = (unsigned long long)__double_as_longlong(w0),
+                                 b1 = (unsigned long long)__double_as_longlong(w1),
+                                 b2 = (unsigned long long)__double_as_longlong(w2);
+        const unsigned long long emin = min(min(b0, b1), b2) >> 52; // widths are positive here
+        fast = q.inv_ok && ((b0 | b1 | b2) & 0xFFFFFFFFFFFFFull) == 0ull && emin >= 823ull;
+    }
+    if (fast) {
+        r0 = w0 * q.inv_tol[0];
+        r1 = w1 * q.inv_tol[1];
+        r2 = w2 * q.inv_tol[2];
+    } else {
+        r0 = w0 / q.tol[0];
+        r1 = w1 / q.tol[1];
+        r2 = w2 / q.tol[2];
+    }
     int split;
     if (r0 >= r1 && r0 >= r2) split = 0;
     else if (r1 >= r0 && r1 >= r2) split = 1;

@@ -17,7 +17,8 @@ for p in (os.path.join(ROOT, "scalable-ccd_amd"), os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-CASES = ["cloth_ball_10k", "cloth_ball_10k_ms", "soup_400", "random_100k", "cloth_ball_small"]
+CASES = ["cloth_ball_10k", "cloth_ball_10k_ms", "soup_400", "random_100k", "cloth_ball_small", "folded_cloth_708"]
+SLOW_CASES = {"folded_cloth_708"}  # BASELINE configs[3]/[4]; ~10 s of CPU, skipped by the CPU test suite
 
 
 def _sha(pairs):
@@ -33,6 +34,8 @@ def scene_of(name):
         return scenes.cloth_ball(20, 1, seed=3)
     if name == "soup_400":
         return scenes.triangle_soup(400, seed=11)
+    if name == "folded_cloth_708":
+        return scenes.folded_cloth(708)
     raise KeyError(name)
 
 

@@ -346,3 +346,86 @@ def test_sort_is_a_stable_permutation(sccd, ctx):
         want_k, want_v = torch.sort(keys, stable=True)
         assert torch.equal(k.cpu().to(torch.int64), want_k)
         assert torch.equal(v.cpu().to(torch.int64), want_v)
+
+
+# ---- BASELINE.json full size (configs[3]/[4]): 708 x 708 folded cloth, 999,698 triangles ---------
+@pytest.fixture(scope="module")
+def cloth1m():
+    return scenes.folded_cloth(708)
+
+
+def test_full_size_pair_sets_match_golden_hashes(sccd, ctx, cloth1m):
+    """1.49 M VF + 5.06 M EE pairs: identical to the CPU restatement (count + SHA-256 of the
+    sorted list), plus size-independent properties: no duplicates, valid ids, no shared vertex."""
+    G = json.load(open(GOLDEN))["folded_cloth_708"]
+    V0, V1, E, F = cloth1m
+    assert (len(V0), len(E), len(F)) == (G["nV"], G["nE"], G["nF"]) == (501264, 1500961, 999698)
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    vb, eb, fb = sccd.DeviceAABBs.from_mesh(mesh, 0.0)
+    assert hashlib.sha256(vb.download().tobytes()).hexdigest() == G["sha_vertex_boxes"]
+    bp = sccd.BroadPhase(ctx)
+    bp.build(vb, fb)
+    vf = _sorted(bp.detect_overlaps())
+    bp.build(eb)
+    ee = _sorted(bp.detect_overlaps())
+    assert len(vf) == G["n_vf"] and hashlib.sha256(vf.tobytes()).hexdigest() == G["sha_vf"]
+    assert len(ee) == G["n_ee"] and hashlib.sha256(ee.tobytes()).hexdigest() == G["sha_ee"]
+    # properties that hold for any input
+    assert np.all((vf[1:] != vf[:-1]).any(axis=1)) and np.all((ee[1:] != ee[:-1]).any(axis=1))  # no duplicate
+    assert vf[:, 0].max() < len(V0) and vf[:, 1].max() < len(F) and ee.max() < len(E) and np.all(ee[:, 0] < ee[:, 1])
+    assert not np.any(F[vf[:, 1]] == vf[:, [0]])  # the vertex is never a corner of its face
+    ea, eb_ = E[ee[:, 0]], E[ee[:, 1]]
+    assert not np.any((ea[:, [0]] == eb_) | (ea[:, [1]] == eb_))  # the two edges share no vertex
+
+
+@pytest.mark.parametrize("arith", [0, 1])
+def test_full_size_ccd_matches_golden_toi(sccd, ctx, cloth1m, arith):
+    G = json.load(open(GOLDEN))["folded_cloth_708"]
+    V0, V1, E, F = cloth1m
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    ctx.set_option(sccd.OPT_ARITH, arith)
+    try:
+        toi, st = sccd.ccd_mesh(mesh, want_stats=True)
+        # idempotence: a second call on the same resident mesh returns the same bits
+        toi2 = sccd.ccd_mesh(mesh)
+    finally:
+        ctx.set_option(sccd.OPT_ARITH, 0)
+    assert toi == toi2 == float.fromhex(G["toi_fma" if arith else "toi_strict"])
+    assert st["n_vf_pairs"] == G["n_vf"] and st["n_ee_pairs"] == G["n_ee"]
+    # the level-synchronous kernel (reference scheme) agrees on the VF pass at full size
+    ctx.set_option(sccd.OPT_NARROW_ALGO, 1)
+    ctx.set_option(sccd.OPT_ARITH, arith)
+    try:
+        sccd.ccd_mesh_prepare(mesh, 0.0)
+        t_vf, _ = sccd.ccd_mesh_pass(mesh, True, 1.0)
+    finally:
+        ctx.set_option(sccd.OPT_NARROW_ALGO, 0)
+        ctx.set_option(sccd.OPT_ARITH, 0)
+    assert t_vf == float.fromhex(G["toi_vf_fma" if arith else "toi_vf_strict"])
+
+
+def test_full_size_sharded_passes_reduce_to_the_same_toi(sccd, ctx, cloth1m):
+    """4 ranks emulated on one GPU: the shards partition the queries and the min over the ranks'
+    TOIs, threaded VF -> EE like dist.ccd_sharded does, is the single-GPU TOI."""
+    G = json.load(open(GOLDEN))["folded_cloth_708"]
+    V0, V1, E, F = cloth1m
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    world = 4
+    try:
+        sccd.ccd_mesh_prepare(mesh, 0.0)
+        toi, n_pairs = 1.0, 0
+        for is_vf in (True, False):
+            parts = []
+            for r in range(world):
+                ctx.set_option(sccd.OPT_SHARD_COUNT, world)
+                ctx.set_option(sccd.OPT_SHARD_RANK, r)
+                t, st = sccd.ccd_mesh_pass(mesh, is_vf, toi)
+                parts.append(t)
+                n_pairs += st["n_vf_pairs"] + st["n_ee_pairs"]
+                assert st["n_vf_pairs"] + st["n_ee_pairs"] > 0.15 * (G["n_vf"] if is_vf else G["n_ee"])  # balanced
+            toi = min(parts)  # the all-reduce(min)
+    finally:
+        ctx.set_option(sccd.OPT_SHARD_COUNT, 1)
+        ctx.set_option(sccd.OPT_SHARD_RANK, 0)
+    assert n_pairs == G["n_vf"] + G["n_ee"]
+    assert toi == float.fromhex(G["toi_strict"])

@@ -195,8 +195,10 @@ def test_per_query_toi_min_is_global(orc):
 def test_golden_vectors(orc):
     with open(os.path.join(GOLDEN, "golden.json")) as f:
         G = json.load(f)
-    from golden.make_golden import compute_case
+    from golden.make_golden import SLOW_CASES, compute_case
 
     for name, want in G.items():
+        if name in SLOW_CASES:
+            continue
         got = compute_case(orc, name)
         assert got == want, name
