@@ -129,22 +129,40 @@ def main():
         queries_per_step = float(qq[0].item()) / args.steps
         value = float(qq[0].item()) / dt
 
-        # roofline of the dominant kernel class of this rank (device time from hipEvents on the ctx stream)
-        units = {
-            "narrow": (BYTES_PER_QUERY * q_local, "Tight-Inclusion np_queue_k / np_level_k"),
-            "sweep": ((BYTES_SWEEP_PER_BOX * (len(V0) + len(F) + len(E)) + 8.0 * q_local / args.steps) * args.steps, "sweep_stq_k"),
-            "sort": (BYTES_SORT_PER_KEY_PASS * 4 * (len(V0) + len(F) + len(E)) * args.steps, "radix sort (4 passes)"),
-            "boxes": (124.0 * (len(V0) + len(F) + len(E)) * args.steps, "box build + key/gather"),
-            "ranges": (28.0 * (len(V0) + len(F) + len(E)) * args.steps, "candidate ranges"),
+        # roofline of the dominant kernel class of this rank: algorithmic bytes / device time
+        # measured live with hipEvents on the context's stream (SCCD_OPT_PROFILE)
+        n_boxes = len(V0) + len(F) + len(E)
+        q_vf, q_ee = stats["n_vf_pairs"], stats["n_ee_pairs"]  # this rank's queries per step
+        units = {  # class -> (algorithmic bytes per step, kernel name, name in the rocprofv3 summaries)
+            "narrow_ee": (BYTES_PER_QUERY * q_ee, "np_queue_k<false> (edge-edge Tight-Inclusion)", "np_queue_k<false, %d>" % args.arith),
+            "narrow_vf": (BYTES_PER_QUERY * q_vf, "np_queue_k<true> (vertex-face Tight-Inclusion)", "np_queue_k<true, %d>" % args.arith),
+            "sweep": (BYTES_SWEEP_PER_BOX * n_boxes + 8.0 * (q_vf + q_ee), "sweep_stq_k (3 launches per step)", "sweep_stq_k"),
+            "sort": (BYTES_SORT_PER_KEY_PASS * 4 * n_boxes, "onesweep radix sort + scans", "os_pass_k"),
+            "boxes": (124.0 * n_boxes, "box build, cell count/fill, gather", "entry_gather_k"),
+            "ranges": (28.0 * n_boxes, "ranges_k", "ranges_k"),
         }
         dom = max(prof, key=lambda k: prof[k][0])
         ms_dom, launches = prof[dom]
-        achieved = units[dom][0] / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
+        per_launch_ms = ms_dom / max(1, launches)
+        launches_per_step = max(1, launches) / args.steps
+        achieved = units[dom][0] / launches_per_step / (per_launch_ms * 1e-3) / 1e9 if ms_dom > 0 else 0.0
+        traffic = None  # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.sh), same workload only
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_cloth1m.json")))
+            if args.workload == "cloth1m" and args.cloth_n == 708 and world == 1:
+                traffic = tj["kernels"][units[dom][2]]["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            traffic = None
+        checks = float(stats["n_vf_checks"] + stats["n_ee_checks"])
         roofline = {
             "bound": "hbm", "kernel": units[dom][1], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-            "avg_launch_ms": round(ms_dom / max(1, launches), 4), "launches": launches,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "avg_launch_ms": round(per_launch_ms, 4), "launches": launches,
             "class_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items()},
+            "note": "the narrow phase is FP64-VALU/latency bound, not HBM bound (DESIGN.md 5.5): "
+                    "%.3g inclusion checks/s = %.1f%% of the FP64 vector peak at 520 FLOP per check"
+                    % (checks / max(1e-9, (prof["narrow_vf"][0] + prof["narrow_ee"][0]) / args.steps * 1e-3),
+                       100.0 * checks * 520.0 / max(1e-9, (prof["narrow_vf"][0] + prof["narrow_ee"][0]) / args.steps * 1e-3) / 78.6e12),
         }
         result = {
             "metric": "CCD queries/sec (broad+narrow)", "value": value, "unit": "queries/s", "n_gpus": world,

@@ -76,6 +76,7 @@ int sccd_synchronize(sccd_ctx* ctx);
 #define SCCD_OPT_OVERLAP_CAPACITY 7 /* initial overlap buffer capacity in pairs (0 = automatic)                           */
 #define SCCD_OPT_PROFILE 8          /* 1: record hipEvents around every kernel class (sccd_get_profile)                   */
 #define SCCD_OPT_MAX_OVERLAP_CUTOFF 9 /* boxes swept per detect_overlaps_partial call (0 = all; memory_handler.hpp:9)      */
+#define SCCD_OPT_MEMORY_LIMIT_MB 10 /* memory budget of the overlap list in MiB (0 = none; MemoryHandler::memory_limit_GB)  */
 int sccd_set_option(sccd_ctx* ctx, int option, int64_t value);
 int64_t sccd_get_option(const sccd_ctx* ctx, int option);
 
@@ -186,8 +187,9 @@ int sccd_ipc_ccd_strategy(sccd_ctx* ctx, const double* V0, const double* V1, int
 #define SCCD_PROF_SORT 1
 #define SCCD_PROF_RANGES 2
 #define SCCD_PROF_SWEEP 3
-#define SCCD_PROF_NARROW 4
-#define SCCD_PROF_COUNT 5
+#define SCCD_PROF_NARROW_VF 4 /* np_queue_k<true> / np_level_k<true> launches  */
+#define SCCD_PROF_NARROW_EE 5 /* np_queue_k<false> / np_level_k<false> launches */
+#define SCCD_PROF_COUNT 6
 /* accumulated device milliseconds and launch counts per kernel class since the last reset */
 int sccd_get_profile(sccd_ctx* ctx, double ms[SCCD_PROF_COUNT], int64_t launches[SCCD_PROF_COUNT]);
 int sccd_reset_profile(sccd_ctx* ctx);

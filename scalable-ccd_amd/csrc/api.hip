@@ -156,6 +156,7 @@ int sccd_set_option(sccd_ctx* c, int opt, int64_t v)
     case SCCD_OPT_OVERLAP_CAPACITY: c->overlap_capacity = v; break;
     case SCCD_OPT_PROFILE: c->profile = v ? 1 : 0; break;
     case SCCD_OPT_MAX_OVERLAP_CUTOFF: c->max_overlap_cutoff = v; break;
+    case SCCD_OPT_MEMORY_LIMIT_MB: c->memory_limit_mb = v; break;
     default: c->err = "unknown option"; return SCCD_E_INVALID;
     }
     return SCCD_OK;
@@ -174,6 +175,7 @@ int64_t sccd_get_option(const sccd_ctx* c, int opt)
     case SCCD_OPT_OVERLAP_CAPACITY: return c->overlap_capacity;
     case SCCD_OPT_PROFILE: return c->profile;
     case SCCD_OPT_MAX_OVERLAP_CUTOFF: return c->max_overlap_cutoff;
+    case SCCD_OPT_MEMORY_LIMIT_MB: return c->memory_limit_mb;
     default: return 0;
     }
 }
@@ -609,7 +611,8 @@ static void bp_detect_partial(sccd_broad_phase* bp)
     const SortedList* B = bp->B ? &bp->lb : nullptr;
     const GridParams* gp = reinterpret_cast<const GridParams*>(bp->grid.as<char>() + 512);
     const int64_t cutoff = c->max_overlap_cutoff > 0 ? c->max_overlap_cutoff : bp->total_rows;
-    const int64_t chunk_lo = bp->cursor, chunk_hi = std::min(bp->cursor + cutoff, bp->total_rows);
+    const int64_t chunk_lo = bp->cursor;
+    int64_t chunk_hi = std::min(bp->cursor + cutoff, bp->total_rows);
 
     SweepCounters* d_cnt = c->scalars.as<SweepCounters>();
     unsigned long long* d_cand = d_cnt->cand_parts;
@@ -631,22 +634,41 @@ static void bp_detect_partial(sccd_broad_phase* bp)
     // SCCD_OPT_SWEEP_ALGO: 0/2 filter-queue-confirm STQ (default: measured faster on every workload
     // once its tiles are dealt without tickets), 1 plain SAP cross-check, 3 direct exact sweep.
     const bool direct = c->sweep_algo == 3;
-    // rows of this chunk per sweep class
-    int a_lo = (int)std::min<int64_t>(chunk_lo, A->m), a_hi = (int)std::min<int64_t>(chunk_hi, A->m);
-    int b_lo = 0, b_hi = 0;
-    if (B) {
-        b_lo = (int)std::max<int64_t>(0, chunk_lo - A->m);
-        b_hi = (int)std::max<int64_t>(0, chunk_hi - A->m);
-    }
-    shard_rows(c, bp->ranges_a.as<uint2>(), a_lo, a_hi, &a_lo, &a_hi);
-    if (B) shard_rows(c, bp->ranges_b.as<uint2>(), b_lo, b_hi, &b_lo, &b_hi);
-
+    // Capacity sizing (MemoryHandler, memory_handler.cpp:11-79): the overlap list may use half of
+    // the memory limit (SCCD_OPT_MEMORY_LIMIT_MB / ccd()'s memory_limit_GB; default: whatever
+    // hipMalloc grants).  A chunk whose pairs do not fit is re-swept over HALF its rows
+    // (MAX_OVERLAP_CUTOFF >>= 1, memory_handler.cpp:64-72) and the cursor advances by what was done.
+    const int64_t limit_pairs = c->memory_limit_mb > 0
+        ? std::max<int64_t>(1024, (c->memory_limit_mb << 20) / 2 / (int64_t)sizeof(int2))
+        : (int64_t)1 << 40;
     if (bp->capacity == 0) {
         int64_t cap = c->overlap_capacity > 0 ? c->overlap_capacity : std::max<int64_t>(1 << 20, 32 * bp->total_rows);
-        bp->overlaps.ensure(sizeof(int2) * (size_t)cap);
+        cap = std::min(cap, limit_pairs);
+        for (;;) {
+            try {
+                bp->overlaps.ensure(sizeof(int2) * (size_t)cap);
+                break;
+            } catch (const SccdError& e) {
+                if (e.code != SCCD_E_NOMEM || cap <= (1 << 16)) throw;
+                (void)hipGetLastError();
+                cap /= 2;
+            }
+        }
         bp->capacity = cap;
     }
+    int64_t chunk_rows = chunk_hi - chunk_lo;
     for (int attempt = 0;; attempt++) { // overflow -> exact-size rerun (broad_phase.cu:142-203)
+        chunk_hi = chunk_lo + chunk_rows;
+        // rows of this chunk per sweep class
+        int a_lo = (int)std::min<int64_t>(chunk_lo, A->m), a_hi = (int)std::min<int64_t>(chunk_hi, A->m);
+        int b_lo = 0, b_hi = 0;
+        if (B) {
+            b_lo = (int)std::max<int64_t>(0, chunk_lo - A->m);
+            b_hi = (int)std::max<int64_t>(0, chunk_hi - A->m);
+        }
+        shard_rows(c, bp->ranges_a.as<uint2>(), a_lo, a_hi, &a_lo, &a_hi);
+        if (B) shard_rows(c, bp->ranges_b.as<uint2>(), b_lo, b_hi, &b_lo, &b_hi);
+
         SCCD_HIP(hipMemsetAsync(&d_cnt->n_pairs, 0, sizeof(unsigned long long), c->stream));
         {
             ProfScope ps(c, SCCD_PROF_SWEEP);
@@ -672,10 +694,26 @@ static void bp_detect_partial(sccd_broad_phase* bp)
             bp->n_overlaps = (int64_t)h.n_pairs;
             break;
         }
-        SCCD_REQUIRE(attempt < 3, "broad phase: overlap buffer keeps overflowing");
-        const int64_t cap = (int64_t)h.n_pairs + (int64_t)h.n_pairs / 16 + 1024;
-        bp->overlaps.ensure(sizeof(int2) * (size_t)cap);
-        bp->capacity = cap;
+        SCCD_REQUIRE(attempt < 64, "broad phase: overlap buffer keeps overflowing");
+        const int64_t want = (int64_t)h.n_pairs + (int64_t)h.n_pairs / 16 + 1024;
+        bool grown = false;
+        if (want <= limit_pairs) {
+            try {
+                bp->overlaps.ensure(sizeof(int2) * (size_t)want);
+                bp->capacity = want;
+                grown = true;
+            } catch (const SccdError& e) {
+                if (e.code != SCCD_E_NOMEM) throw;
+                (void)hipGetLastError();
+                // the old buffer was released by ensure(): get the previous size back
+                bp->overlaps.ensure(sizeof(int2) * (size_t)bp->capacity);
+            }
+        }
+        if (!grown) {
+            if (chunk_rows <= 1)
+                throw SccdError { SCCD_E_NOMEM, "Insufficient memory to increase overlap size; cannot allocate even a single box's overlaps." };
+            chunk_rows = (chunk_rows + 1) / 2;
+        }
     }
     bp->cursor = chunk_hi; // thread_start_box_id += MAX_OVERLAP_CUTOFF (broad_phase.cu:207)
 }
@@ -863,7 +901,8 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
         st->ms_sort = c->prof_ms[SCCD_PROF_SORT] - before[SCCD_PROF_SORT];
         st->ms_sweep = (c->prof_ms[SCCD_PROF_SWEEP] - before[SCCD_PROF_SWEEP])
             + (c->prof_ms[SCCD_PROF_RANGES] - before[SCCD_PROF_RANGES]);
-        st->ms_narrow = c->prof_ms[SCCD_PROF_NARROW] - before[SCCD_PROF_NARROW];
+        st->ms_narrow = (c->prof_ms[SCCD_PROF_NARROW_VF] - before[SCCD_PROF_NARROW_VF])
+            + (c->prof_ms[SCCD_PROF_NARROW_EE] - before[SCCD_PROF_NARROW_EE]);
     }
 }
 
@@ -913,8 +952,14 @@ extern "C" int sccd_ccd(sccd_ctx* c, const double* V0, const double* V1, int nV,
                         const int32_t* F, int nF, double ms, int max_iter, double tol, int allow_zero_toi,
                         int memory_limit_GB, double* toi)
 {
-    (void)memory_limit_GB; // sizing is exact-with-retry here; the knob is accepted for API parity
     if (!c || !toi) return SCCD_E_INVALID;
+    const int64_t saved_limit = c->memory_limit_mb; // memory_limit_GB applies to this call (ccd.cu:40-43)
+    if (memory_limit_GB > 0) c->memory_limit_mb = (int64_t)memory_limit_GB << 10;
+    struct Restore {
+        sccd_ctx* c;
+        int64_t v;
+        ~Restore() { c->memory_limit_mb = v; }
+    } restore { c, saved_limit };
     sccd_mesh* m = nullptr;
     int rc = guarded(c, [&] { check_mesh_host(V0, V1, nV, E, nE, F, nF); });
     if (rc != SCCD_OK) return rc;

@@ -100,6 +100,7 @@ struct sccd_ctx {
     int64_t overlap_capacity = 0;
     int profile = 0;
     int64_t max_overlap_cutoff = 0;
+    int64_t memory_limit_mb = 0;
 
     // profiling: accumulated per kernel class
     double prof_ms[SCCD_PROF_COUNT] = { 0 };

@@ -203,7 +203,7 @@ void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
         n = (long long)hn;
     }
     if (run && n > 0) {
-        ProfScope ps(c, SCCD_PROF_NARROW);
+        ProfScope ps(c, p.is_vf ? SCCD_PROF_NARROW_VF : SCCD_PROF_NARROW_EE);
         const bool level_sync = c->narrow_algo == 1 || d_per_query_toi != nullptr || p.max_iter >= 0;
         if (level_sync) {
             if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi);
@@ -240,7 +240,6 @@ void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
         if (h.overflow) throw SccdError { SCCD_E_OVERFLOW, "narrow phase: work queue capacity exhausted" };
     }
     std::memcpy(h_toi_inout, &h.toi_bits, 8);
-    c->prof_launches[SCCD_PROF_NARROW] += 0;
     // n_checks is read by the caller through d_cnt mirror
     c->h_scalars.ensure(sizeof(NarrowCounters));
     std::memcpy(c->h_scalars.p, &h, sizeof h);

@@ -34,7 +34,8 @@ assert AABB_DTYPE.itemsize == 64 and COLLISION_DTYPE.itemsize == 16
 # sccd.h option ids
 OPT_ARITH, OPT_NARROW_ALGO, OPT_SWEEP_ALGO, OPT_SORT_AXIS = 1, 2, 3, 4
 OPT_SHARD_RANK, OPT_SHARD_COUNT, OPT_OVERLAP_CAPACITY, OPT_PROFILE, OPT_MAX_OVERLAP_CUTOFF = 5, 6, 7, 8, 9
-PROF_NAMES = ["boxes", "sort", "ranges", "sweep", "narrow"]
+OPT_MEMORY_LIMIT_MB = 10
+PROF_NAMES = ["boxes", "sort", "ranges", "sweep", "narrow_vf", "narrow_ee"]
 
 # every symbol include/sccd.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [

@@ -181,6 +181,32 @@ def test_partial_cursor_covers_everything_once(sccd, ctx, orc):
     assert np.array_equal(_sorted(got), want)
 
 
+def test_memory_limit_halves_the_swept_range(sccd, ctx, orc):
+    """MemoryHandler behaviour (memory_handler.cpp:55-79): when the pairs of a chunk do not fit the
+    budget, the swept box range is halved and the cursor advances by what was done."""
+    V0, V1, E, F = _scene("soup_dense")
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F)
+    want, _, _ = orc.sort_and_sweep(eb, nthreads=8)
+    assert len(want) > 100_000
+    ctx.set_option(sccd.OPT_MEMORY_LIMIT_MB, 1)  # room for 65,536 pairs: several chunks are needed
+    try:
+        bp = sccd.BroadPhase(ctx)
+        bp.build(sccd.DeviceAABBs(eb, ctx))
+        chunks, parts = 0, []
+        while not bp.is_complete():
+            ptr, n = bp.detect_overlaps_partial()
+            assert n <= 65536
+            chunks += 1
+        assert chunks >= 2
+        bp.build(sccd.DeviceAABBs(eb, ctx))
+        got = bp.detect_overlaps()
+        toi = sccd.ccd(V0, V1, E, F, 0.0, -1, 1e-6, True, ctx=ctx)  # the driver loops over the chunks too (ccd.cu:55)
+    finally:
+        ctx.set_option(sccd.OPT_MEMORY_LIMIT_MB, 0)
+    assert np.array_equal(_sorted(got), want)
+    assert toi == sccd.ccd(V0, V1, E, F, 0.0, -1, 1e-6, True, ctx=ctx)
+
+
 def test_sharded_sweeps_partition_the_pair_set(sccd, ctx, orc):
     V0, V1, E, F = _scene("cloth_ball_small")
     vb, eb, fb = orc.build_boxes(V0, V1, E, F)
