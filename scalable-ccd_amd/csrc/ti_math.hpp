@@ -38,8 +38,11 @@ __device__ __forceinline__ void ti_prepare_inv_tol(TIQuery& q)
     q.inv_ok = ok;
 }
 
-__device__ __forceinline__ double ti_min(double a, double b) { return (b < a) ? b : a; }
-__device__ __forceinline__ double ti_max(double a, double b) { return (a < b) ? b : a; }
+// Eigen's Array::min/max (root_finder.cu:178-179) select with a compare; v_min_f64 / v_max_f64
+// return the same VALUE for non-NaN operands in one instruction instead of three (a different
+// sign of zero is the only possible difference, and nothing downstream distinguishes +-0).
+__device__ __forceinline__ double ti_min(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double ti_max(double a, double b) { return __builtin_fmax(a, b); }
 
 // add_data<is_vf> (narrow_phase.cu:24-74) on the packed mesh, in two steps so that the narrow-phase
 // kernel can software-pipeline them: the four vertex ids of a query ...
