@@ -56,8 +56,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("SCCD_FORCE_DIST") == "1"  # the latter: exercise RCCL with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -76,7 +78,7 @@ def main():
     def barrier():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     result = None
@@ -122,7 +124,7 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         qq = torch.tensor([float(q_local), float(stats["n_vf_checks"] + stats["n_ee_checks"]),
                            float(stats["n_vf_candidates"] + stats["n_ee_candidates"])], dtype=torch.float64, device=dev)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dist.all_reduce(qq, op=dist.ReduceOp.SUM)
         dt = float(tt.item())
@@ -183,7 +185,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

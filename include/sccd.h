@@ -72,7 +72,7 @@ int sccd_synchronize(sccd_ctx* ctx);
 #define SCCD_OPT_SWEEP_ALGO 3       /* 0 = 2 filter/queue/confirm STQ (default); 1 plain sweep-and-prune (sweep.cu:48-99); 3 direct exact sweep */
 #define SCCD_OPT_SORT_AXIS 4        /* 0/1/2 = x/y/z (reference device path: x, aabb.cu:85-86); -1 = arg-max variance   */
 #define SCCD_OPT_SHARD_RANK 5       /* multi-GPU: this rank's index ...                                                  */
-#define SCCD_OPT_SHARD_COUNT 6      /* ... of this many ranks; the sweep emits only this rank's share of the candidates   */
+#define SCCD_OPT_SHARD_COUNT 6      /* ... of this many ranks; a rank sorts and sweeps only its window of grid cells      */
 #define SCCD_OPT_OVERLAP_CAPACITY 7 /* initial overlap buffer capacity in pairs (0 = automatic)                           */
 #define SCCD_OPT_PROFILE 8          /* 1: record hipEvents around every kernel class (sccd_get_profile)                   */
 #define SCCD_OPT_MAX_OVERLAP_CUTOFF 9 /* boxes swept per detect_overlaps_partial call (0 = all; memory_handler.hpp:9)      */
@@ -193,6 +193,11 @@ int sccd_ipc_ccd_strategy(sccd_ctx* ctx, const double* V0, const double* V1, int
 /* accumulated device milliseconds and launch counts per kernel class since the last reset */
 int sccd_get_profile(sccd_ctx* ctx, double ms[SCCD_PROF_COUNT], int64_t launches[SCCD_PROF_COUNT]);
 int sccd_reset_profile(sccd_ctx* ctx);
+
+/* Host-side split behind SCCD_OPT_SHARD_*: cuts n weighted items (grid cells weighted by their
+ * entry counts) into `parts` contiguous windows of nearly equal weight.  bounds has parts+1
+ * entries, bounds[0] = 0, bounds[parts] = n; window r is [bounds[r], bounds[r+1]).  Needs no GPU. */
+int sccd_shard_bounds(const uint32_t* weights, int n, int parts, int* bounds);
 
 /* standalone kernels exposed for roofline measurements (bench.py --workload sort) */
 int sccd_sort_pairs_u32(sccd_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, int64_t n);

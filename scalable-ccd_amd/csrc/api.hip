@@ -457,19 +457,45 @@ static double cell_factor()
     return f > 0 ? f : 1e300; // <= 0 switches the grid off (one cell)
 }
 
+// An item goes to the window its midpoint (in running weight) falls into: boundaries are
+// monotone, cover [0, n) and no window is more than one item's weight away from total / parts.
+static void shard_bounds(const uint32_t* w, int n, int parts, int* bounds)
+{
+    unsigned long long total = 0;
+    for (int k = 0; k < n; k++) total += w[k];
+    bounds[0] = 0;
+    unsigned long long run = 0;
+    int k = 0;
+    for (int r = 1; r < parts; r++) {
+        const unsigned long long target = total * (unsigned long long)r / (unsigned long long)parts;
+        while (k < n && run + w[k] / 2 < target) run += w[k++];
+        bounds[r] = k;
+    }
+    bounds[parts] = n;
+}
+
+extern "C" int sccd_shard_bounds(const uint32_t* weights, int n, int parts, int* bounds)
+{
+    if (n < 0 || parts < 1 || !bounds || (n > 0 && !weights)) return SCCD_E_INVALID;
+    shard_bounds(weights, n, parts, bounds);
+    return SCCD_OK;
+}
+
 // count -> scan -> fill -> sort -> gather for one list.  Returns false when the replication
 // into cells exceeded the budget (the caller then coarsens the grid).
-static bool build_sorted_list(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, bool can_shrink, SortedList* L)
+static bool build_sorted_list(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, int cell_lo, int cell_hi,
+                              bool can_shrink, SortedList* L)
 {
     const int n = b->n;
     L->m = 0;
     if (n == 0) return true;
+    const bool windowed = cell_lo > 0 || cell_hi < (1 << 30);
     uint32_t* d_total = reinterpret_cast<uint32_t*>(c->scalars.as<char>() + 1536);
     c->tmp0.ensure(sizeof(uint32_t) * ((size_t)n + 64));
     uint32_t* counts = c->tmp0.as<uint32_t>();
     {
         ProfScope ps(c, SCCD_PROF_BOXES);
-        launch_cell_count(c, b->raw.as<sccd_aabb>(), n, gp, counts);
+        launch_cell_count(c, b->raw.as<sccd_aabb>(), n, gp, cell_lo, cell_hi, counts);
     }
     uint32_t total = 0;
     GridParams hgp;
@@ -480,7 +506,8 @@ static bool build_sorted_list(sccd_ctx* c, const sccd_boxes* b, const GridParams
         SCCD_HIP(hipMemcpyAsync(&hgp, gp, sizeof hgp, hipMemcpyDeviceToHost, c->stream));
         SCCD_HIP(hipStreamSynchronize(c->stream));
     }
-    if (can_shrink && (int64_t)total > std::max<int64_t>(3 * (int64_t)n, (int64_t)n + 4096)) return false;
+    if (can_shrink && !windowed && (int64_t)total > std::max<int64_t>(3 * (int64_t)n, (int64_t)n + 4096)) return false;
+    if (total == 0) return true; // no box of this list touches the rank's cells
     SCCD_REQUIRE(total < (1u << 31), "broad phase: too many cell entries");
     const size_t m = total, pad = 64; // the sweep streams whole 32-column blocks
     L->m = (int)m;
@@ -492,7 +519,8 @@ static bool build_sorted_list(sccd_ctx* c, const sccd_boxes* b, const GridParams
     L->lowcell.ensure(sizeof(uint32_t) * (m + pad));
     {
         ProfScope ps(c, SCCD_PROF_BOXES);
-        launch_cell_fill(c, b->raw.as<sccd_aabb>(), n, gp, counts, L->key.as<uint32_t>(), L->idx.as<uint32_t>());
+        launch_cell_fill(c, b->raw.as<sccd_aabb>(), n, gp, cell_lo, cell_hi, counts, L->key.as<uint32_t>(),
+                         L->idx.as<uint32_t>());
     }
     {
         ProfScope ps(c, SCCD_PROF_SORT);
@@ -533,7 +561,7 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     // two lists with an empty side produce nothing (sort_and_sweep.cpp:221-223)
     if (A->n == 0 || (B && B->n == 0)) return;
 
-    bp->grid.ensure(1024);
+    bp->grid.ensure(8192);
     GridStats* st = bp->grid.as<GridStats>();
     GridParams* gp = reinterpret_cast<GridParams*>(bp->grid.as<char>() + 512);
     int axis = c->sort_axis;
@@ -547,13 +575,46 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     }
     const int n_total = A->n + (B ? B->n : 0);
     const double cf = cell_factor();
+    bp->cell_lo = 0;
+    bp->cell_hi = 1 << 30;
+    bp->row_shard = false;
     for (int shrink = 0;; shrink++) {
         launch_grid_setup(c, st, n_total, axis, cf, shrink, gp);
         const bool can_shrink = shrink < 10;
-        if (!build_sorted_list(c, A, gp, can_shrink, &bp->la)) continue;
-        if (B && !build_sorted_list(c, B, gp, can_shrink, &bp->lb)) continue;
+        // Multi-GPU: every rank takes a contiguous window of cells with an equal share of the
+        // entries, and builds / sorts / sweeps only that window.  A pair is reported from exactly
+        // one cell (owns_pair), hence by exactly one rank: no exchange of boxes or pairs.
+        if (c->shard_count > 1) {
+            uint32_t* d_hist = bp->grid.as<uint32_t>() + 1024; // bytes [4096, 8192) of the grid block
+            SCCD_HIP(hipMemsetAsync(d_hist, 0, 4096, c->stream));
+            launch_cell_hist(c, A->raw.as<sccd_aabb>(), A->n, gp, d_hist);
+            if (B) launch_cell_hist(c, B->raw.as<sccd_aabb>(), B->n, gp, d_hist);
+            uint32_t hist[1024];
+            GridParams hgp;
+            SCCD_HIP(hipMemcpyAsync(hist, d_hist, sizeof hist, hipMemcpyDeviceToHost, c->stream));
+            SCCD_HIP(hipMemcpyAsync(&hgp, gp, sizeof hgp, hipMemcpyDeviceToHost, c->stream));
+            SCCD_HIP(hipStreamSynchronize(c->stream));
+            unsigned long long total = 0;
+            for (int k = 0; k < hgp.n_cells; k++) total += hist[k];
+            // same replication budget as build_sorted_list, decided on the whole grid so that
+            // every rank coarsens alike
+            if (can_shrink && total > (unsigned long long)std::max<int64_t>(3 * (int64_t)n_total, (int64_t)n_total + 4096))
+                continue;
+            if (hgp.n_cells >= 4 * c->shard_count) {
+                std::vector<int> bounds(c->shard_count + 1);
+                shard_bounds(hist, hgp.n_cells, c->shard_count, bounds.data());
+                bp->cell_lo = bounds[c->shard_rank];
+                bp->cell_hi = bounds[c->shard_rank + 1];
+                bp->row_shard = false;
+            } else {
+                bp->row_shard = true; // (almost) one cell: every rank sorts everything and takes a slice of the rows
+            }
+        }
+        if (!build_sorted_list(c, A, gp, bp->cell_lo, bp->cell_hi, can_shrink, &bp->la)) continue;
+        if (B && !build_sorted_list(c, B, gp, bp->cell_lo, bp->cell_hi, can_shrink, &bp->lb)) continue;
         break;
     }
+    if (B && (bp->la.m == 0 || bp->lb.m == 0)) bp->la.m = bp->lb.m = 0; // nothing to pair in this window
     bp->total_rows = (int64_t)bp->la.m + (B ? bp->lb.m : 0);
 }
 
@@ -574,31 +635,15 @@ extern "C" int64_t sccd_broad_phase_num_boxes(const sccd_broad_phase* bp)
 }
 extern "C" int64_t sccd_broad_phase_candidates(const sccd_broad_phase* bp) { return bp ? bp->candidates : 0; }
 
-// candidate-balanced share of rows [lo, hi) for this rank: equal sums of (end - start)
-static void shard_rows(sccd_ctx* c, const uint2* d_ranges, int lo, int hi, int* out_lo, int* out_hi)
+// Fallback shard when the grid has too few cells to deal out: an equal slice of the rows.
+static void shard_rows(sccd_ctx* c, bool row_shard, int lo, int hi, int* out_lo, int* out_hi)
 {
     *out_lo = lo;
     *out_hi = hi;
-    if (c->shard_count <= 1 || hi <= lo) return;
-    const int n = hi - lo;
-    std::vector<uint2> h((size_t)n);
-    SCCD_HIP(hipMemcpyAsync(h.data(), d_ranges + lo, sizeof(uint2) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    SCCD_HIP(hipStreamSynchronize(c->stream));
-    // weight = candidates + 1 so that empty rows still spread
-    unsigned long long total = 0;
-    for (int i = 0; i < n; i++) total += (unsigned long long)(h[(size_t)i].y - h[(size_t)i].x) + 1ull;
-    const unsigned long long t0 = total * (unsigned long long)c->shard_rank / (unsigned long long)c->shard_count;
-    const unsigned long long t1 = total * (unsigned long long)(c->shard_rank + 1) / (unsigned long long)c->shard_count;
-    unsigned long long run = 0;
-    int a = n, b = n;
-    for (int i = 0; i < n; i++) {
-        if (a == n && run >= t0) a = i;
-        if (b == n && run >= t1) b = i;
-        run += (unsigned long long)(h[(size_t)i].y - h[(size_t)i].x) + 1ull;
-    }
-    if (c->shard_rank == c->shard_count - 1) b = n;
-    *out_lo = lo + a;
-    *out_hi = lo + b;
+    if (!row_shard || c->shard_count <= 1 || hi <= lo) return;
+    const long long n = hi - lo;
+    *out_lo = lo + (int)(n * c->shard_rank / c->shard_count);
+    *out_hi = lo + (int)(n * (c->shard_rank + 1) / c->shard_count);
 }
 
 static void bp_detect_partial(sccd_broad_phase* bp)
@@ -666,8 +711,8 @@ static void bp_detect_partial(sccd_broad_phase* bp)
             b_lo = (int)std::max<int64_t>(0, chunk_lo - A->m);
             b_hi = (int)std::max<int64_t>(0, chunk_hi - A->m);
         }
-        shard_rows(c, bp->ranges_a.as<uint2>(), a_lo, a_hi, &a_lo, &a_hi);
-        if (B) shard_rows(c, bp->ranges_b.as<uint2>(), b_lo, b_hi, &b_lo, &b_hi);
+        shard_rows(c, bp->row_shard, a_lo, a_hi, &a_lo, &a_hi);
+        if (B) shard_rows(c, bp->row_shard, b_lo, b_hi, &b_lo, &b_hi);
 
         SCCD_HIP(hipMemsetAsync(&d_cnt->n_pairs, 0, sizeof(unsigned long long), c->stream));
         {

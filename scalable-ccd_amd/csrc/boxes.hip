@@ -267,21 +267,31 @@ __device__ __forceinline__ CellSpan cell_span(const GridParams& g, const BoxLoad
     return s;
 }
 
-// number of cells each box overlaps (the interval starts the prefix scan turns into offsets)
+// number of cells of [cell_lo, cell_hi) each box overlaps (the interval starts the prefix scan
+// turns into offsets).  The cell window is this rank's shard (all cells on one GPU).
 __global__ void cell_count_k(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp,
-                             uint32_t* __restrict__ counts)
+                             int cell_lo, int cell_hi, uint32_t* __restrict__ counts)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const GridParams g = *gp;
     const CellSpan s = cell_span(g, load_box_geom(raw + i));
-    counts[i] = (uint32_t)((s.a1 - s.a0 + 1) * (s.b1 - s.b0 + 1));
+    uint32_t cnt = 0;
+    if (cell_lo <= 0 && cell_hi >= g.n_cells) {
+        cnt = (uint32_t)((s.a1 - s.a0 + 1) * (s.b1 - s.b0 + 1));
+    } else {
+        for (int ca = s.a0; ca <= s.a1; ca++) {
+            const int c0 = max(ca * g.Sb + s.b0, cell_lo), c1 = min(ca * g.Sb + s.b1, cell_hi - 1);
+            cnt += c1 >= c0 ? (uint32_t)(c1 - c0 + 1) : 0u;
+        }
+    }
+    counts[i] = cnt;
 }
 
-// split_boxes, key part (aabb.cu:40-72): one (key, box index) entry per overlapped cell
+// split_boxes, key part (aabb.cu:40-72): one (key, box index) entry per overlapped cell of the window
 __global__ void cell_fill_k(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp,
-                            const uint32_t* __restrict__ offsets, uint32_t* __restrict__ key,
-                            uint32_t* __restrict__ idx)
+                            int cell_lo, int cell_hi, const uint32_t* __restrict__ offsets,
+                            uint32_t* __restrict__ key, uint32_t* __restrict__ idx)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -292,10 +302,30 @@ __global__ void cell_fill_k(const sccd_aabb* __restrict__ raw, int n, const Grid
     uint32_t at = offsets[i];
     for (int ca = s.a0; ca <= s.a1; ca++)
         for (int cb = s.b0; cb <= s.b1; cb++) {
-            key[at] = (uint32_t)(((unsigned long long)(ca * g.Sb + cb) << g.xb) | q); // xb may be 32
+            const int cell = ca * g.Sb + cb;
+            if (cell < cell_lo || cell >= cell_hi) continue;
+            key[at] = (uint32_t)(((unsigned long long)cell << g.xb) | q); // xb may be 32
             idx[at] = (uint32_t)i;
             ++at;
         }
+}
+
+// entries per cell (multi-GPU: the ranks take contiguous cell windows of equal entry counts)
+__global__ void cell_hist_k(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp,
+                            uint32_t* __restrict__ hist /*[1024]*/)
+{
+    __shared__ uint32_t h[1024];
+    for (int k = threadIdx.x; k < 1024; k += blockDim.x) h[k] = 0;
+    __syncthreads();
+    const GridParams g = *gp;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const CellSpan s = cell_span(g, load_box_geom(raw + i));
+        for (int ca = s.a0; ca <= s.a1; ca++)
+            for (int cb = s.b0; cb <= s.b1; cb++) atomicAdd(&h[ca * g.Sb + cb], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 1024; k += blockDim.x)
+        if (h[k]) atomicAdd(&hist[k], h[k]);
 }
 
 // payload movement of thrust::sort_by_key (aabb.cu:107-109) as ONE gather after the index sort,
@@ -405,17 +435,26 @@ void launch_grid_setup(sccd_ctx* c, const GridStats* st, int n_total, int axis, 
     hipLaunchKernelGGL(grid_setup_k, dim3(1), dim3(64), 0, c->stream, st, n_total, axis, cell_factor, shrink, g);
     SCCD_HIP(hipGetLastError());
 }
-void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, uint32_t* counts)
+void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, uint32_t* hist)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(cell_count_k, dim3(grid_for(n)), dim3(TPB), 0, c->stream, raw, n, g, counts);
+    hipLaunchKernelGGL(cell_hist_k, dim3(std::min(grid_for(n), c->num_cus * 2)), dim3(TPB), 0, c->stream, raw, n, g,
+                       hist);
     SCCD_HIP(hipGetLastError());
 }
-void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, const uint32_t* offsets,
-                      uint32_t* key, uint32_t* idx)
+void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
+                       uint32_t* counts)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(cell_fill_k, dim3(grid_for(n)), dim3(TPB), 0, c->stream, raw, n, g, offsets, key, idx);
+    hipLaunchKernelGGL(cell_count_k, dim3(grid_for(n)), dim3(TPB), 0, c->stream, raw, n, g, cell_lo, cell_hi, counts);
+    SCCD_HIP(hipGetLastError());
+}
+void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
+                      const uint32_t* offsets, uint32_t* key, uint32_t* idx)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(cell_fill_k, dim3(grid_for(n)), dim3(TPB), 0, c->stream, raw, n, g, cell_lo, cell_hi, offsets,
+                       key, idx);
     SCCD_HIP(hipGetLastError());
 }
 void launch_entry_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,

@@ -52,6 +52,8 @@ struct sccd_broad_phase {
     int64_t capacity = 0;
     int64_t n_overlaps = 0;
     int64_t candidates = 0;
+    int cell_lo = 0, cell_hi = 1 << 30; // this rank's window of cells (multi-GPU shard)
+    bool row_shard = false;             // too few cells to shard by: split the rows instead
 };
 
 // ------------------------------------------------------------------------------------------
@@ -67,9 +69,11 @@ struct GridParams;
 void launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st);
 void launch_grid_setup(sccd_ctx* c, const GridStats* st, int n_total, int axis, double cell_factor, int shrink,
                        GridParams* g);
-void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, uint32_t* counts);
-void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, const uint32_t* offsets,
-                      uint32_t* key, uint32_t* idx);
+void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, uint32_t* hist);
+void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
+                       uint32_t* counts);
+void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
+                      const uint32_t* offsets, uint32_t* key, uint32_t* idx);
 void launch_entry_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,
                          const GridParams* g, sccd_aabb* sorted, float4* filt, uint32_t* kmax, uint32_t* lowcell);
 
@@ -124,7 +128,7 @@ struct NarrowCounters {
     unsigned long long refill_execs; // executions of the gather+constants block
     unsigned long long steals;       // sub-domains moved between lanes
     unsigned long long stamp[8];     // SCCD_NP_DIAG=2: shader cycles per loop section, summed over waves
-    unsigned long long stamp_ticket, stamp_comp;
+    unsigned long long max_wave_steps, waves_run; // longest wave (the kernel's critical path), waves that got work
     unsigned long long pops_reg, pops_mem; // pops served by the register top / by the HBM stack
 };
 // runs the narrow phase on the stream; *toi in/out lives in d_cnt->toi_bits

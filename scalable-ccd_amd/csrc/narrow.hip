@@ -215,17 +215,16 @@ void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
     SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
     SCCD_HIP(hipStreamSynchronize(c->stream));
     if (std::getenv("SCCD_NP_DIAG") && h.wave_steps)
-        std::fprintf(stderr, "[sccd np] n=%lld checks=%llu wave_steps=%llu lane_util=%.3f refill_execs=%llu steals=%llu pops reg/mem=%llu/%llu\n",
-                     n, h.n_checks, h.wave_steps, (double)h.lane_steps / (64.0 * (double)h.wave_steps), h.refill_execs,
-                     h.steals, h.pops_reg, h.pops_mem);
+        std::fprintf(stderr, "[sccd np] n=%lld checks=%llu wave_steps=%llu (waves %llu, mean %.1f, longest %llu) lane_util=%.3f refill_execs=%llu steals=%llu pops reg/mem=%llu/%llu\n",
+                     n, h.n_checks, h.wave_steps, h.waves_run, (double)h.wave_steps / (double)std::max<unsigned long long>(1, h.waves_run),
+                     h.max_wave_steps, (double)h.lane_steps / (64.0 * (double)h.wave_steps), h.refill_execs, h.steals,
+                     h.pops_reg, h.pops_mem);
     if (std::getenv("SCCD_NP_DIAG") && h.stamp[4])
-        std::fprintf(stderr, "[sccd np] cycles/wave-step: toi=%.0f pop=%.0f steal=%.0f refill=%.0f check=%.0f push=%.0f | per ingest: pairs=%.0f gather=%.0f comp+lds=%.0f ticket(total/ingest)=%.0f\n",
+        std::fprintf(stderr, "[sccd np] cycles/wave-step: toi=%.0f pop=%.0f steal=%.0f refill=%.0f check=%.0f push=%.0f | cycles/ingest: total=%.0f gather wait=%.0f\n",
                      (double)h.stamp[0] / h.wave_steps, (double)h.stamp[1] / h.wave_steps, (double)h.stamp[2] / h.wave_steps,
                      (double)h.stamp[3] / h.wave_steps, (double)h.stamp[4] / h.wave_steps, (double)h.stamp[5] / h.wave_steps,
                      (double)h.stamp[6] / (double)std::max<unsigned long long>(1, h.refill_execs),
-                     (double)h.stamp[7] / (double)std::max<unsigned long long>(1, h.refill_execs),
-                     (double)h.stamp_comp / (double)std::max<unsigned long long>(1, h.refill_execs),
-                     (double)h.stamp_ticket / (double)std::max<unsigned long long>(1, h.refill_execs));
+                     (double)h.stamp[7] / (double)std::max<unsigned long long>(1, h.refill_execs));
     if (h.overflow) {
         // the persistent kernel gave up (spill stack full, or an interval that cannot be held as
         // lo + 2^-d): redo the call with the level-synchronous scheme, which has neither limit

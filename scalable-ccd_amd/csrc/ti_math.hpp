@@ -25,6 +25,16 @@ struct TIQuery {
 //   fl(w_k / tol_k) == w_k * fl(1 / tol_k)      (no overflow/underflow)
 // so the three divisions per check become three multiplications by per-query constants, with
 // the same bits.  Guard: every reciprocal is 0, +inf or within [2^-500, 2^500].
+__device__ __forceinline__ bool ti_inv_tol_ok(const double inv_tol[3])
+{
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double a = fabs(inv_tol[k]);
+        ok = ok && (a == 0.0 || a == __builtin_huge_val() || (a >= 0x1p-500 && a <= 0x1p500));
+    }
+    return ok;
+}
 __device__ __forceinline__ void ti_prepare_inv_tol(TIQuery& q)
 {
     bool ok = true;
@@ -132,6 +142,67 @@ template <bool VF> __device__ __forceinline__ void ti_tolerance(const double v[8
         tol[1] = tol[0];
         tol[2] = co_domain_tol / (3 * ti_max_linf_4(p000, p100, p101, p001, p010, p110, p111, p011));
     }
+}
+
+// The same tolerances and error bounds ONE COORDINATE AT A TIME, for callers that cannot afford
+// all 24 coordinates plus the eight differences in registers at once (np_queue_k's ingest reads
+// the coordinates back from LDS).  x[j] = v[j][k]; m[0..2] accumulate the three max_Linf_4 values
+// over k (max is exact, so the order of the maxima does not change a bit), start them at 0.
+template <bool VF> __device__ __forceinline__ void ti_tolerance_dim(const double x[8], double m[3])
+{
+    double p000, p001, p011, p010, p100, p101, p111, p110;
+    if (VF) {
+        p000 = x[0] - x[1];
+        p001 = x[0] - x[3];
+        p011 = x[0] - (x[2] + x[3] - x[1]);
+        p010 = x[0] - x[2];
+        p100 = x[4] - x[5];
+        p101 = x[4] - x[7];
+        p111 = x[4] - (x[6] + x[7] - x[5]);
+        p110 = x[4] - x[6];
+    } else {
+        p000 = x[0] - x[2];
+        p001 = x[0] - x[3];
+        p010 = x[1] - x[2];
+        p011 = x[1] - x[3];
+        p100 = x[4] - x[6];
+        p101 = x[4] - x[7];
+        p110 = x[5] - x[6];
+        p111 = x[5] - x[7];
+    }
+    // pairings of ti_tolerance's three max_Linf_4 calls
+    const double ma = ti_max(ti_max(fabs(p100 - p000), fabs(p101 - p001)), ti_max(fabs(p111 - p011), fabs(p110 - p010)));
+    const double mb = ti_max(ti_max(fabs(p010 - p000), fabs(p110 - p100)), ti_max(fabs(p111 - p101), fabs(p011 - p001)));
+    m[0] = ti_max(m[0], ma);
+    if (VF) {
+        const double mc = ti_max(ti_max(fabs(p001 - p000), fabs(p101 - p100)), ti_max(fabs(p111 - p110), fabs(p011 - p010)));
+        m[1] = ti_max(m[1], mb);
+        m[2] = ti_max(m[2], mc);
+    } else {
+        m[2] = ti_max(m[2], mb);
+    }
+}
+template <bool VF> __device__ __forceinline__ void ti_tolerance_finish(const double m[3], double co_domain_tol, double tol[3])
+{
+    tol[0] = co_domain_tol / (3 * m[0]);
+    if (VF) {
+        tol[1] = co_domain_tol / (3 * m[1]);
+        tol[2] = co_domain_tol / (3 * m[2]);
+    } else {
+        tol[1] = tol[0];
+        tol[2] = co_domain_tol / (3 * m[2]);
+    }
+}
+template <bool VF> __device__ __forceinline__ double ti_error_dim(const double x[8], bool use_ms)
+{
+    double filter;
+    if (!use_ms) filter = VF ? 6.661338147750939e-15 : 6.217248937900877e-15;
+    else filter = VF ? 7.549516567451064e-15 : 7.105427357601002e-15;
+    double m = fabs(x[0]);
+#pragma unroll
+    for (int j = 1; j < 8; j++) m = ti_max(m, fabs(x[j]));
+    m = ti_max(m, 1.0);
+    return m * m * m * filter;
 }
 
 // get_numerical_error (root_finder.cu:90-135), double constants

@@ -47,6 +47,7 @@ ABI_SYMBOLS = [
     "sccd_broad_phase_detect_overlaps_partial", "sccd_broad_phase_detect_overlaps", "sccd_broad_phase_is_complete",
     "sccd_broad_phase_num_boxes", "sccd_broad_phase_candidates", "sccd_free", "sccd_narrow_phase", "sccd_ccd",
     "sccd_ccd_mesh", "sccd_ccd_mesh_prepare", "sccd_ccd_mesh_pass", "sccd_ipc_ccd_strategy", "sccd_get_profile", "sccd_reset_profile", "sccd_sort_pairs_u32",
+    "sccd_shard_bounds",
 ]
 
 
@@ -167,6 +168,17 @@ class Context:
 
 
 _default_ctx = None
+
+
+def shard_bounds(weights, parts):
+    """sccd_shard_bounds: the host-side split of weighted grid cells into `parts` contiguous
+    windows that SCCD_OPT_SHARD_RANK/COUNT applies (needs no GPU)."""
+    w = np.ascontiguousarray(weights, dtype=np.uint32)
+    out = (C.c_int * (max(int(parts), 0) + 1))()
+    rc = lib().sccd_shard_bounds(w.ctypes.data_as(C.c_void_p), C.c_int(len(w)), C.c_int(int(parts)), out)
+    if rc != 0:
+        raise ValueError(f"sccd_shard_bounds failed ({rc})")
+    return list(out)
 
 
 def default_context():

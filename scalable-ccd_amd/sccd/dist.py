@@ -1,28 +1,35 @@
-"""Multi-GPU CCD: one process per GPU, pairs shard naturally, one min-reduce of the TOI.
+"""Multi-GPU CCD: one process per GPU, grid cells shard naturally, one min-reduce of the TOI.
 
 The reference has no working multi-GPU path (its _multigpu prototype is not compiled,
-src/scalable_ccd/cuda/broad_phase/CMakeLists.txt:21).  Here every rank builds and sorts the
-(small) box lists redundantly, sweeps only its candidate-balanced share of the sorted rows,
-runs the narrow phase on the pairs it emitted, and the ranks exchange exactly one scalar per
-pass: an all-reduce(min) of the time of impact over RCCL/xGMI (or gloo on CPU in the tests).
+src/scalable_ccd/cuda/broad_phase/CMakeLists.txt:21).  Here every rank builds the (cheap) boxes
+and the cell grid redundantly, then takes a contiguous window of grid cells holding an equal
+share of the sort entries (csrc/api.hip bp_build / shard_bounds): it sorts, sweeps and narrows
+only that window.  A pair is reported from exactly one cell, hence by exactly one rank, and the
+ranks exchange exactly one scalar per pass: an all-reduce(min) of the time of impact over
+RCCL/xGMI (or gloo on CPU in the tests).
 """
 import numpy as np
 
 
 def balanced_bounds(weights, parts):
-    """Split rows with the given weights into `parts` contiguous shards of nearly equal total
-    weight.  Mirrors shard_rows() of csrc/api.hip (weight = candidates + 1 per row).
+    """Cut weighted items (grid cells weighted by their entry counts) into `parts` contiguous
+    windows of nearly equal weight: an item goes to the window its midpoint in running weight
+    falls into.  Line-for-line mirror of shard_bounds() in csrc/api.hip (C ABI:
+    sccd_shard_bounds); tests/test_sharding.py holds the two against each other.
     Returns parts+1 boundaries."""
-    w = np.asarray(weights, dtype=np.uint64) + np.uint64(1)
-    total = int(w.sum())
-    run = np.concatenate([[0], np.cumsum(w, dtype=np.uint64)[:-1]]).astype(np.uint64) if len(w) else np.zeros(0, np.uint64)
+    w = [int(x) for x in np.asarray(weights).ravel()]
+    n = len(w)
+    total = sum(w)
     bounds = [0]
+    run = 0
+    k = 0
     for r in range(1, parts):
         target = total * r // parts
-        # first row whose running prefix reaches the target
-        idx = int(np.searchsorted(run, np.uint64(target), side="left")) if len(w) else 0
-        bounds.append(min(idx, len(w)))
-    bounds.append(len(w))
+        while k < n and run + w[k] // 2 < target:
+            run += w[k]
+            k += 1
+        bounds.append(k)
+    bounds.append(n)
     return bounds
 
 

@@ -207,23 +207,53 @@ def test_memory_limit_halves_the_swept_range(sccd, ctx, orc):
     assert toi == sccd.ccd(V0, V1, E, F, 0.0, -1, 1e-6, True, ctx=ctx)
 
 
-def test_sharded_sweeps_partition_the_pair_set(sccd, ctx, orc):
-    V0, V1, E, F = _scene("cloth_ball_small")
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("two_lists", [False, True])
+def test_sharded_sweeps_partition_the_pair_set(sccd, ctx, orc, world, two_lists):
+    """Every rank sweeps its window of grid cells (or, on a grid too small to deal out, its slice
+    of the rows): the union over the ranks is the reference's pair set, with no pair twice."""
+    V0, V1, E, F = _scene("cloth_ball_10k")
     vb, eb, fb = orc.build_boxes(V0, V1, E, F)
-    want, _, _ = orc.sort_and_sweep(eb)
+    if two_lists:
+        want, _, _ = orc.sort_and_sweep(vb, fb, nthreads=8)
+    else:
+        want, _, _ = orc.sort_and_sweep(eb, nthreads=8)
     parts = []
     try:
-        for r in range(3):
-            ctx.set_option(sccd.OPT_SHARD_COUNT, 3)
+        for r in range(world):
+            ctx.set_option(sccd.OPT_SHARD_COUNT, world)
             ctx.set_option(sccd.OPT_SHARD_RANK, r)
             bp = sccd.BroadPhase(ctx)
-            bp.build(sccd.DeviceAABBs(eb, ctx))
-            parts.append(bp.detect_overlaps())
+            if two_lists:
+                bp.build(sccd.DeviceAABBs(vb, ctx), sccd.DeviceAABBs(fb, ctx))
+            else:
+                bp.build(sccd.DeviceAABBs(eb, ctx))
+            parts.append(bp.detect_overlaps().reshape(-1, 2))
+    finally:
+        ctx.set_option(sccd.OPT_SHARD_COUNT, 1)
+        ctx.set_option(sccd.OPT_SHARD_RANK, 0)
+    assert sum(len(p) > 0 for p in parts) >= 2
+    assert np.array_equal(_sorted(np.concatenate(parts)), want)  # disjoint and complete
+
+
+def test_sharded_sweep_on_a_single_cell_grid_splits_rows(sccd, ctx, orc, monkeypatch):
+    """SCCD_CELL_FACTOR<=0 switches the grid off: the shards fall back to slices of the rows."""
+    monkeypatch.setenv("SCCD_CELL_FACTOR", "0")
+    b = scenes.random_boxes(20_000, seed=5, max_extent=0.05)
+    want, _, _ = orc.sort_and_sweep(b, nthreads=8)
+    parts = []
+    try:
+        for r in range(4):
+            ctx.set_option(sccd.OPT_SHARD_COUNT, 4)
+            ctx.set_option(sccd.OPT_SHARD_RANK, r)
+            bp = sccd.BroadPhase(ctx)
+            bp.build(sccd.DeviceAABBs(b, ctx))
+            parts.append(bp.detect_overlaps().reshape(-1, 2))
     finally:
         ctx.set_option(sccd.OPT_SHARD_COUNT, 1)
         ctx.set_option(sccd.OPT_SHARD_RANK, 0)
     assert all(len(p) > 0 for p in parts)
-    assert np.array_equal(_sorted(np.concatenate(parts)), want)  # disjoint and complete
+    assert np.array_equal(_sorted(np.concatenate(parts)), want)
 
 
 def test_random_100k_matches_golden_hash(sccd, ctx):

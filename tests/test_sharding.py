@@ -1,5 +1,5 @@
 """Multi-GPU host logic on CPU: one process per rank over gloo (world_size 2), exactly the code
-path bench.py uses with RCCL -- candidate-balanced row shards, per-rank VF/EE passes, one
+path bench.py uses with RCCL -- entry-balanced windows of grid cells, per-rank VF/EE passes, one
 all-reduce(min) of the time of impact per pass.  The per-rank compute is stubbed with the CPU
 oracle here (tests may use it); the GPU version of the same flow is tests/test_gpu_parity.py::
 test_sharded_sweeps_partition_the_pair_set and bench.py --gpus N."""
@@ -21,13 +21,32 @@ def test_balanced_bounds_cover_and_balance():
     for parts in (1, 2, 3, 8):
         b = sdist.balanced_bounds(w, parts)
         assert b[0] == 0 and b[-1] == len(w) and all(x <= y for x, y in zip(b, b[1:]))
-        sums = [int((w[b[i]:b[i + 1]] + 1).sum()) for i in range(parts)]
-        assert sum(sums) == int((w + 1).sum())
-        assert max(sums) - min(sums) <= 2 * 1001  # within one row's weight of the ideal split
+        sums = [int(w[b[i]:b[i + 1]].sum()) for i in range(parts)]
+        assert sum(sums) == int(w.sum())
+        assert max(sums) - min(sums) <= 2 * 1000  # within one item's weight of the ideal split
     assert sdist.balanced_bounds([], 4) == [0, 0, 0, 0, 0]
-    # one huge row cannot be split: it lands in exactly one shard
-    b = sdist.balanced_bounds([10**9, 1, 1, 1], 2)
-    assert b[0] == 0 and b[-1] == 4
+    # one huge item cannot be split: it lands in exactly one window
+    b = sdist.balanced_bounds([1, 10**9, 1, 1], 2)
+    assert b[0] == 0 and b[-1] == 4 and b[1] in (1, 2)
+    # all the weight in one cell: the other windows are empty, nothing is lost
+    b = sdist.balanced_bounds([0, 0, 7, 0], 3)
+    assert b == sorted(b) and b[0] == 0 and b[-1] == 4
+
+
+def test_shard_bounds_abi_matches_python_mirror():
+    """The split the library applies to the per-cell histogram (host code, runs without a GPU)."""
+    import sccd
+    from sccd import dist as sdist
+
+    rng = np.random.default_rng(3)
+    cases = [rng.integers(0, 5000, size=n).astype(np.uint32) for n in (1, 2, 7, 64, 1000, 1024)]
+    cases += [np.zeros(16, np.uint32), np.array([0, 0, 9, 0], np.uint32), np.full(1024, 0xFFFFFFFF, np.uint32)]
+    for w in cases:
+        for parts in (1, 2, 3, 4, 8, 13):
+            assert sccd.shard_bounds(w, parts) == sdist.balanced_bounds(w, parts)
+    assert sccd.shard_bounds(np.zeros(0, np.uint32), 3) == [0, 0, 0, 0]
+    with pytest.raises(ValueError):
+        sccd.shard_bounds(np.zeros(4, np.uint32), 0)
 
 
 def _free_port():
@@ -57,8 +76,8 @@ def _worker(rank, world, port, q):
 
         def run_pass(is_vf, toi):
             pairs = vf if is_vf else ee
-            # this rank's candidate-balanced share (weights = 1 per pair here)
-            b = sdist.balanced_bounds(np.zeros(len(pairs), np.int64), world)
+            # this rank's share (weights = 1 per pair here)
+            b = sdist.balanced_bounds(np.ones(len(pairs), np.int64), world)
             mine = pairs[b[rank]:b[rank + 1]]
             checked["n"] += len(mine)
             t, _ = orc.narrow_phase_mt(V0, V1, E, F, mine, is_vf, toi=toi, nthreads=2)

@@ -1,0 +1,37 @@
+# SQ counters of the narrow-phase kernels (one rocprofv3 --pmc pass per group of counters):
+#   bash tools/pmc_sq.sh [workload]
+W=${1:-cloth1m}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+i=0
+for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+         "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" \
+         "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_BRANCH" \
+         "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM" \
+         "SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS" \
+         "SQ_INST_LEVEL_SMEM SQ_WAVES" \
+         "SQ_IFETCH SQ_IFETCH_LEVEL" \
+         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY" \
+         "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_SALU" \
+         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_VMEM"; do
+  i=$((i+1))
+  rm -rf gpurun_out/pmcsq_$i
+  rocprofv3 --pmc $G -d gpurun_out/pmcsq_$i --output-format csv -- python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmcsq_$i.log 2>&1 || tail -3 gpurun_out/pmcsq_$i.log
+done
+python3 - <<PY
+import csv,glob,collections,json
+out=collections.defaultdict(dict)
+for d in sorted(glob.glob("gpurun_out/pmcsq_*/")):
+    fs=sorted(glob.glob(d+"*/*counter_collection.csv"))
+    if not fs: continue
+    agg=collections.defaultdict(lambda:[0.0,0])
+    for r in csv.DictReader(open(fs[-1])):
+        nm=r["Kernel_Name"]
+        if "np_queue_k" not in nm and "sweep_stq_k" not in nm and "os_pass_k" not in nm: continue
+        nm=nm.split("(")[0].replace("void ","")
+        agg[(nm,r["Counter_Name"])][0]+=float(r["Counter_Value"]); agg[(nm,r["Counter_Name"])][1]+=1
+    for (k,c),(v,n) in agg.items(): out[k][c]=v/n
+json.dump(out, open("gpurun_out/pmc_sq_$W.json","w"), indent=1, sort_keys=True)
+for k,v in out.items():
+    print(k)
+    for c,x in sorted(v.items()): print("   %-26s %.4g"%(c,x))
+PY
