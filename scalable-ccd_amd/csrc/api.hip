@@ -249,7 +249,7 @@ extern "C" int sccd_mesh_create(sccd_ctx* c, const double* V0, const double* V1,
         m->nV = nV;
         m->nE = nE;
         m->nF = nF;
-        m->V.ensure(sizeof(double) * 8 * (size_t)std::max(nV, 1));
+        m->V.ensure(sizeof(double) * 6 * (size_t)std::max(nV, 1));
         m->E.ensure(sizeof(int2) * (size_t)std::max(nE, 1));
         m->F.ensure(sizeof(int4) * (size_t)std::max(nF, 1));
         const int32_t *dE = E, *dF = F;
@@ -298,7 +298,7 @@ extern "C" int sccd_build_vertex_boxes(sccd_ctx* c, const double* V0, const doub
         const size_t nb = sizeof(double) * 3 * (size_t)nV;
         c->tmp0.ensure(nb);
         c->tmp1.ensure(nb);
-        c->tmp2.ensure(sizeof(double) * 8 * (size_t)nV);
+        c->tmp2.ensure(sizeof(double) * 6 * (size_t)nV);
         c->np_scratch0.ensure(sizeof(sccd_aabb) * (size_t)nV);
         copy_in(c, c->tmp0.p, V0, nb, 0);
         copy_in(c, c->tmp1.p, V1, nb, 0);

@@ -18,17 +18,16 @@ namespace {
 constexpr int TPB = 256;
 inline int grid_for(long long n) { return (int)((n + TPB - 1) / TPB); }
 
-// column-major V0,V1 (Eigen) -> packed {x0,y0,z0,0,x1,y1,z1,0}
+// column-major V0,V1 (Eigen) -> packed {x0,y0,z0,x1,y1,z1}
 __global__ void pack_vertices_k(const double* __restrict__ V0, const double* __restrict__ V1, int nV,
                                 double* __restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nV) return;
-    double4 a = make_double4(V0[i], V0[i + (size_t)nV], V0[i + 2 * (size_t)nV], 0.0);
-    double4 b = make_double4(V1[i], V1[i + (size_t)nV], V1[i + 2 * (size_t)nV], 0.0);
-    double4* o = reinterpret_cast<double4*>(out) + 2 * (size_t)i;
-    o[0] = a;
-    o[1] = b;
+    double2* o = reinterpret_cast<double2*>(out) + 3 * (size_t)i;
+    o[0] = make_double2(V0[i], V0[i + (size_t)nV]);
+    o[1] = make_double2(V0[i + 2 * (size_t)nV], V1[i]);
+    o[2] = make_double2(V1[i + (size_t)nV], V1[i + 2 * (size_t)nV]);
 }
 
 __global__ void pack_edges_k(const int* __restrict__ E, int nE, int2* __restrict__ out)
@@ -64,9 +63,9 @@ __global__ void vertex_boxes_k(const double* __restrict__ V, int nV, double r, s
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nV) return;
-    const double4* v = reinterpret_cast<const double4*>(V) + 2 * (size_t)i;
-    const double4 a = v[0], b = v[1];
-    const double p0[3] = { a.x, a.y, a.z }, p1[3] = { b.x, b.y, b.z };
+    const double2* v = reinterpret_cast<const double2*>(V) + 3 * (size_t)i;
+    const double2 a = v[0], b = v[1], c2 = v[2];
+    const double p0[3] = { a.x, a.y, b.x }, p1[3] = { b.y, c2.x, c2.y };
     const double ru = nextafter_up(r);
     double lo[3], hi[3];
 #pragma unroll

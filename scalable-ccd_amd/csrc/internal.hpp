@@ -5,9 +5,10 @@
 // ------------------------------------------------------------------------------------------
 // HBM layouts (DESIGN.md "Data layout in HBM")
 //
-// mesh.V   : double[nV][8]  = {x0,y0,z0,0, x1,y1,z1,0}  -- both frames of a vertex in ONE
-//            64-byte record, so a narrow-phase query gathers 4 records (reference: two
-//            column-major matrices, 24 separate 8-byte gathers per query, narrow_phase.cu:44-66)
+// mesh.V   : double[nV][6]  = {x0,y0,z0, x1,y1,z1}  -- both frames of a vertex in ONE 48-byte
+//            record of three 16-byte pieces (the unit of the narrow phase's LDS-direct loads), so
+//            a query gathers 4 records (reference: two column-major matrices, 24 separate
+//            8-byte gathers per query, narrow_phase.cu:44-66)
 // mesh.E   : int2[nE], mesh.F : int4[nF] = {f0,f1,f2,0}   (row records instead of columns)
 //
 // boxes    : sorted along the sort axis by key32(min[axis])
@@ -117,20 +118,26 @@ struct NarrowParams {
     int arith;
 };
 struct NarrowCounters {
-    unsigned long long toi_bits;  // running minimum (non-negative double as u64)
-    unsigned long long n_checks;  // inclusion-function evaluations
-    unsigned long long ticket;    // query chunk ticket
+    // The three hot words sit on separate 128-byte lines: sharing one line, the ticket atomics
+    // queued behind every wave's TOI polls and cost tens of microseconds each.
+    unsigned long long toi_bits; // running minimum (non-negative double as u64): polled + atomicMin
+    unsigned long long pad0[15];
+    unsigned long long ticket;   // query chunk ticket
+    unsigned long long pad1[15];
+    unsigned long long n_checks; // inclusion-function evaluations (one atomicAdd per wave)
     unsigned int overflow;
-    unsigned int pad;
+    unsigned int pad2;
+    unsigned long long pad3[14];
     // occupancy diagnostics of np_queue_k (SCCD_NP_DIAG=1 prints them)
     unsigned long long wave_steps;   // check steps executed by waves
     unsigned long long lane_steps;   // live lanes summed over those steps
-    unsigned long long refill_execs; // executions of the gather+constants block
+    unsigned long long refill_execs; // hand-overs of a staging buffer
     unsigned long long steals;       // sub-domains moved between lanes
     unsigned long long stamp[8];     // SCCD_NP_DIAG=2: shader cycles per loop section, summed over waves
     unsigned long long max_wave_steps, waves_run; // longest wave (the kernel's critical path), waves that got work
     unsigned long long pops_reg, pops_mem; // pops served by the register top / by the HBM stack
 };
+static_assert(sizeof(NarrowCounters) <= 1024, "NarrowCounters must fit its slot of the scalars block");
 // runs the narrow phase on the stream; *toi in/out lives in d_cnt->toi_bits
 void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
                       double* d_per_query_toi);

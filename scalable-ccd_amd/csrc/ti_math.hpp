@@ -67,20 +67,20 @@ __device__ __forceinline__ int4 ti_indices(const int2* __restrict__ E, const int
         return make_int4(ea.x, ea.y, eb.x, eb.y);
     }
 }
-// ... and the gather of their 64-byte records {x0,y0,z0,0,x1,y1,z1,0}
+// ... and the gather of their 48-byte records {x0,y0,z0,x1,y1,z1}
 __device__ __forceinline__ void ti_gather_ids(const double* __restrict__ V, int4 ids, double v[8][3])
 {
     const int id[4] = { ids.x, ids.y, ids.z, ids.w };
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const double4* rec = reinterpret_cast<const double4*>(V) + 2 * (size_t)id[k];
-        const double4 a = rec[0], b = rec[1];
+        const double2* rec = reinterpret_cast<const double2*>(V) + 3 * (size_t)id[k];
+        const double2 a = rec[0], b = rec[1], c = rec[2];
         v[k][0] = a.x;
         v[k][1] = a.y;
-        v[k][2] = a.z;
-        v[k + 4][0] = b.x;
-        v[k + 4][1] = b.y;
-        v[k + 4][2] = b.z;
+        v[k][2] = b.x;
+        v[k + 4][0] = b.y;
+        v[k + 4][1] = c.x;
+        v[k + 4][2] = c.y;
     }
 }
 template <bool VF>
