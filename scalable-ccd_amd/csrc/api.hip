@@ -569,7 +569,6 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     {
         ProfScope ps(c, SCCD_PROF_BOXES);
         SCCD_HIP(hipMemsetAsync(st, 0, sizeof(GridStats), c->stream));
-        SCCD_HIP(hipMemsetAsync(st->kmin, 0xFF, sizeof(st->kmin), c->stream));
         launch_box_stats(c, A->raw.as<sccd_aabb>(), A->n, st);
         if (B) launch_box_stats(c, B->raw.as<sccd_aabb>(), B->n, st);
     }

@@ -178,7 +178,7 @@ __global__ void box_stats_k(const sccd_aabb* __restrict__ raw, int n, GridStats*
             h = fmax(h, red[j][3 + k]);
             s += red[j][6 + k];
         }
-        atomicMin(&st->kmin[k], mono64(l));
+        atomicMax(&st->kmin[k], ~mono64(l)); // stored inverted: the block is zero-initialised by ONE memset
         atomicMax(&st->kmax[k], mono64(h));
         atomicAdd(&st->sumext[k], s);
     }
@@ -192,7 +192,7 @@ __global__ void grid_setup_k(const GridStats* __restrict__ st, int n_total, int 
     const int aa = (axis == 0) ? 1 : 0, ab = (axis == 2) ? 1 : 2;
     double lo[3], hi[3];
     for (int k = 0; k < 3; k++) {
-        lo[k] = mono64_inv(st->kmin[k]);
+        lo[k] = mono64_inv(~st->kmin[k]);
         hi[k] = mono64_inv(st->kmax[k]);
     }
     int S[2];

@@ -13,7 +13,7 @@
 #include "common.hpp"
 
 struct GridStats { // device, filled by box_stats_k
-    unsigned long long kmin[3]; // monotone u64 images of the global min / max per axis
+    unsigned long long kmin[3]; // monotone u64 images of the global min (bitwise INVERTED) / max per axis
     unsigned long long kmax[3];
     double sumext[3];           // sum of box extents per axis
 };

@@ -69,8 +69,12 @@ __device__ __forceinline__ void wave_rank_rows(const uint32_t (&key)[RS_ITEMS], 
 
 // ---- onesweep ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(RS_THREADS) void os_hist_k(const uint32_t* __restrict__ keys, long long n, int num_tiles,
-                                                        uint32_t* __restrict__ partial)
+                                                        uint32_t* __restrict__ partial, uint4* __restrict__ zero,
+                                                        long long zero_n)
 {
+    // every word the passes poll (tickets + look-back status) is zeroed here, not by memsets
+    for (long long i = (long long)blockIdx.x * RS_THREADS + threadIdx.x; i < zero_n; i += (long long)gridDim.x * RS_THREADS)
+        zero[i] = make_uint4(0u, 0u, 0u, 0u);
     __shared__ uint32_t h[4][256];
 #pragma unroll
     for (int p = 0; p < 4; p++) h[p][threadIdx.x] = 0;
@@ -107,19 +111,26 @@ __global__ __launch_bounds__(RS_THREADS) void os_hist_k(const uint32_t* __restri
     for (int p = 0; p < 4; p++) partial[(size_t)blockIdx.x * 1024 + p * 256 + threadIdx.x] = h[p][threadIdx.x];
 }
 
-// bases[p][d] = number of keys whose digit p is < d.  One block per pass; thread d sums its
-// bin over the per-block partial histograms (coalesced across d), then a block scan over d.
-__global__ __launch_bounds__(256) void os_bases_k(const uint32_t* __restrict__ partial, int n_blocks,
-                                                  uint32_t* __restrict__ bases)
+// bases[p][d] = number of keys whose digit p is < d.  One block of 1024 threads per pass: four
+// threads share a digit's column of the per-block partial histograms (coalesced across d, eight
+// independent loads in flight each), LDS adds them up, then a block scan over d.
+__global__ __launch_bounds__(1024) void os_bases_k(const uint32_t* __restrict__ partial, int n_blocks,
+                                                   uint32_t* __restrict__ bases)
 {
+    __shared__ uint32_t part[4][256];
     __shared__ uint32_t wsum[4];
-    const int p = blockIdx.x, d = threadIdx.x;
+    const int p = blockIdx.x, d = threadIdx.x & 255, q = threadIdx.x >> 8;
     uint32_t s = 0;
-    for (int b = 0; b < n_blocks; b++) s += partial[(size_t)b * 1024 + p * 256 + d];
+#pragma unroll 8
+    for (int b = q; b < n_blocks; b += 4) s += partial[(size_t)b * 1024 + p * 256 + d];
+    part[q][d] = s;
+    __syncthreads();
+    s = part[0][d] + part[1][d] + part[2][d] + part[3][d];
     const int lane = lane_id(), w = d >> 6;
     const uint32_t incl = (uint32_t)wave_incl_scan((int)s);
-    if (lane == 63) wsum[w] = incl;
+    if (q == 0 && lane == 63) wsum[w] = incl;
     __syncthreads();
+    if (q != 0) return;
     uint32_t base = 0;
     for (int k = 0; k < w; k++) base += wsum[k];
     bases[p * 256 + d] = base + incl - s;
@@ -397,23 +408,21 @@ bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
         SCCD_HIP(hipGetLastError());
         return (passes & 1) != 0;
     }
-    // onesweep: [4 tickets (padded to 64 B)] [bases 4x256] [partial hist blocks x 1024] [status 4 x tiles x 256]
+    // onesweep: [4 tickets (padded to 64 B)] [status passes x tiles x 256] [bases 4x256] [partial hist blocks x 1024]
     const int hist_blocks = std::min(num_tiles, c->num_cus);
     const int dbg = std::getenv("SCCD_SORT_DBG") ? std::atoi(std::getenv("SCCD_SORT_DBG")) : 0; // timing ablations only
-    const size_t off_bases = 64, off_partial = off_bases + 4096, off_status = off_partial + (size_t)hist_blocks * 4096;
-    const size_t status_bytes = (size_t)4 * num_tiles * 256 * sizeof(uint32_t);
-    c->sort_hist.ensure(off_status + status_bytes);
+    const size_t status_bytes = (size_t)passes * num_tiles * 256 * sizeof(uint32_t);
+    const size_t off_status = 64, off_bases = off_status + status_bytes, off_partial = off_bases + 4096;
+    c->sort_hist.ensure(off_partial + (size_t)hist_blocks * 4096);
     char* base = c->sort_hist.as<char>();
     uint32_t* tickets = reinterpret_cast<uint32_t*>(base);
     uint32_t* bases = reinterpret_cast<uint32_t*>(base + off_bases);
     uint32_t* partial = reinterpret_cast<uint32_t*>(base + off_partial);
     uint32_t* status = reinterpret_cast<uint32_t*>(base + off_status);
-    // every polled word is zeroed before the launches of this call (tickets and status)
-    SCCD_HIP(hipMemsetAsync(tickets, 0, 64, c->stream));
-    SCCD_HIP(hipMemsetAsync(status, 0, status_bytes, c->stream));
+    // every polled word (tickets and status, contiguous) is zeroed by os_hist_k before the passes
     hipLaunchKernelGGL(os_hist_k, dim3(hist_blocks), dim3(RS_THREADS), 0, c->stream, k_in, (long long)n, num_tiles,
-                       partial);
-    hipLaunchKernelGGL(os_bases_k, dim3(4), dim3(256), 0, c->stream, partial, hist_blocks, bases);
+                       partial, reinterpret_cast<uint4*>(base), (long long)((64 + status_bytes) / 16));
+    hipLaunchKernelGGL(os_bases_k, dim3(4), dim3(1024), 0, c->stream, partial, hist_blocks, bases);
     for (int pass = 0; pass < passes; pass++) {
         hipLaunchKernelGGL(os_pass_k, dim3(std::min(num_tiles, c->num_cus * 3)), dim3(RS_THREADS), 0, c->stream, k_in,
                            v_in, k_out, v_out, (long long)n, 8 * pass, num_tiles, bases + 256 * pass,

@@ -450,7 +450,6 @@ void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, c
                   SweepCounters* d_cnt, bool direct)
 {
     if (row_end <= row_begin || cols->m == 0) return;
-    SCCD_HIP(hipMemsetAsync(&d_cnt->tile_ticket, 0, sizeof(unsigned), c->stream));
     if (c->sweep_algo == 1) {
         const int n = row_end - row_begin;
         hipLaunchKernelGGL(sweep_sap_k, dim3((n + 255) / 256), dim3(256), 0, c->stream, rows->box.as<sccd_aabb>(),
