@@ -136,8 +136,8 @@ def main():
         n_boxes = len(V0) + len(F) + len(E)
         q_vf, q_ee = stats["n_vf_pairs"], stats["n_ee_pairs"]  # this rank's queries per step
         units = {  # class -> (algorithmic bytes per step, kernel name, name in the rocprofv3 summaries)
-            "narrow_ee": (BYTES_PER_QUERY * q_ee, "np_queue_k<false> (edge-edge Tight-Inclusion)", "np_queue_k<false, %d>" % args.arith),
-            "narrow_vf": (BYTES_PER_QUERY * q_vf, "np_queue_k<true> (vertex-face Tight-Inclusion)", "np_queue_k<true, %d>" % args.arith),
+            "narrow_ee": (BYTES_PER_QUERY * q_ee, "np_queue_k<false> (edge-edge Tight-Inclusion)", "np_queue_k<false, %d, false>" % args.arith),
+            "narrow_vf": (BYTES_PER_QUERY * q_vf, "np_queue_k<true> (vertex-face Tight-Inclusion)", "np_queue_k<true, %d, false>" % args.arith),
             "sweep": (BYTES_SWEEP_PER_BOX * n_boxes + 8.0 * (q_vf + q_ee), "sweep_stq_k (3 launches per step)", "sweep_stq_k"),
             "sort": (BYTES_SORT_PER_KEY_PASS * 4 * n_boxes, "onesweep radix sort + scans", "os_pass_k"),
             "boxes": (124.0 * n_boxes, "box build, cell count/fill, gather", "entry_gather_k"),
@@ -252,13 +252,20 @@ def bench_sort(args, ctx, sccd, torch):
     ms, launches = prof["sort"]
     ok = bool((keys[1:] >= keys[:-1]).all().item())
     achieved = BYTES_SORT_PER_KEY_PASS * 4 * n * args.steps / (ms * 1e-3) / 1e9
+    traffic = None  # HBM bytes of one sort (4 passes + histogram) from the committed PMC passes (tools/pmc_traffic.sh)
+    try:
+        tk = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_sort16m.json")))["kernels"]
+        traffic = 4 * tk["os_pass_k"]["hbm_bytes_per_launch_corrected"] + tk["os_hist_k"]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        traffic = None
     return {
         "metric": "radix sort keys/sec", "value": n * args.steps / (ms * 1e-3), "unit": "keys/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms / args.steps, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": "16M (u32 key, u32 index) pairs, 4 x 8-bit LSD passes", "sorted": ok},
-        "roofline": {"bound": "hbm", "kernel": "rs_count_k + rs_scan_k + rs_scatter_k x 4", "achieved": round(achieved, 2),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None},
+        "roofline": {"bound": "hbm", "kernel": "onesweep: os_hist_k + os_bases_k + os_pass_k x 4", "achieved": round(achieved, 2),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "avg_launch_ms": round(ms / max(1, launches), 4), "launches": launches},
     }
 
 
