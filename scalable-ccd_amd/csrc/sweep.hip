@@ -238,7 +238,7 @@ __device__ __forceinline__ void confirm(bool active, uint2 cand, const sccd_aabb
     em.push(ok, pr);
 }
 
-__global__ __launch_bounds__(SW_THREADS) void sweep_stq_k(
+__global__ __launch_bounds__(SW_THREADS, 4) void sweep_stq_k(
     const float4* __restrict__ filt_r, const sccd_aabb* __restrict__ box_r, const uint32_t* __restrict__ key_r,
     const uint2* __restrict__ ranges, int row_begin, int row_end, const float4* __restrict__ filt_c,
     const sccd_aabb* __restrict__ box_c, const GridParams* __restrict__ gp, int emit, int2* __restrict__ out,
@@ -257,14 +257,30 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_stq_k(
     // sweep ticket-bound: one hot word serves ~90 atomics/us chip-wide, and a launch has ~27k
     // tiles that each take only a few microseconds.)
     const int n_waves = (int)gridDim.x * SW_WAVES;
+    // the rows of the NEXT tile are requested before the current one is processed (their
+    // latency hides behind the filter / confirm work)
+    uint2 rg_n = make_uint2(0u, 0u);
+    float4 fr_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const int row0 = row_begin + ((int)blockIdx.x * SW_WAVES + w) * 64 + lane;
+        if (row0 < row_end) {
+            rg_n = ranges[row0];
+            fr_n = filt_r[row0];
+        }
+    }
     for (int tile = (int)blockIdx.x * SW_WAVES + w; tile < num_tiles; tile += n_waves) {
         const int row = row_begin + tile * 64 + lane;
         const bool valid = row < row_end;
-        uint2 rg = make_uint2(0u, 0u);
-        float4 fr = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) {
-            rg = ranges[row];
-            fr = filt_r[row];
+        const uint2 rg = rg_n;
+        const float4 fr = fr_n;
+        {
+            const int row_next = row + n_waves * 64;
+            rg_n = make_uint2(0u, 0u);
+            fr_n = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tile + n_waves < num_tiles && row_next < row_end) {
+                rg_n = ranges[row_next];
+                fr_n = filt_r[row_next];
+            }
         }
         const bool nonempty = valid && rg.y > rg.x;
         const unsigned jmin = readfirst_u32(wave_min_u32(nonempty ? rg.x : 0xFFFFFFFFu));
@@ -464,7 +480,11 @@ void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, c
                            (long long)capacity, d_cnt);
     } else {
         const int num_tiles = (row_end - row_begin + 63) / 64;
-        const int grid = std::max(1, std::min((num_tiles + SW_WAVES - 1) / SW_WAVES, c->num_cus * 4));
+        // RESIDENT blocks only: tiles are dealt statically over the grid, so a block that has to wait
+        // for a slot doubles the tail.  128 VGPRs (launch bounds) and 40 KB of LDS -> 4 blocks per CU.
+        // (With 156 VGPRs only 3 of the 4 blocks per CU were resident: sweep 0.61 -> 0.47 ms on C4.)
+        static const int per_cu = std::getenv("SCCD_SWEEP_BLOCKS") ? std::atoi(std::getenv("SCCD_SWEEP_BLOCKS")) : 4;
+        const int grid = std::max(1, std::min((num_tiles + SW_WAVES - 1) / SW_WAVES, c->num_cus * per_cu));
         hipLaunchKernelGGL(sweep_stq_k, dim3(grid), dim3(SW_THREADS), 0, c->stream, rows->filt.as<float4>(),
                            rows->box.as<sccd_aabb>(), rows->key.as<uint32_t>(), ranges, row_begin, row_end,
                            cols->filt.as<float4>(), cols->box.as<sccd_aabb>(), gp, emit, out, (long long)capacity,
