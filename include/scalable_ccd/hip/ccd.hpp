@@ -187,6 +187,49 @@ private:
     std::shared_ptr<DeviceAABBs> m_a, m_b; // shared ownership as in the reference
 };
 
+/// sort_and_sweep() of the reference's CPU API (broad_phase/sort_and_sweep.hpp:28-42,
+/// sort_and_sweep.cpp:197-240), served by the device path: sweeps along `sort_axis` and hands
+/// back the arg-max-variance axis for the next call.  Boxes are taken by value like there.
+inline void sort_and_sweep(std::vector<AABB> boxes, int& sort_axis, std::vector<std::pair<int, int>>& overlaps,
+                           Context& ctx = Context::default_context())
+{
+    overlaps.clear();
+    if (boxes.empty()) return;
+    const int64_t saved = sccd_get_option(ctx.get(), SCCD_OPT_SORT_AXIS);
+    ctx.set_option(SCCD_OPT_SORT_AXIS, sort_axis);
+    try {
+        auto d = std::make_shared<DeviceAABBs>(boxes, ctx);
+        BroadPhase bp(ctx);
+        bp.build(d);
+        overlaps = bp.detect_overlaps();
+        ctx.check(sccd_boxes_variance_axis(ctx.get(), d->get(), nullptr, &sort_axis));
+    } catch (...) {
+        ctx.set_option(SCCD_OPT_SORT_AXIS, saved);
+        throw;
+    }
+    ctx.set_option(SCCD_OPT_SORT_AXIS, saved);
+}
+inline void sort_and_sweep(std::vector<AABB> boxesA, std::vector<AABB> boxesB, int& sort_axis,
+                           std::vector<std::pair<int, int>>& overlaps, Context& ctx = Context::default_context())
+{
+    overlaps.clear();
+    if (boxesA.empty() || boxesB.empty()) return;
+    const int64_t saved = sccd_get_option(ctx.get(), SCCD_OPT_SORT_AXIS);
+    ctx.set_option(SCCD_OPT_SORT_AXIS, sort_axis);
+    try {
+        auto a = std::make_shared<DeviceAABBs>(boxesA, ctx);
+        auto b = std::make_shared<DeviceAABBs>(boxesB, ctx);
+        BroadPhase bp(ctx);
+        bp.build(a, b);
+        overlaps = bp.detect_overlaps();
+        ctx.check(sccd_boxes_variance_axis(ctx.get(), a->get(), b->get(), &sort_axis));
+    } catch (...) {
+        ctx.set_option(SCCD_OPT_SORT_AXIS, saved);
+        throw;
+    }
+    ctx.set_option(SCCD_OPT_SORT_AXIS, saved);
+}
+
 /// The four DeviceMatrix objects of ccd() (ccd.cu:103-106) as one device-resident mesh.
 class DeviceMesh {
 public:

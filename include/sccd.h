@@ -135,6 +135,10 @@ int sccd_broad_phase_is_complete(const sccd_broad_phase* bp); /* broad_phase.cuh
 int64_t sccd_broad_phase_num_boxes(const sccd_broad_phase* bp); /* broad_phase.cuh:63 */
 /* number of sort-axis candidate tests of the last detect call (work metric) */
 int64_t sccd_broad_phase_candidates(const sccd_broad_phase* bp);
+/* The axis the reference's CPU sort_and_sweep() hands back for the NEXT call: arg-max over x, y, z
+ * of sum(c^2) - sum(c)^2 / n of the box centres c = (min + max) / 2 of all boxes of A (and B),
+ * ties to the lower axis (broad_phase/sort_and_sweep.cpp:176-195).  B may be NULL. */
+int sccd_boxes_variance_axis(sccd_ctx* ctx, const sccd_boxes* A, const sccd_boxes* B, int* axis);
 void sccd_free(void* host_ptr);
 
 /* ------------------------------------------------------------------------------------------ */

@@ -634,6 +634,14 @@ extern "C" int64_t sccd_broad_phase_num_boxes(const sccd_broad_phase* bp)
 }
 extern "C" int64_t sccd_broad_phase_candidates(const sccd_broad_phase* bp) { return bp ? bp->candidates : 0; }
 
+extern "C" int sccd_boxes_variance_axis(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B, int* axis)
+{
+    if (!c || !A || !axis) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        *axis = pick_sort_axis(c, A->raw.as<sccd_aabb>(), A->n, B ? B->raw.as<sccd_aabb>() : nullptr, B ? B->n : 0);
+    });
+}
+
 // Fallback shard when the grid has too few cells to deal out: an equal slice of the rows.
 static void shard_rows(sccd_ctx* c, bool row_shard, int lo, int hi, int* out_lo, int* out_hi)
 {

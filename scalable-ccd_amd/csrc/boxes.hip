@@ -465,20 +465,24 @@ void launch_entry_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key,
     SCCD_HIP(hipGetLastError());
 }
 
-int pick_sort_axis(sccd_ctx* c, const sccd_aabb* raw, int n)
+int pick_sort_axis(sccd_ctx* c, const sccd_aabb* raw, int n, const sccd_aabb* raw_b, int n_b)
 {
-    if (n == 0) return 0;
+    if (n + n_b == 0) return 0;
     c->tmp2.ensure(6 * sizeof(double));
     double* acc = c->tmp2.as<double>();
     SCCD_HIP(hipMemsetAsync(acc, 0, 6 * sizeof(double), c->stream));
-    const int grid = std::min(grid_for(n), c->num_cus * 8);
-    hipLaunchKernelGGL(centre_moments_k, dim3(grid), dim3(TPB), 0, c->stream, raw, n, acc);
+    if (n > 0)
+        hipLaunchKernelGGL(centre_moments_k, dim3(std::min(grid_for(n), c->num_cus * 8)), dim3(TPB), 0, c->stream, raw, n,
+                           acc);
+    if (n_b > 0)
+        hipLaunchKernelGGL(centre_moments_k, dim3(std::min(grid_for(n_b), c->num_cus * 8)), dim3(TPB), 0, c->stream,
+                           raw_b, n_b, acc);
     SCCD_HIP(hipGetLastError());
     double h[6];
     SCCD_HIP(hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, c->stream));
     SCCD_HIP(hipStreamSynchronize(c->stream));
     double var[3];
-    for (int k = 0; k < 3; k++) var[k] = h[3 + k] - h[k] * h[k] / n;
+    for (int k = 0; k < 3; k++) var[k] = h[3 + k] - h[k] * h[k] / (n + n_b);
     int ax = 0; // sort_and_sweep.cpp:188-195
     if (var[1] > var[0]) ax = 1;
     if (var[2] > var[ax]) ax = 2;

@@ -81,7 +81,7 @@ void launch_entry_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key,
 // scan.hip
 void exclusive_scan_u32(sccd_ctx* c, const uint32_t* in, uint32_t* out, int n, uint32_t* d_total);
 // variance of box centres per axis -> arg-max axis (sort_and_sweep.cpp:176-195); blocking
-int pick_sort_axis(sccd_ctx* c, const sccd_aabb* raw, int n);
+int pick_sort_axis(sccd_ctx* c, const sccd_aabb* raw, int n, const sccd_aabb* raw_b = nullptr, int n_b = 0);
 
 // sort.hip: in-place LSD radix sort of (key, value) pairs by key, ascending, stable
 bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n, int key_bits = 32);

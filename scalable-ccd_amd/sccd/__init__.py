@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "sccd_broad_phase_detect_overlaps_partial", "sccd_broad_phase_detect_overlaps", "sccd_broad_phase_is_complete",
     "sccd_broad_phase_num_boxes", "sccd_broad_phase_candidates", "sccd_free", "sccd_narrow_phase", "sccd_ccd",
     "sccd_ccd_mesh", "sccd_ccd_mesh_prepare", "sccd_ccd_mesh_pass", "sccd_ipc_ccd_strategy", "sccd_get_profile", "sccd_reset_profile", "sccd_sort_pairs_u32",
-    "sccd_shard_bounds",
+    "sccd_shard_bounds", "sccd_boxes_variance_axis",
 ]
 
 
@@ -366,6 +366,28 @@ class BroadPhase:
             self.close()
         except Exception:
             pass
+
+
+def sort_and_sweep(boxes, boxes_b=None, sort_axis=0, ctx=None):
+    """The reference's CPU entry point (broad_phase/sort_and_sweep.hpp:28-42) on the device path:
+    returns (pairs[n, 2] int32, next_sort_axis) -- one list: (min id, max id); two lists: (A id, B id);
+    next_sort_axis = arg-max variance of the box centres (sort_and_sweep.cpp:176-195)."""
+    ctx = ctx or default_context()
+    if len(boxes) == 0 or (boxes_b is not None and len(boxes_b) == 0):
+        return np.zeros((0, 2), np.int32), sort_axis
+    saved = ctx.get_option(OPT_SORT_AXIS)
+    ctx.set_option(OPT_SORT_AXIS, sort_axis)
+    try:
+        a = DeviceAABBs(boxes, ctx)
+        b = DeviceAABBs(boxes_b, ctx) if boxes_b is not None else None
+        bp = BroadPhase(ctx)
+        bp.build(a, b)
+        pairs = bp.detect_overlaps().reshape(-1, 2)
+        ax = C.c_int(0)
+        ctx._check(lib().sccd_boxes_variance_axis(ctx._h, a._h, b._h if b is not None else None, C.byref(ax)))
+    finally:
+        ctx.set_option(OPT_SORT_AXIS, saved)
+    return pairs, ax.value
 
 
 def narrow_phase(mesh, overlaps, is_vf, max_iter=-1, tol=1e-6, ms=0.0, allow_zero_toi=True, toi=1.0,

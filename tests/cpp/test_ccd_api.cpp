@@ -142,6 +142,32 @@ int main()
     CHECK(ee_overlaps == want_ee);
     CHECK(!want_vf.empty() && !want_ee.empty());
 
+    // ---- the CPU entry point of the reference (tests/test_broad_phase.cpp:46-55), on the device path:
+    // same pairs along every sort axis, and the next axis the CPU code would hand back
+    for (int ax_in = 0; ax_in < 3; ax_in++) {
+        int sort_axis = ax_in, want_axis = ax_in;
+        std::vector<std::pair<int, int>> got;
+        sort_and_sweep(vertex_boxes, face_boxes, sort_axis, got);
+        std::sort(got.begin(), got.end());
+        CHECK(got == want_vf);
+        on = orc_sort_and_sweep_two_lists(ovb.data(), nV, ofb.data(), nF, &want_axis, &op, 4);
+        orc_free(op);
+        CHECK(sort_axis == want_axis);
+        sort_axis = want_axis = ax_in;
+        sort_and_sweep(edge_boxes, sort_axis, got);
+        std::sort(got.begin(), got.end());
+        CHECK(got == want_ee);
+        on = orc_sort_and_sweep(oeb.data(), nE, &want_axis, &op, 4);
+        orc_free(op);
+        CHECK(sort_axis == want_axis);
+    }
+    {
+        int sort_axis = 0;
+        std::vector<std::pair<int, int>> got = { { 1, 2 } };
+        sort_and_sweep(std::vector<AABB>(), sort_axis, got);
+        CHECK(got.empty() && sort_axis == 0); // sort_and_sweep.cpp:203-207
+    }
+
     // ---- narrow phase + ccd (tests/test_narrow_phase.cu:41-65)
     constexpr bool allow_zero_toi = true;
     constexpr Scalar min_distance = 0;

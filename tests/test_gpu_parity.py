@@ -256,6 +256,32 @@ def test_sharded_sweep_on_a_single_cell_grid_splits_rows(sccd, ctx, orc, monkeyp
     assert np.array_equal(_sorted(np.concatenate(parts)), want)
 
 
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_cpu_entry_point_sort_and_sweep(sccd, ctx, orc, axis):
+    """scalable_ccd::sort_and_sweep (sort_and_sweep.hpp:28-42) served by the device path: the pair
+    set of the CPU code along any sort axis, and the arg-max-variance axis it hands back."""
+    V0, V1, E, F = _scene("cloth_ball_small")
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F)
+    want, want_axis, _ = orc.sort_and_sweep(eb, sort_axis=axis)
+    got, got_axis = sccd.sort_and_sweep(eb, sort_axis=axis, ctx=ctx)
+    assert np.array_equal(_sorted(got), want) and got_axis == want_axis
+    want, want_axis, _ = orc.sort_and_sweep(vb, fb, sort_axis=axis)
+    got, got_axis = sccd.sort_and_sweep(vb, fb, sort_axis=axis, ctx=ctx)
+    assert np.array_equal(_sorted(got), want) and got_axis == want_axis
+    # a thin slab: the variance rule must pick the long axis whatever axis was swept
+    b = scenes.random_boxes(5000, seed=9, max_extent=0.02)
+    b["min"][:, 0] *= 0.01
+    b["max"][:, 0] *= 0.01
+    b["min"][:, 2] *= 7.0
+    b["max"][:, 2] *= 7.0
+    want, want_axis, _ = orc.sort_and_sweep(b, sort_axis=axis)
+    got, got_axis = sccd.sort_and_sweep(b, sort_axis=axis, ctx=ctx)
+    assert np.array_equal(_sorted(got), want) and got_axis == want_axis == 2
+    assert ctx.get_option(sccd.OPT_SORT_AXIS) == 0  # the context's own setting is restored
+    empty, ax = sccd.sort_and_sweep(b[:0], sort_axis=axis, ctx=ctx)
+    assert len(empty) == 0 and ax == axis
+
+
 def test_random_100k_matches_golden_hash(sccd, ctx):
     G = json.load(open(GOLDEN))["random_100k"]
     b = scenes.random_boxes(100_000, seed=42, max_extent=0.027)
