@@ -17,8 +17,9 @@ for p in (os.path.join(ROOT, "scalable-ccd_amd"), os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-CASES = ["cloth_ball_10k", "cloth_ball_10k_ms", "soup_400", "random_100k", "cloth_ball_small", "folded_cloth_708"]
-SLOW_CASES = {"folded_cloth_708"}  # BASELINE configs[3]/[4]; ~10 s of CPU, skipped by the CPU test suite
+CASES = ["cloth_ball_10k", "cloth_ball_10k_ms", "soup_400", "random_100k", "cloth_ball_small", "folded_cloth_708", "random_1m"]
+# BASELINE configs[3]/[4] and configs[2]; ~10 s of CPU each, skipped by the CPU test suite
+SLOW_CASES = {"folded_cloth_708", "random_1m"}
 
 
 def _sha(pairs):
@@ -42,8 +43,8 @@ def scene_of(name):
 def compute_case(orc, name):
     from sccd import scenes
 
-    if name == "random_100k":
-        b = scenes.random_boxes(100_000, seed=42, max_extent=0.027)
+    if name in ("random_100k", "random_1m"):
+        b = scenes.random_boxes(100_000 if name == "random_100k" else 1_000_000, seed=42, max_extent=0.027)
         pairs, ax, tests = orc.sort_and_sweep(b, nthreads=8)
         return {"n": int(len(pairs)), "sha256": _sha(pairs), "next_axis": int(ax), "candidate_tests": int(tests)}
     V0, V1, E, F = scene_of(name)

@@ -436,6 +436,34 @@ def cloth1m():
     return scenes.folded_cloth(708)
 
 
+def test_full_size_random_1m_boxes(sccd, ctx):
+    """BASELINE configs[2] at full size: 1M random boxes, one list.  The sorted pair list must hash to
+    the oracle's (tests/golden), and hold the size-independent properties: no pair twice, a < b,
+    every reported pair really overlaps, sweeping along y or z reports the same set."""
+    G = json.load(open(GOLDEN))["random_1m"]
+    b = scenes.random_boxes(1_000_000, seed=42, max_extent=0.027)
+    bp = sccd.BroadPhase(ctx)
+    bp.build(sccd.DeviceAABBs(b, ctx))
+    got = bp.detect_overlaps().reshape(-1, 2)
+    assert len(got) == G["n"]
+    srt = _sorted(got)
+    assert hashlib.sha256(srt.tobytes()).hexdigest() == G["sha256"]
+    assert (srt[:, 0] < srt[:, 1]).all()
+    key = srt[:, 0].astype(np.int64) * len(b) + srt[:, 1]
+    assert (np.diff(key) > 0).all()  # sorted and unique
+    i, j = srt[::97, 0], srt[::97, 1]
+    assert ((b["min"][i] <= b["max"][j]) & (b["min"][j] <= b["max"][i])).all()
+    try:
+        ctx.set_option(sccd.OPT_SORT_AXIS, 2)
+        bp.build(sccd.DeviceAABBs(b, ctx))
+        other = bp.detect_overlaps().reshape(-1, 2)
+    finally:
+        ctx.set_option(sccd.OPT_SORT_AXIS, 0)
+    assert hashlib.sha256(_sorted(other).tobytes()).hexdigest() == G["sha256"]
+    got2, next_axis = sccd.sort_and_sweep(b, sort_axis=0, ctx=ctx)
+    assert len(got2) == G["n"] and next_axis == G["next_axis"]
+
+
 def test_full_size_pair_sets_match_golden_hashes(sccd, ctx, cloth1m):
     """1.49 M VF + 5.06 M EE pairs: identical to the CPU restatement (count + SHA-256 of the
     sorted list), plus size-independent properties: no duplicates, valid ids, no shared vertex."""
