@@ -86,7 +86,7 @@ int sccd_create(int device, sccd_ctx** out)
         SCCD_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
         c->scalars.ensure(4096);
-        c->h_scalars.ensure(4096);
+        c->h_scalars.ensure(16384);
     });
     if (rc != SCCD_OK) {
         g_create_error = c->err;
@@ -502,9 +502,10 @@ static bool build_sorted_list(sccd_ctx* c, const sccd_boxes* b, const GridParams
     {
         ProfScope ps(c, SCCD_PROF_SORT);
         exclusive_scan_u32(c, counts, counts, n, d_total);
-        SCCD_HIP(hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
-        SCCD_HIP(hipMemcpyAsync(&hgp, gp, sizeof hgp, hipMemcpyDeviceToHost, c->stream));
-        SCCD_HIP(hipStreamSynchronize(c->stream));
+        ReadBack rb(c);
+        rb.add(&total, d_total, sizeof total);
+        rb.add(&hgp, gp, sizeof hgp);
+        rb.sync();
     }
     if (can_shrink && !windowed && (int64_t)total > std::max<int64_t>(3 * (int64_t)n, (int64_t)n + 4096)) return false;
     if (total == 0) return true; // no box of this list touches the rank's cells
@@ -590,9 +591,10 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
             if (B) launch_cell_hist(c, B->raw.as<sccd_aabb>(), B->n, gp, d_hist);
             uint32_t hist[1024];
             GridParams hgp;
-            SCCD_HIP(hipMemcpyAsync(hist, d_hist, sizeof hist, hipMemcpyDeviceToHost, c->stream));
-            SCCD_HIP(hipMemcpyAsync(&hgp, gp, sizeof hgp, hipMemcpyDeviceToHost, c->stream));
-            SCCD_HIP(hipStreamSynchronize(c->stream));
+            ReadBack rb(c);
+            rb.add(hist, d_hist, sizeof hist);
+            rb.add(&hgp, gp, sizeof hgp);
+            rb.sync();
             unsigned long long total = 0;
             for (int k = 0; k < hgp.n_cells; k++) total += hist[k];
             // same replication budget as build_sorted_list, decided on the whole grid so that
@@ -735,8 +737,11 @@ static void bp_detect_partial(sccd_broad_phase* bp)
             }
         }
         SweepCounters h;
-        SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
-        SCCD_HIP(hipStreamSynchronize(c->stream));
+        {
+            ReadBack rb(c);
+            rb.add(&h, d_cnt, sizeof h);
+            rb.sync();
+        }
         {
             unsigned long long cs = 0;
             for (int k = 0; k < 32; k++) cs += h.cand_parts[k];
@@ -839,7 +844,7 @@ static NarrowResult run_narrow(sccd_ctx* c, const sccd_mesh* m, const int2* d_pa
     p.arith = c->arith;
     narrow_phase_run(c, p, narrow_counters(c), toi, d_per_query);
     NarrowCounters h;
-    std::memcpy(&h, c->h_scalars.p, sizeof h);
+    std::memcpy(&h, c->h_scalars.as<char>() + 8192, sizeof h);
     return NarrowResult { h.n_checks };
 }
 

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -153,6 +154,34 @@ struct ProfScope {
 };
 
 void sccd_collect_profile(sccd_ctx* c); // api.cpp
+
+// Small device -> host reads go through the pinned mirror: with a pageable destination the
+// runtime stages the copy itself, which costs tens of microseconds per synchronisation point.
+struct ReadBack {
+    sccd_ctx* c;
+    size_t off = 0;
+    struct Item {
+        void* dst;
+        size_t off, bytes;
+    };
+    Item items[8];
+    int n = 0;
+    explicit ReadBack(sccd_ctx* ctx) : c(ctx) {}
+    void add(void* dst, const void* src_dev, size_t bytes)
+    {
+        if (n >= 8 || off + bytes > 8192) throw SccdError { SCCD_E_INVALID, "ReadBack: too many items" }; // [0, 8 KB) of the mirror
+        SCCD_HIP(hipMemcpyAsync(c->h_scalars.as<char>() + off, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        items[n++] = Item { dst, off, bytes };
+        off += (bytes + 15) & ~(size_t)15;
+    }
+    void sync()
+    {
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < n; i++) std::memcpy(items[i].dst, c->h_scalars.as<char>() + items[i].off, items[i].bytes);
+        n = 0;
+        off = 0;
+    }
+};
 
 // ------------------------------------------------------------------------------------------
 // device-side helpers

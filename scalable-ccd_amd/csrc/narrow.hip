@@ -188,10 +188,12 @@ void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
 {
     // toi is in/out and must be >= 0 (narrow_phase.cu:126)
     SCCD_REQUIRE(*h_toi_inout >= 0, "narrow_phase: toi must be >= 0");
+    // pinned mirror: [8 KB, 12 KB) the counters handed to the caller, [12 KB, 16 KB) the upload source
     NarrowCounters h;
-    std::memset(&h, 0, sizeof h);
-    std::memcpy(&h.toi_bits, h_toi_inout, 8);
-    SCCD_HIP(hipMemcpyAsync(d_cnt, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    NarrowCounters* const h_up = reinterpret_cast<NarrowCounters*>(c->h_scalars.as<char>() + 12288);
+    std::memset(h_up, 0, sizeof h);
+    std::memcpy(&h_up->toi_bits, h_toi_inout, 8);
+    SCCD_HIP(hipMemcpyAsync(d_cnt, h_up, sizeof h, hipMemcpyHostToDevice, c->stream));
     // the reference's outer loop runs only while toi > 0 (narrow_phase.cu:136); in the
     // per-query build the guard is absent (:138)
     const bool run = (*h_toi_inout > 0) || d_per_query_toi != nullptr;
@@ -212,8 +214,11 @@ void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
             run_queue(c, p, d_cnt, n);
         }
     }
-    SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    SCCD_HIP(hipStreamSynchronize(c->stream));
+    {
+        ReadBack rb(c);
+        rb.add(&h, d_cnt, sizeof h);
+        rb.sync();
+    }
     if (std::getenv("SCCD_NP_DIAG") && h.wave_steps)
         std::fprintf(stderr, "[sccd np] n=%lld checks=%llu wave_steps=%llu (waves %llu, mean %.1f, longest %llu) lane_util=%.3f refill_execs=%llu steals=%llu pops reg/mem=%llu/%llu\n",
                      n, h.n_checks, h.wave_steps, h.waves_run, (double)h.wave_steps / (double)std::max<unsigned long long>(1, h.waves_run),
@@ -240,6 +245,5 @@ void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
     }
     std::memcpy(h_toi_inout, &h.toi_bits, 8);
     // n_checks is read by the caller through d_cnt mirror
-    c->h_scalars.ensure(sizeof(NarrowCounters));
-    std::memcpy(c->h_scalars.p, &h, sizeof h);
+    std::memcpy(c->h_scalars.as<char>() + 8192, &h, sizeof h);
 }
