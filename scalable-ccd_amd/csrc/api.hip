@@ -481,34 +481,30 @@ extern "C" int sccd_shard_bounds(const uint32_t* weights, int n, int parts, int*
     return SCCD_OK;
 }
 
-// count -> scan -> fill -> sort -> gather for one list.  Returns false when the replication
-// into cells exceeded the budget (the caller then coarsens the grid).
-static bool build_sorted_list(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, int cell_lo, int cell_hi,
-                              bool can_shrink, SortedList* L)
+// One list: count -> scan | (host learns the totals of BOTH lists in one round trip) | fill ->
+// sort -> gather.
+static void list_count(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, int cell_lo, int cell_hi, SortedList* L,
+                       uint32_t* d_total)
 {
     const int n = b->n;
     L->m = 0;
-    if (n == 0) return true;
-    const bool windowed = cell_lo > 0 || cell_hi < (1 << 30);
-    uint32_t* d_total = reinterpret_cast<uint32_t*>(c->scalars.as<char>() + 1536);
-    c->tmp0.ensure(sizeof(uint32_t) * ((size_t)n + 64));
-    uint32_t* counts = c->tmp0.as<uint32_t>();
+    if (n == 0) return;
+    L->offsets.ensure(sizeof(uint32_t) * ((size_t)n + 64));
+    uint32_t* counts = L->offsets.as<uint32_t>();
     {
         ProfScope ps(c, SCCD_PROF_BOXES);
         launch_cell_count(c, b->raw.as<sccd_aabb>(), n, gp, cell_lo, cell_hi, counts);
     }
-    uint32_t total = 0;
-    GridParams hgp;
     {
         ProfScope ps(c, SCCD_PROF_SORT);
         exclusive_scan_u32(c, counts, counts, n, d_total);
-        ReadBack rb(c);
-        rb.add(&total, d_total, sizeof total);
-        rb.add(&hgp, gp, sizeof hgp);
-        rb.sync();
     }
-    if (can_shrink && !windowed && (int64_t)total > std::max<int64_t>(3 * (int64_t)n, (int64_t)n + 4096)) return false;
-    if (total == 0) return true; // no box of this list touches the rank's cells
+}
+static void list_finish(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, int cell_lo, int cell_hi, uint32_t total,
+                        int key_bits, SortedList* L)
+{
+    const int n = b->n;
+    if (n == 0 || total == 0) return; // (no box of this list touches the rank's cells)
     SCCD_REQUIRE(total < (1u << 31), "broad phase: too many cell entries");
     const size_t m = total, pad = 64; // the sweep streams whole 32-column blocks
     L->m = (int)m;
@@ -520,14 +516,14 @@ static bool build_sorted_list(sccd_ctx* c, const sccd_boxes* b, const GridParams
     L->lowcell.ensure(sizeof(uint32_t) * (m + pad));
     {
         ProfScope ps(c, SCCD_PROF_BOXES);
-        launch_cell_fill(c, b->raw.as<sccd_aabb>(), n, gp, cell_lo, cell_hi, counts, L->key.as<uint32_t>(),
-                         L->idx.as<uint32_t>());
+        launch_cell_fill(c, b->raw.as<sccd_aabb>(), n, gp, cell_lo, cell_hi, L->offsets.as<uint32_t>(),
+                         L->key.as<uint32_t>(), L->idx.as<uint32_t>());
     }
     {
         ProfScope ps(c, SCCD_PROF_SORT);
         c->sort_tmp_keys.ensure(sizeof(uint32_t) * (m + pad));
         c->sort_tmp_vals.ensure(sizeof(uint32_t) * (m + pad));
-        if (radix_sort_pairs_u32(c, L->key.as<uint32_t>(), L->idx.as<uint32_t>(), (int64_t)m, hgp.key_bits)) {
+        if (radix_sort_pairs_u32(c, L->key.as<uint32_t>(), L->idx.as<uint32_t>(), (int64_t)m, key_bits)) {
             // odd number of passes: the sorted pairs sit in the ping-pong buffers -- swap, no copy
             std::swap(L->key.p, c->sort_tmp_keys.p);
             std::swap(L->key.cap, c->sort_tmp_keys.cap);
@@ -541,7 +537,6 @@ static bool build_sorted_list(sccd_ctx* c, const sccd_boxes* b, const GridParams
                             L->box.as<sccd_aabb>(), L->filt.as<float4>(), L->kmax.as<uint32_t>(),
                             L->lowcell.as<uint32_t>());
     }
-    return true;
 }
 
 // BroadPhase::build (broad_phase.cu:29-101) together with the key split + sort the reference
@@ -611,8 +606,24 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                 bp->row_shard = true; // (almost) one cell: every rank sorts everything and takes a slice of the rows
             }
         }
-        if (!build_sorted_list(c, A, gp, bp->cell_lo, bp->cell_hi, can_shrink, &bp->la)) continue;
-        if (B && !build_sorted_list(c, B, gp, bp->cell_lo, bp->cell_hi, can_shrink, &bp->lb)) continue;
+        uint32_t* d_total = reinterpret_cast<uint32_t*>(c->scalars.as<char>() + 1536);
+        list_count(c, A, gp, bp->cell_lo, bp->cell_hi, &bp->la, d_total);
+        if (B) list_count(c, B, gp, bp->cell_lo, bp->cell_hi, &bp->lb, d_total + 1);
+        uint32_t total[2] = { 0, 0 };
+        GridParams hgp;
+        {
+            ProfScope ps(c, SCCD_PROF_SORT);
+            ReadBack rb(c);
+            rb.add(total, d_total, sizeof(uint32_t) * (B ? 2 : 1));
+            rb.add(&hgp, gp, sizeof hgp);
+            rb.sync();
+        }
+        // replication into cells beyond the budget: coarsen the grid (decided per list, whole grid only)
+        const bool windowed = bp->cell_lo > 0 || bp->cell_hi < (1 << 30);
+        auto over = [&](uint32_t t, int n) { return (int64_t)t > std::max<int64_t>(3 * (int64_t)n, (int64_t)n + 4096); };
+        if (can_shrink && !windowed && (over(total[0], A->n) || (B && over(total[1], B->n)))) continue;
+        list_finish(c, A, gp, bp->cell_lo, bp->cell_hi, total[0], hgp.key_bits, &bp->la);
+        if (B) list_finish(c, B, gp, bp->cell_lo, bp->cell_hi, total[1], hgp.key_bits, &bp->lb);
         break;
     }
     if (B && (bp->la.m == 0 || bp->lb.m == 0)) bp->la.m = bp->lb.m = 0; // nothing to pair in this window

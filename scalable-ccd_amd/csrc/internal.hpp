@@ -37,6 +37,7 @@ struct SortedList {
     int m = 0; // entries (>= number of boxes)
     DevBuf key, kmax, filt, box, idx;
     DevBuf lowcell; // uint32[m]: lowest cell of the entry's box on the two minor axes (a | b << 16)
+    DevBuf offsets; // uint32[n boxes]: first entry of each box (scanned cell counts), build scratch
 };
 
 struct sccd_broad_phase {
