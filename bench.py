@@ -183,10 +183,11 @@ def main():
     else:
         result = bench_sort(args, ctx, sccd, torch)
 
-    if rank == 0:
-        print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:  # the ONE JSON line is the last thing on stdout (RCCL may print a banner at init / teardown)
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 def bench_boxes(args, ctx, sccd, scenes, torch):
