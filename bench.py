@@ -57,13 +57,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or os.environ.get("SCCD_FORCE_DIST") == "1"  # the latter: exercise RCCL with one rank
+    # SCCD_BENCH_BACKEND=gloo lets several ranks share ONE GPU (a functional check of the N > 1 path on a
+    # 1-GPU box; the timings of such a run mean nothing).  The driver's runs use nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get("SCCD_BENCH_BACKEND", "nccl")
+    dev_index = (local_rank % max(1, torch.cuda.device_count())) if world > 1 else 0
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the scalars of the all-reduces live
 
     import sccd
     from sccd import dist as sdist
@@ -102,7 +110,7 @@ def main():
         def step():
             return sdist.ccd_sharded(
                 lambda is_vf, toi: sccd.ccd_mesh_pass(mesh, is_vf, toi, **params),
-                rank, world, device=dev, prepare=lambda: sccd.ccd_mesh_prepare(mesh, 0.0))
+                rank, world, device=red_dev, prepare=lambda: sccd.ccd_mesh_prepare(mesh, 0.0))
 
         for _ in range(args.warmup):
             step()
@@ -121,9 +129,9 @@ def main():
         prof = ctx.profile()
         ctx.set_option(sccd.OPT_PROFILE, 0)
         # max over ranks of the elapsed time, sum over ranks of the queries
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         qq = torch.tensor([float(q_local), float(stats["n_vf_checks"] + stats["n_ee_checks"]),
-                           float(stats["n_vf_candidates"] + stats["n_ee_candidates"])], dtype=torch.float64, device=dev)
+                           float(stats["n_vf_candidates"] + stats["n_ee_candidates"])], dtype=torch.float64, device=red_dev)
         if use_dist:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dist.all_reduce(qq, op=dist.ReduceOp.SUM)

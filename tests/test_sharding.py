@@ -116,3 +116,33 @@ def test_single_rank_needs_no_process_group():
     assert sdist.allreduce_min(0.25) == 0.25
     toi, st = sdist.ccd_sharded(lambda is_vf, toi: (min(toi, 0.5 if is_vf else 0.75), {"x": 1}), 0, 1)
     assert toi == 0.5 and st == {"x": 2}
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu_and_agree_with_one_rank():
+    """bench.py's N > 1 path end to end on the GPU box: two processes (gloo, both on cuda:0), each
+    building / sorting / sweeping / narrowing its window of grid cells, two all-reduce(min).
+    Queries must add up to the single-rank count and the TOI must be the same."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, SCCD_BENCH_BACKEND="gloo")
+    common = ["bench.py", "--cloth-n", "160", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+
+    def last_json(out):
+        lines = [ln for ln in out.splitlines() if ln.startswith("{\"metric\"")]
+        assert lines, out[-2000:]
+        return json.loads(lines[-1])
+
+    one = subprocess.run([sys.executable] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    port = _free_port()
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port)] + common + ["--gpus", "2"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a, b = last_json(one.stdout), last_json(two.stdout)
+    assert b["n_gpus"] == 2 and a["n_gpus"] == 1
+    assert b["config"]["queries_per_step"] == a["config"]["queries_per_step"] > 0
+    assert b["config"]["toi"] == a["config"]["toi"]
+    assert b["config"]["candidates_per_step"] == a["config"]["candidates_per_step"]
