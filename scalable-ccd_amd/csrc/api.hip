@@ -557,16 +557,18 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     // two lists with an empty side produce nothing (sort_and_sweep.cpp:221-223)
     if (A->n == 0 || (B && B->n == 0)) return;
 
-    bp->grid.ensure(8192);
+    bp->grid.ensure(8192 + sizeof(double) * 3 * 2 * SCCD_STATS_BLOCKS); // stats | params | cell histogram | extent partials
     GridStats* st = bp->grid.as<GridStats>();
     GridParams* gp = reinterpret_cast<GridParams*>(bp->grid.as<char>() + 512);
+    double* part = reinterpret_cast<double*>(bp->grid.as<char>() + 8192);
+    int n_part = 0;
     int axis = c->sort_axis;
     if (axis < 0) axis = pick_sort_axis(c, A->raw.as<sccd_aabb>(), A->n);
     {
         ProfScope ps(c, SCCD_PROF_BOXES);
         SCCD_HIP(hipMemsetAsync(st, 0, sizeof(GridStats), c->stream));
-        launch_box_stats(c, A->raw.as<sccd_aabb>(), A->n, st);
-        if (B) launch_box_stats(c, B->raw.as<sccd_aabb>(), B->n, st);
+        n_part = launch_box_stats(c, A->raw.as<sccd_aabb>(), A->n, st, part);
+        if (B) n_part += launch_box_stats(c, B->raw.as<sccd_aabb>(), B->n, st, part + 3 * n_part);
     }
     const int n_total = A->n + (B ? B->n : 0);
     const double cf = cell_factor();
@@ -574,7 +576,7 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     bp->cell_hi = 1 << 30;
     bp->row_shard = false;
     for (int shrink = 0;; shrink++) {
-        launch_grid_setup(c, st, n_total, axis, cf, shrink, gp);
+        launch_grid_setup(c, st, part, n_part, n_total, axis, cf, shrink, gp);
         const bool can_shrink = shrink < 10;
         // Multi-GPU: every rank takes a contiguous window of cells with an equal share of the
         // entries, and builds / sorts / sweeps only that window.  A pair is reported from exactly

@@ -135,8 +135,13 @@ __global__ void face_boxes_k(const sccd_aabb* __restrict__ vb, const int4* __res
 
 // ---- composite key: cell on the minor axes + quantised sort coordinate (grid.hpp) ------------
 
-// global bounds and summed extents of a box list (run once per list of a build)
-__global__ void box_stats_k(const sccd_aabb* __restrict__ raw, int n, GridStats* __restrict__ st)
+// Global bounds and summed extents of a box list (run once per list of a build).  The bounds
+// are exact and order-independent (integer atomics on monotone images); the extent sums are
+// written per BLOCK and added up in a fixed order by grid_setup_k, so that every rank of a
+// multi-GPU run derives bit-identical grid parameters from the same boxes (a floating-point
+// atomicAdd would make the cell size depend on the order the blocks happen to finish in).
+__global__ void box_stats_k(const sccd_aabb* __restrict__ raw, int n, GridStats* __restrict__ st,
+                            double* __restrict__ part /* [gridDim.x][3] */)
 {
     double lo[3] = { TI_INF, TI_INF, TI_INF }, hi[3] = { -TI_INF, -TI_INF, -TI_INF }, se[3] = { 0, 0, 0 };
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -180,14 +185,28 @@ __global__ void box_stats_k(const sccd_aabb* __restrict__ raw, int n, GridStats*
         }
         atomicMax(&st->kmin[k], ~mono64(l)); // stored inverted: the block is zero-initialised by ONE memset
         atomicMax(&st->kmax[k], mono64(h));
-        atomicAdd(&st->sumext[k], s);
+        part[blockIdx.x * 3 + k] = s;
     }
 }
 
 // cell size = cell_factor x mean box extent on that axis; at most 2^10 cells in total
-__global__ void grid_setup_k(const GridStats* __restrict__ st, int n_total, int axis, double cell_factor, int shrink,
-                             GridParams* __restrict__ g)
+__global__ void grid_setup_k(const GridStats* __restrict__ st, const double* __restrict__ part, int n_part, int n_total,
+                             int axis, double cell_factor, int shrink, GridParams* __restrict__ g)
 {
+    // summed extents: lane l adds the block partials l, l + 64, ... in that order, then a fixed
+    // shuffle tree -- the same bits on every run and every rank (one wave)
+    double sumext[3];
+    {
+        const int lane = lane_id();
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double s = 0.0;
+            for (int j = lane; j < n_part; j += 64) s += part[j * 3 + k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            sumext[k] = s;
+        }
+    }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int aa = (axis == 0) ? 1 : 0, ab = (axis == 2) ? 1 : 2;
     double lo[3], hi[3];
@@ -200,7 +219,7 @@ __global__ void grid_setup_k(const GridStats* __restrict__ st, int n_total, int 
     for (int t = 0; t < 2; t++) {
         const int k = ax2[t];
         const double range = hi[k] - lo[k];
-        const double mean = n_total > 0 ? st->sumext[k] / (double)n_total : 0.0;
+        const double mean = n_total > 0 ? sumext[k] / (double)n_total : 0.0;
         const double h = cell_factor * mean;
         double s = (h > 0.0 && range > 0.0 && range < TI_INF) ? floor(range / h) : 1.0;
         if (!(s >= 1.0)) s = 1.0;
@@ -227,7 +246,7 @@ __global__ void grid_setup_k(const GridStats* __restrict__ st, int n_total, int 
     // bits of the quantised sort coordinate: 16 quanta per mean box extent keep the candidate
     // ranges tight; the total key width is rounded up to whole 8-bit radix passes (<= 32 bits)
     const double xr = hi[axis] - lo[axis];
-    const double xmean = n_total > 0 ? st->sumext[axis] / (double)n_total : 0.0;
+    const double xmean = n_total > 0 ? (axis == 0 ? sumext[0] : (axis == 1 ? sumext[1] : sumext[2])) / (double)n_total : 0.0;
     int need = 32;
     if (xr > 0.0 && xr < TI_INF && xmean > 0.0) {
         double ratio = 16.0 * xr / xmean;
@@ -353,8 +372,9 @@ __global__ void entry_gather_k(const sccd_aabb* __restrict__ raw, const uint32_t
     lowcell[e] = (uint32_t)grid_cell_a(g, lo[g.aa]) | ((uint32_t)grid_cell_b(g, lo[g.ab]) << 16);
 }
 
-// sum and sum of squares of the box centres per axis (sort_and_sweep.cpp:176-186)
-__global__ void centre_moments_k(const sccd_aabb* __restrict__ raw, int n, double* __restrict__ acc)
+// sum and sum of squares of the box centres per axis (sort_and_sweep.cpp:176-186): per-block
+// partials, added up on the host in index order (deterministic, like the extent sums)
+__global__ void centre_moments_k(const sccd_aabb* __restrict__ raw, int n, double* __restrict__ part /* [gridDim.x][6] */)
 {
     double s[3] = { 0, 0, 0 }, s2[3] = { 0, 0, 0 };
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -374,12 +394,21 @@ __global__ void centre_moments_k(const sccd_aabb* __restrict__ raw, int n, doubl
             s2[k] += __shfl_xor(s2[k], o, 64);
         }
     }
+    __shared__ double red[TPB / 64][6];
+    const int w = threadIdx.x >> 6;
     if (lane_id() == 0) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            atomicAdd(&acc[k], s[k]);
-            atomicAdd(&acc[3 + k], s2[k]);
+            red[w][k] = s[k];
+            red[w][3 + k] = s2[k];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double t = red[0][threadIdx.x];
+#pragma unroll
+        for (int j = 1; j < TPB / 64; j++) t += red[j][threadIdx.x];
+        part[blockIdx.x * 6 + threadIdx.x] = t;
     }
 }
 
@@ -421,17 +450,20 @@ void launch_face_boxes(sccd_ctx* c, const sccd_aabb* vb, const int4* F, int nF, 
     hipLaunchKernelGGL(face_boxes_k, dim3(grid_for(nF)), dim3(TPB), 0, c->stream, vb, F, nF, out);
     SCCD_HIP(hipGetLastError());
 }
-void launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st)
+// returns the number of block partials written to `part` (at most SCCD_STATS_BLOCKS)
+int launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st, double* part)
 {
-    if (n == 0) return;
-    const int grid = std::min(grid_for(n), c->num_cus * 2);
-    hipLaunchKernelGGL(box_stats_k, dim3(grid), dim3(TPB), 0, c->stream, raw, n, st);
+    if (n == 0) return 0;
+    const int grid = std::min(grid_for(n), SCCD_STATS_BLOCKS);
+    hipLaunchKernelGGL(box_stats_k, dim3(grid), dim3(TPB), 0, c->stream, raw, n, st, part);
     SCCD_HIP(hipGetLastError());
+    return grid;
 }
-void launch_grid_setup(sccd_ctx* c, const GridStats* st, int n_total, int axis, double cell_factor, int shrink,
-                       GridParams* g)
+void launch_grid_setup(sccd_ctx* c, const GridStats* st, const double* part, int n_part, int n_total, int axis,
+                       double cell_factor, int shrink, GridParams* g)
 {
-    hipLaunchKernelGGL(grid_setup_k, dim3(1), dim3(64), 0, c->stream, st, n_total, axis, cell_factor, shrink, g);
+    hipLaunchKernelGGL(grid_setup_k, dim3(1), dim3(64), 0, c->stream, st, part, n_part, n_total, axis, cell_factor,
+                       shrink, g);
     SCCD_HIP(hipGetLastError());
 }
 void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, uint32_t* hist)
@@ -468,19 +500,18 @@ void launch_entry_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key,
 int pick_sort_axis(sccd_ctx* c, const sccd_aabb* raw, int n, const sccd_aabb* raw_b, int n_b)
 {
     if (n + n_b == 0) return 0;
-    c->tmp2.ensure(6 * sizeof(double));
-    double* acc = c->tmp2.as<double>();
-    SCCD_HIP(hipMemsetAsync(acc, 0, 6 * sizeof(double), c->stream));
-    if (n > 0)
-        hipLaunchKernelGGL(centre_moments_k, dim3(std::min(grid_for(n), c->num_cus * 8)), dim3(TPB), 0, c->stream, raw, n,
-                           acc);
-    if (n_b > 0)
-        hipLaunchKernelGGL(centre_moments_k, dim3(std::min(grid_for(n_b), c->num_cus * 8)), dim3(TPB), 0, c->stream,
-                           raw_b, n_b, acc);
+    const int ga = n > 0 ? std::min(grid_for(n), SCCD_STATS_BLOCKS) : 0, gb = n_b > 0 ? std::min(grid_for(n_b), SCCD_STATS_BLOCKS) : 0;
+    c->tmp2.ensure(sizeof(double) * 6 * (size_t)(ga + gb));
+    double* part = c->tmp2.as<double>();
+    if (ga) hipLaunchKernelGGL(centre_moments_k, dim3(ga), dim3(TPB), 0, c->stream, raw, n, part);
+    if (gb) hipLaunchKernelGGL(centre_moments_k, dim3(gb), dim3(TPB), 0, c->stream, raw_b, n_b, part + 6 * ga);
     SCCD_HIP(hipGetLastError());
-    double h[6];
-    SCCD_HIP(hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> hp(6 * (size_t)(ga + gb));
+    SCCD_HIP(hipMemcpyAsync(hp.data(), part, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, c->stream));
     SCCD_HIP(hipStreamSynchronize(c->stream));
+    double h[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int j = 0; j < ga + gb; j++)
+        for (int k = 0; k < 6; k++) h[k] += hp[(size_t)j * 6 + k];
     double var[3];
     for (int k = 0; k < 3; k++) var[k] = h[3 + k] - h[k] * h[k] / (n + n_b);
     int ax = 0; // sort_and_sweep.cpp:188-195

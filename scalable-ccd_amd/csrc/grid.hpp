@@ -15,8 +15,9 @@
 struct GridStats { // device, filled by box_stats_k
     unsigned long long kmin[3]; // monotone u64 images of the global min (bitwise INVERTED) / max per axis
     unsigned long long kmax[3];
-    double sumext[3];           // sum of box extents per axis
+    double sumext[3];           // (unused: the extent sums travel as per-block partials, see box_stats_k)
 };
+constexpr int SCCD_STATS_BLOCKS = 512; // blocks of box_stats_k per list (fixed: the partial sums must not depend on the device)
 
 struct GridParams { // device, written by grid_setup_k
     int axis, aa, ab; // sort axis and the two minor axes

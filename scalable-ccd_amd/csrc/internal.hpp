@@ -68,9 +68,9 @@ void launch_edge_boxes(sccd_ctx* c, const sccd_aabb* vb, const int2* E, int nE, 
 void launch_face_boxes(sccd_ctx* c, const sccd_aabb* vb, const int4* F, int nF, sccd_aabb* out);
 struct GridStats;
 struct GridParams;
-void launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st);
-void launch_grid_setup(sccd_ctx* c, const GridStats* st, int n_total, int axis, double cell_factor, int shrink,
-                       GridParams* g);
+int launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st, double* part);
+void launch_grid_setup(sccd_ctx* c, const GridStats* st, const double* part, int n_part, int n_total, int axis,
+                       double cell_factor, int shrink, GridParams* g);
 void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, uint32_t* hist);
 void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
                        uint32_t* counts);
