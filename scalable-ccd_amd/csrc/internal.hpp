@@ -137,6 +137,7 @@ struct NarrowCounters {
     unsigned long long stamp[8];     // SCCD_NP_DIAG=2: shader cycles per loop section, summed over waves
     unsigned long long max_wave_steps, waves_run; // longest wave (the kernel's critical path), waves that got work
     unsigned long long pops_reg, pops_mem; // pops served by the register top / by the HBM stack
+    unsigned long long wave_hist[16];      // waves by number of check steps, buckets of 16 (last: >= 240)
 };
 static_assert(sizeof(NarrowCounters) <= 1024, "NarrowCounters must fit its slot of the scalars block");
 // runs the narrow phase on the stream; *toi in/out lives in d_cnt->toi_bits
