@@ -371,19 +371,44 @@ static void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline*
 {
     (void)want_v;
     ProfScope ps(c, SCCD_PROF_BOXES);
+    // the builders also produce the bounds / extent sums the grid needs (no second pass over the boxes)
+    auto begin_stats = [&](sccd_boxes& b) {
+        b.stats.ensure(SCCD_STATS_BYTES);
+        SCCD_HIP(hipMemsetAsync(b.stats.p, 0, 128, c->stream));
+        b.have_stats = false;
+    };
     pl->vb.n = m->nV;
     pl->vb.raw.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nV, 1));
-    launch_vertex_boxes(c, m->V.as<double>(), m->nV, r, pl->vb.raw.as<sccd_aabb>());
+    begin_stats(pl->vb);
+    pl->vb.n_part = launch_vertex_boxes(c, m->V.as<double>(), m->nV, r, pl->vb.raw.as<sccd_aabb>(), pl->vb.stats_head(),
+                                        pl->vb.stats_part());
+    pl->vb.have_stats = true;
     if (want_e) {
         pl->eb.n = m->nE;
         pl->eb.raw.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nE, 1));
-        launch_edge_boxes(c, pl->vb.raw.as<sccd_aabb>(), m->E.as<int2>(), m->nE, pl->eb.raw.as<sccd_aabb>());
+        begin_stats(pl->eb);
+        pl->eb.n_part = launch_edge_boxes(c, pl->vb.raw.as<sccd_aabb>(), m->E.as<int2>(), m->nE,
+                                          pl->eb.raw.as<sccd_aabb>(), pl->eb.stats_head(), pl->eb.stats_part());
+        pl->eb.have_stats = true;
     }
     if (want_f) {
         pl->fb.n = m->nF;
         pl->fb.raw.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nF, 1));
-        launch_face_boxes(c, pl->vb.raw.as<sccd_aabb>(), m->F.as<int4>(), m->nF, pl->fb.raw.as<sccd_aabb>());
+        begin_stats(pl->fb);
+        pl->fb.n_part = launch_face_boxes(c, pl->vb.raw.as<sccd_aabb>(), m->F.as<int4>(), m->nF,
+                                          pl->fb.raw.as<sccd_aabb>(), pl->fb.stats_head(), pl->fb.stats_part());
+        pl->fb.have_stats = true;
     }
+}
+
+// statistics of a list that was uploaded rather than built here: one pass, cached in the object
+static void ensure_stats(sccd_ctx* c, const sccd_boxes* b)
+{
+    if (b->have_stats) return;
+    b->stats.ensure(SCCD_STATS_BYTES);
+    SCCD_HIP(hipMemsetAsync(b->stats.p, 0, 128, c->stream));
+    b->n_part = launch_box_stats(c, b->raw.as<sccd_aabb>(), b->n, b->stats_head(), b->stats_part());
+    b->have_stats = true;
 }
 
 static sccd_boxes* clone_boxes(sccd_ctx* c, const sccd_boxes& s)
@@ -557,18 +582,14 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     // two lists with an empty side produce nothing (sort_and_sweep.cpp:221-223)
     if (A->n == 0 || (B && B->n == 0)) return;
 
-    bp->grid.ensure(8192 + sizeof(double) * 3 * 2 * SCCD_STATS_BLOCKS); // stats | params | cell histogram | extent partials
-    GridStats* st = bp->grid.as<GridStats>();
+    bp->grid.ensure(8192); // (unused) | params @512 | cell histogram @4096
     GridParams* gp = reinterpret_cast<GridParams*>(bp->grid.as<char>() + 512);
-    double* part = reinterpret_cast<double*>(bp->grid.as<char>() + 8192);
-    int n_part = 0;
     int axis = c->sort_axis;
     if (axis < 0) axis = pick_sort_axis(c, A->raw.as<sccd_aabb>(), A->n);
     {
         ProfScope ps(c, SCCD_PROF_BOXES);
-        SCCD_HIP(hipMemsetAsync(st, 0, sizeof(GridStats), c->stream));
-        n_part = launch_box_stats(c, A->raw.as<sccd_aabb>(), A->n, st, part);
-        if (B) n_part += launch_box_stats(c, B->raw.as<sccd_aabb>(), B->n, st, part + 3 * n_part);
+        ensure_stats(c, A);
+        if (B) ensure_stats(c, B);
     }
     const int n_total = A->n + (B ? B->n : 0);
     const double cf = cell_factor();
@@ -576,7 +597,8 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     bp->cell_hi = 1 << 30;
     bp->row_shard = false;
     for (int shrink = 0;; shrink++) {
-        launch_grid_setup(c, st, part, n_part, n_total, axis, cf, shrink, gp);
+        launch_grid_setup(c, A->stats_head(), A->stats_part(), A->n_part, B ? B->stats_head() : nullptr,
+                          B ? B->stats_part() : nullptr, B ? B->n_part : 0, n_total, axis, cf, shrink, gp);
         const bool can_shrink = shrink < 10;
         // Multi-GPU: every rank takes a contiguous window of cells with an equal share of the
         // entries, and builds / sorts / sweeps only that window.  A pair is reported from exactly

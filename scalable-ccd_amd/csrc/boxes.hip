@@ -55,27 +55,94 @@ __device__ __forceinline__ void store_box(sccd_aabb* out, const double lo[3], co
     oi[0] = make_int4(v0, v1, v2, eid);
 }
 
+// bounds + summed extents of the boxes a thread has produced / read; finish() reduces over the
+// block and publishes: exact integer atomics for the bounds, ONE partial per block for the sums
+// (added up in a fixed order by grid_setup_k: every rank of a multi-GPU run must derive
+// bit-identical grid parameters, which a floating-point atomicAdd would not guarantee)
+struct StatsAcc {
+    double lo[3], hi[3], se[3];
+    __device__ __forceinline__ StatsAcc()
+    {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            lo[k] = TI_INF;
+            hi[k] = -TI_INF;
+            se[k] = 0.0;
+        }
+    }
+    __device__ __forceinline__ void add(const double (&l)[3], const double (&h)[3])
+    {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            lo[k] = fmin(lo[k], l[k]);
+            hi[k] = fmax(hi[k], h[k]);
+            se[k] += h[k] - l[k];
+        }
+    }
+    // every thread of the block must call this
+    __device__ __forceinline__ void finish(GridStats* __restrict__ st, double* __restrict__ part)
+    {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                lo[k] = fmin(lo[k], __shfl_xor(lo[k], o, 64));
+                hi[k] = fmax(hi[k], __shfl_xor(hi[k], o, 64));
+                se[k] += __shfl_xor(se[k], o, 64);
+            }
+        }
+        __shared__ double red[TPB / 64][9];
+        const int w = threadIdx.x >> 6;
+        if (lane_id() == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                red[w][k] = lo[k];
+                red[w][3 + k] = hi[k];
+                red[w][6 + k] = se[k];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int k = threadIdx.x;
+            double l = red[0][k], h = red[0][3 + k], s = red[0][6 + k];
+#pragma unroll
+            for (int j = 1; j < TPB / 64; j++) {
+                l = fmin(l, red[j][k]);
+                h = fmax(h, red[j][3 + k]);
+                s += red[j][6 + k];
+            }
+            atomicMax(&st->kmin[k], ~mono64(l)); // stored inverted: the block is zero-initialised by ONE memset
+            atomicMax(&st->kmax[k], mono64(h));
+            part[blockIdx.x * 3 + k] = s;
+        }
+    }
+};
+
 // AABB::from_point(p_t0, p_t1, r): per coordinate
 //   lo = min(nextafter_down(p0) - nextafter_up(r), nextafter_down(p1) - nextafter_up(r))
 //   hi = max(nextafter_up(p0)   + nextafter_up(r), nextafter_up(p1)   + nextafter_up(r))
 // (aabb.cu:19-37, aabb.cuh:55-63; ids aabb.cu:180-181)
-__global__ void vertex_boxes_k(const double* __restrict__ V, int nV, double r, sccd_aabb* __restrict__ out)
+__global__ void vertex_boxes_k(const double* __restrict__ V, int nV, double r, sccd_aabb* __restrict__ out,
+                               GridStats* __restrict__ st, double* __restrict__ part)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nV) return;
-    const double2* v = reinterpret_cast<const double2*>(V) + 3 * (size_t)i;
-    const double2 a = v[0], b = v[1], c2 = v[2];
-    const double p0[3] = { a.x, a.y, b.x }, p1[3] = { b.y, c2.x, c2.y };
+    StatsAcc acc;
     const double ru = nextafter_up(r);
-    double lo[3], hi[3];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nV; i += gridDim.x * blockDim.x) {
+        const double2* v = reinterpret_cast<const double2*>(V) + 3 * (size_t)i;
+        const double2 a = v[0], b = v[1], c2 = v[2];
+        const double p0[3] = { a.x, a.y, b.x }, p1[3] = { b.y, c2.x, c2.y };
+        double lo[3], hi[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const double l0 = nextafter_down(p0[k]) - ru, l1 = nextafter_down(p1[k]) - ru;
-        const double h0 = nextafter_up(p0[k]) + ru, h1 = nextafter_up(p1[k]) + ru;
-        lo[k] = (l1 < l0) ? l1 : l0;
-        hi[k] = (h0 < h1) ? h1 : h0;
+        for (int k = 0; k < 3; k++) {
+            const double l0 = nextafter_down(p0[k]) - ru, l1 = nextafter_down(p1[k]) - ru;
+            const double h0 = nextafter_up(p0[k]) + ru, h1 = nextafter_up(p1[k]) + ru;
+            lo[k] = (l1 < l0) ? l1 : l0;
+            hi[k] = (h0 < h1) ? h1 : h0;
+        }
+        store_box(out + i, lo, hi, i, -i - 1, -i - 1, i);
+        acc.add(lo, hi);
     }
-    store_box(out + i, lo, hi, i, -i - 1, -i - 1, i);
+    if (st) acc.finish(st, part);
 }
 
 struct BoxLoad {
@@ -97,111 +164,78 @@ __device__ __forceinline__ BoxLoad load_box_geom(const sccd_aabb* b)
 
 // AABB(a, b): component-wise min/max (aabb.cuh:18-29); ids aabb.cu:200-203
 __global__ void edge_boxes_k(const sccd_aabb* __restrict__ vb, const int2* __restrict__ E, int nE,
-                             sccd_aabb* __restrict__ out)
+                             sccd_aabb* __restrict__ out, GridStats* __restrict__ st, double* __restrict__ part)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nE) return;
-    const int2 e = E[i];
-    const BoxLoad a = load_box_geom(vb + e.x), b = load_box_geom(vb + e.y);
-    double lo[3], hi[3];
+    StatsAcc acc;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nE; i += gridDim.x * blockDim.x) {
+        const int2 e = E[i];
+        const BoxLoad a = load_box_geom(vb + e.x), b = load_box_geom(vb + e.y);
+        double lo[3], hi[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        lo[k] = (b.lo[k] < a.lo[k]) ? b.lo[k] : a.lo[k];
-        hi[k] = (a.hi[k] < b.hi[k]) ? b.hi[k] : a.hi[k];
+        for (int k = 0; k < 3; k++) {
+            lo[k] = (b.lo[k] < a.lo[k]) ? b.lo[k] : a.lo[k];
+            hi[k] = (a.hi[k] < b.hi[k]) ? b.hi[k] : a.hi[k];
+        }
+        store_box(out + i, lo, hi, e.x, e.y, -e.x - 1, i);
+        acc.add(lo, hi);
     }
-    store_box(out + i, lo, hi, e.x, e.y, -e.x - 1, i);
+    if (st) acc.finish(st, part);
 }
 
 // AABB(a, b, c) (aabb.cuh:31-42); ids aabb.cu:223-225
 __global__ void face_boxes_k(const sccd_aabb* __restrict__ vb, const int4* __restrict__ F, int nF,
-                             sccd_aabb* __restrict__ out)
+                             sccd_aabb* __restrict__ out, GridStats* __restrict__ st, double* __restrict__ part)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nF) return;
-    const int4 f = F[i];
-    const BoxLoad a = load_box_geom(vb + f.x), b = load_box_geom(vb + f.y), c = load_box_geom(vb + f.z);
-    double lo[3], hi[3];
+    StatsAcc acc;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nF; i += gridDim.x * blockDim.x) {
+        const int4 f = F[i];
+        const BoxLoad a = load_box_geom(vb + f.x), b = load_box_geom(vb + f.y), c = load_box_geom(vb + f.z);
+        double lo[3], hi[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        double l = (b.lo[k] < a.lo[k]) ? b.lo[k] : a.lo[k];
-        l = (c.lo[k] < l) ? c.lo[k] : l;
-        double h = (a.hi[k] < b.hi[k]) ? b.hi[k] : a.hi[k];
-        h = (h < c.hi[k]) ? c.hi[k] : h;
-        lo[k] = l;
-        hi[k] = h;
+        for (int k = 0; k < 3; k++) {
+            double l = (b.lo[k] < a.lo[k]) ? b.lo[k] : a.lo[k];
+            l = (c.lo[k] < l) ? c.lo[k] : l;
+            double h = (a.hi[k] < b.hi[k]) ? b.hi[k] : a.hi[k];
+            h = (h < c.hi[k]) ? c.hi[k] : h;
+            lo[k] = l;
+            hi[k] = h;
+        }
+        store_box(out + i, lo, hi, f.x, f.y, f.z, i);
+        acc.add(lo, hi);
     }
-    store_box(out + i, lo, hi, f.x, f.y, f.z, i);
+    if (st) acc.finish(st, part);
 }
 
 // ---- composite key: cell on the minor axes + quantised sort coordinate (grid.hpp) ------------
 
-// Global bounds and summed extents of a box list (run once per list of a build).  The bounds
-// are exact and order-independent (integer atomics on monotone images); the extent sums are
-// written per BLOCK and added up in a fixed order by grid_setup_k, so that every rank of a
-// multi-GPU run derives bit-identical grid parameters from the same boxes (a floating-point
-// atomicAdd would make the cell size depend on the order the blocks happen to finish in).
+// Bounds and summed extents of a box list that was NOT built here (uploaded boxes): same outputs
+// as the builders' fused statistics.
 __global__ void box_stats_k(const sccd_aabb* __restrict__ raw, int n, GridStats* __restrict__ st,
                             double* __restrict__ part /* [gridDim.x][3] */)
 {
-    double lo[3] = { TI_INF, TI_INF, TI_INF }, hi[3] = { -TI_INF, -TI_INF, -TI_INF }, se[3] = { 0, 0, 0 };
+    StatsAcc acc;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const BoxLoad b = load_box_geom(raw + i);
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            lo[k] = fmin(lo[k], b.lo[k]);
-            hi[k] = fmax(hi[k], b.hi[k]);
-            se[k] += b.hi[k] - b.lo[k];
-        }
+        acc.add(b.lo, b.hi);
     }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo[k] = fmin(lo[k], __shfl_xor(lo[k], o, 64));
-            hi[k] = fmax(hi[k], __shfl_xor(hi[k], o, 64));
-            se[k] += __shfl_xor(se[k], o, 64);
-        }
-    }
-    // one set of global atomics per BLOCK: nine contended words shared by the whole grid
-    __shared__ double red[TPB / 64][9];
-    const int w = threadIdx.x >> 6;
-    if (lane_id() == 0) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            red[w][k] = lo[k];
-            red[w][3 + k] = hi[k];
-            red[w][6 + k] = se[k];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        const int k = threadIdx.x;
-        double l = red[0][k], h = red[0][3 + k], s = red[0][6 + k];
-#pragma unroll
-        for (int j = 1; j < TPB / 64; j++) {
-            l = fmin(l, red[j][k]);
-            h = fmax(h, red[j][3 + k]);
-            s += red[j][6 + k];
-        }
-        atomicMax(&st->kmin[k], ~mono64(l)); // stored inverted: the block is zero-initialised by ONE memset
-        atomicMax(&st->kmax[k], mono64(h));
-        part[blockIdx.x * 3 + k] = s;
-    }
+    acc.finish(st, part);
 }
 
 // cell size = cell_factor x mean box extent on that axis; at most 2^10 cells in total
-__global__ void grid_setup_k(const GridStats* __restrict__ st, const double* __restrict__ part, int n_part, int n_total,
-                             int axis, double cell_factor, int shrink, GridParams* __restrict__ g)
+__global__ void grid_setup_k(const GridStats* __restrict__ st_a, const double* __restrict__ part_a, int n_part_a,
+                             const GridStats* __restrict__ st_b, const double* __restrict__ part_b, int n_part_b,
+                             int n_total, int axis, double cell_factor, int shrink, GridParams* __restrict__ g)
 {
-    // summed extents: lane l adds the block partials l, l + 64, ... in that order, then a fixed
-    // shuffle tree -- the same bits on every run and every rank (one wave)
+    // summed extents: lane l adds the block partials l, l + 64, ... of list A, then of list B, in
+    // that order, then a fixed shuffle tree -- the same bits on every run and every rank (one wave)
     double sumext[3];
     {
         const int lane = lane_id();
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             double s = 0.0;
-            for (int j = lane; j < n_part; j += 64) s += part[j * 3 + k];
+            for (int j = lane; j < n_part_a; j += 64) s += part_a[j * 3 + k];
+            for (int j = lane; j < n_part_b; j += 64) s += part_b[j * 3 + k];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
             sumext[k] = s;
@@ -211,8 +245,13 @@ __global__ void grid_setup_k(const GridStats* __restrict__ st, const double* __r
     const int aa = (axis == 0) ? 1 : 0, ab = (axis == 2) ? 1 : 2;
     double lo[3], hi[3];
     for (int k = 0; k < 3; k++) {
-        lo[k] = mono64_inv(~st->kmin[k]);
-        hi[k] = mono64_inv(st->kmax[k]);
+        unsigned long long kmin_inv = st_a->kmin[k], kmax = st_a->kmax[k];
+        if (st_b) {
+            kmin_inv = max(kmin_inv, st_b->kmin[k]);
+            kmax = max(kmax, st_b->kmax[k]);
+        }
+        lo[k] = mono64_inv(~kmin_inv);
+        hi[k] = mono64_inv(kmax);
     }
     int S[2];
     const int ax2[2] = { aa, ab };
@@ -432,23 +471,30 @@ void launch_pack_faces(sccd_ctx* c, const int32_t* dF, int nF, int4* out)
     hipLaunchKernelGGL(pack_faces_k, dim3(grid_for(nF)), dim3(TPB), 0, c->stream, dF, nF, out);
     SCCD_HIP(hipGetLastError());
 }
-void launch_vertex_boxes(sccd_ctx* c, const double* dV, int nV, double inflation, sccd_aabb* out)
+// builders: grid-stride over at most SCCD_STATS_BLOCKS blocks (one extent partial per block)
+int launch_vertex_boxes(sccd_ctx* c, const double* dV, int nV, double inflation, sccd_aabb* out, GridStats* st, double* part)
 {
-    if (nV == 0) return;
-    hipLaunchKernelGGL(vertex_boxes_k, dim3(grid_for(nV)), dim3(TPB), 0, c->stream, dV, nV, inflation, out);
+    if (nV == 0) return 0;
+    const int grid = std::min(grid_for(nV), SCCD_STATS_BLOCKS);
+    hipLaunchKernelGGL(vertex_boxes_k, dim3(grid), dim3(TPB), 0, c->stream, dV, nV, inflation, out, st, part);
     SCCD_HIP(hipGetLastError());
+    return grid;
 }
-void launch_edge_boxes(sccd_ctx* c, const sccd_aabb* vb, const int2* E, int nE, sccd_aabb* out)
+int launch_edge_boxes(sccd_ctx* c, const sccd_aabb* vb, const int2* E, int nE, sccd_aabb* out, GridStats* st, double* part)
 {
-    if (nE == 0) return;
-    hipLaunchKernelGGL(edge_boxes_k, dim3(grid_for(nE)), dim3(TPB), 0, c->stream, vb, E, nE, out);
+    if (nE == 0) return 0;
+    const int grid = std::min(grid_for(nE), SCCD_STATS_BLOCKS);
+    hipLaunchKernelGGL(edge_boxes_k, dim3(grid), dim3(TPB), 0, c->stream, vb, E, nE, out, st, part);
     SCCD_HIP(hipGetLastError());
+    return grid;
 }
-void launch_face_boxes(sccd_ctx* c, const sccd_aabb* vb, const int4* F, int nF, sccd_aabb* out)
+int launch_face_boxes(sccd_ctx* c, const sccd_aabb* vb, const int4* F, int nF, sccd_aabb* out, GridStats* st, double* part)
 {
-    if (nF == 0) return;
-    hipLaunchKernelGGL(face_boxes_k, dim3(grid_for(nF)), dim3(TPB), 0, c->stream, vb, F, nF, out);
+    if (nF == 0) return 0;
+    const int grid = std::min(grid_for(nF), SCCD_STATS_BLOCKS);
+    hipLaunchKernelGGL(face_boxes_k, dim3(grid), dim3(TPB), 0, c->stream, vb, F, nF, out, st, part);
     SCCD_HIP(hipGetLastError());
+    return grid;
 }
 // returns the number of block partials written to `part` (at most SCCD_STATS_BLOCKS)
 int launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st, double* part)
@@ -459,11 +505,12 @@ int launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st, do
     SCCD_HIP(hipGetLastError());
     return grid;
 }
-void launch_grid_setup(sccd_ctx* c, const GridStats* st, const double* part, int n_part, int n_total, int axis,
-                       double cell_factor, int shrink, GridParams* g)
+void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a, int n_part_a, const GridStats* st_b,
+                       const double* part_b, int n_part_b, int n_total, int axis, double cell_factor, int shrink,
+                       GridParams* g)
 {
-    hipLaunchKernelGGL(grid_setup_k, dim3(1), dim3(64), 0, c->stream, st, part, n_part, n_total, axis, cell_factor,
-                       shrink, g);
+    hipLaunchKernelGGL(grid_setup_k, dim3(1), dim3(64), 0, c->stream, st_a, part_a, n_part_a, st_b, part_b, n_part_b,
+                       n_total, axis, cell_factor, shrink, g);
     SCCD_HIP(hipGetLastError());
 }
 void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, uint32_t* hist)

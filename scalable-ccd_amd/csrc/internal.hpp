@@ -1,6 +1,7 @@
 // internal.hpp -- object layouts in HBM and the launcher functions each .hip file exports.
 #pragma once
 #include "common.hpp"
+#include "grid.hpp"
 
 // ------------------------------------------------------------------------------------------
 // HBM layouts (DESIGN.md "Data layout in HBM")
@@ -30,7 +31,15 @@ struct sccd_boxes {
     sccd_ctx* ctx = nullptr;
     int n = 0;
     DevBuf raw; // sccd_aabb[n]
+    // bounds + extent partials of the list ({GridStats, pad to 128 B, double[n_part][3]}): written by the
+    // box builders themselves (fused) or, for uploaded boxes, by box_stats_k on first use
+    mutable DevBuf stats;
+    mutable int n_part = 0;
+    mutable bool have_stats = false;
+    GridStats* stats_head() const { return stats.as<GridStats>(); }
+    double* stats_part() const { return reinterpret_cast<double*>(stats.as<char>() + 128); }
 };
+constexpr size_t SCCD_STATS_BYTES = 128 + sizeof(double) * 3 * SCCD_STATS_BLOCKS;
 
 // one sweep list: an entry per (box, overlapped cell), sorted by the composite key of grid.hpp
 struct SortedList {
@@ -63,14 +72,20 @@ struct sccd_broad_phase {
 void launch_pack_vertices(sccd_ctx* c, const double* dV0, const double* dV1, int nV, double* dV);
 void launch_pack_edges(sccd_ctx* c, const int32_t* dE, int nE, int2* out);
 void launch_pack_faces(sccd_ctx* c, const int32_t* dF, int nF, int4* out);
-void launch_vertex_boxes(sccd_ctx* c, const double* dV, int nV, double inflation, sccd_aabb* out);
-void launch_edge_boxes(sccd_ctx* c, const sccd_aabb* vb, const int2* E, int nE, sccd_aabb* out);
-void launch_face_boxes(sccd_ctx* c, const sccd_aabb* vb, const int4* F, int nF, sccd_aabb* out);
+// st / part may be null (no statistics); otherwise *st must be zeroed and the return value is the
+// number of block partials written
+int launch_vertex_boxes(sccd_ctx* c, const double* dV, int nV, double inflation, sccd_aabb* out, GridStats* st = nullptr,
+                        double* part = nullptr);
+int launch_edge_boxes(sccd_ctx* c, const sccd_aabb* vb, const int2* E, int nE, sccd_aabb* out, GridStats* st = nullptr,
+                      double* part = nullptr);
+int launch_face_boxes(sccd_ctx* c, const sccd_aabb* vb, const int4* F, int nF, sccd_aabb* out, GridStats* st = nullptr,
+                      double* part = nullptr);
 struct GridStats;
 struct GridParams;
 int launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st, double* part);
-void launch_grid_setup(sccd_ctx* c, const GridStats* st, const double* part, int n_part, int n_total, int axis,
-                       double cell_factor, int shrink, GridParams* g);
+void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a, int n_part_a, const GridStats* st_b,
+                       const double* part_b, int n_part_b, int n_total, int axis, double cell_factor, int shrink,
+                       GridParams* g);
 void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, uint32_t* hist);
 void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
                        uint32_t* counts);
