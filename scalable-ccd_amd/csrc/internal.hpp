@@ -153,6 +153,7 @@ struct NarrowCounters {
     unsigned long long max_wave_steps, waves_run; // longest wave (the kernel's critical path), waves that got work
     unsigned long long pops_reg, pops_mem; // pops served by the register top / by the HBM stack
     unsigned long long wave_hist[16];      // waves by number of check steps, buckets of 16 (last: >= 240)
+    unsigned long long xcd_steps[8], xcd_waves[8]; // check steps and waves per XCD (HW_REG_XCC_ID)
 };
 static_assert(sizeof(NarrowCounters) <= 1024, "NarrowCounters must fit its slot of the scalars block");
 // runs the narrow phase on the stream; *toi in/out lives in d_cnt->toi_bits

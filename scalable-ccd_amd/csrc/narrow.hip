@@ -227,6 +227,8 @@ void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
     if (std::getenv("SCCD_NP_DIAG") && h.wave_steps) {
         std::fprintf(stderr, "[sccd np] waves by steps (x16):");
         for (int k = 0; k < 16; k++) std::fprintf(stderr, " %llu", h.wave_hist[k]);
+        std::fprintf(stderr, " | mean steps per XCD:");
+        for (int k = 0; k < 8; k++) std::fprintf(stderr, " %.0f(%llu)", (double)h.xcd_steps[k] / (double)std::max<unsigned long long>(1, h.xcd_waves[k]), h.xcd_waves[k]);
         std::fprintf(stderr, "\n");
     }
     if (std::getenv("SCCD_NP_DIAG") && h.stamp[4])
