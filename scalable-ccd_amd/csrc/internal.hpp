@@ -156,6 +156,7 @@ struct NarrowCounters {
     unsigned long long xcd_steps[8], xcd_waves[8]; // check steps and waves per XCD (HW_REG_XCC_ID)
 };
 static_assert(sizeof(NarrowCounters) <= 1024, "NarrowCounters must fit its slot of the scalars block");
+constexpr int SCCD_QUEUE_MIN_MAX_ITER = 4096; // smaller check limits are served by the level-synchronous kernel
 // runs the narrow phase on the stream; *toi in/out lives in d_cnt->toi_bits
 void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
                       double* d_per_query_toi);

@@ -206,7 +206,11 @@ void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
     }
     if (run && n > 0) {
         ProfScope ps(c, p.is_vf ? SCCD_PROF_NARROW_VF : SCCD_PROF_NARROW_EE);
-        const bool level_sync = c->narrow_algo == 1 || d_per_query_toi != nullptr || p.max_iter >= 0;
+        // A check limit is exact only in the reference's level order.  Limits that no query comes near
+        // (the IPC Toolkit passes 1e7) run on the work-queue kernel, which counts per query and hands the
+        // whole call to the level-synchronous kernel if any query does get there; small limits go there directly.
+        const bool level_sync = c->narrow_algo == 1 || d_per_query_toi != nullptr
+            || (p.max_iter >= 0 && p.max_iter < SCCD_QUEUE_MIN_MAX_ITER);
         if (level_sync) {
             if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi);
             else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi);

@@ -413,6 +413,27 @@ def test_ipc_ccd_strategy(sccd, ctx, orc):
     assert 0.0 <= t <= 1e-5
 
 
+def test_check_limit_that_no_query_reaches_runs_on_the_fast_kernel(sccd, ctx, orc):
+    """max_iter >= 0 (the IPC Toolkit passes 1e7): a limit no query comes near changes nothing, and
+    is served by the work-queue kernel (same check count as max_iter = -1, far fewer than the
+    level-order scheme needs); a small limit follows the reference's level order (oracle)."""
+    V0, V1, E, F = _scene("cloth_ball_10k")
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    t_free, st_free = sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True, want_stats=True)
+    for limit in (4096, 10_000_000):
+        t, st = sccd.ccd_mesh(mesh, 0.0, limit, 1e-6, True, want_stats=True)
+        assert t == t_free
+        # depth-first with pruning: the count depends a little on timing, never by a factor
+        assert st["n_vf_checks"] + st["n_ee_checks"] < 1.5 * (st_free["n_vf_checks"] + st_free["n_ee_checks"])
+    t_ipc = sccd.ipc_ccd_strategy(V0, V1, E, F, 0.0, 10_000_000, 1e-6, ctx=ctx)
+    assert t_ipc == sccd.ipc_ccd_strategy(V0, V1, E, F, 0.0, -1, 1e-6, ctx=ctx)
+    # a limit below SCCD_QUEUE_MIN_MAX_ITER: level-synchronous kernel, one legal order of the reference's scheme
+    want, _, _ = orc.ccd(V0, V1, E, F, 0.0, 3, 1e-6, True)
+    got = sccd.ccd_mesh(mesh, 0.0, 3, 1e-6, True)
+    assert got >= t_free  # truncation can only lose collisions
+    assert got == want
+
+
 def test_sort_is_a_stable_permutation(sccd, ctx):
     import torch
 
