@@ -107,7 +107,7 @@ enum SweepEmit { EMIT_ONE_LIST = 0, EMIT_ROWS_A = 1, EMIT_ROWS_B = 2 };
 struct SweepCounters { // lives in device memory (ctx->scalars)
     unsigned long long n_pairs;    // pairs found (may exceed capacity: overflow -> rerun)
     unsigned long long candidates; // (host side: sum of cand_parts)
-    unsigned int tile_ticket;      // persistent-wave tile counter
+    unsigned int tile_ticket;      // (unused: tiles are dealt statically)
     unsigned int pad;
     unsigned long long cand_parts[32]; // sum of (end-start) over the rows, spread to avoid one hot word
 };

@@ -6,12 +6,12 @@
 //
 // Two algorithms, same results for max_iter < 0 (the final TOI is a min over accepted domains
 // and pruning by the running TOI never changes that min -- SURVEY Appendix A.20):
-//   algo 0  np_queue_k: ONE persistent launch.  Every wave owns a work pool of (query slot,
-//           [t]x[u]x[v]) domains in LDS, pops 64 domains per step (one per lane, earliest
-//           sub-intervals on top so the running TOI drops early), and ingests 64 fresh queries
-//           (gather + per-query constants, all lanes busy) whenever the pool runs low.
-//           Divergent bisection depth is absorbed by the pool: lanes never wait for the
-//           deepest query of a batch.  No CCDData array in HBM, no per-level host round trip.
+//   algo 0  np_queue_k (narrow_queue.inc): ONE persistent launch.  Every lane walks its query's
+//           [t]x[u]x[v] tree depth-first (earlier half first, so the running TOI drops early) with
+//           an on-chip stack; idle lanes pick fresh queries from a per-wave LDS staging area that
+//           LDS-direct loads refill in the background.  Divergent bisection depth is absorbed per
+//           lane: nobody waits for the deepest query of a batch.  No CCDData array in HBM, no
+//           per-level host round trip.
 //   algo 1  np_level_k: level-synchronous BFS with a host loop, the reference's scheme
 //           (root_finder.cu:431-447).  Kept as the in-library cross-check.
 #include "internal.hpp"
