@@ -316,6 +316,78 @@ def test_toi_matches_oracle(sccd, ctx, orc, name, arith, algo):
     assert got_vf == want_vf and got_ee == want_ee  # bit-equal under the same arithmetic contract
 
 
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (1e-6, 0.0), (1e4, -3.7e6), (3.0, 1.0e9)])
+def test_pair_set_under_translation_and_scale(sccd, ctx, orc, scale, offset):
+    """The composite key quantises coordinates relative to the scene bounds; tiny scenes, huge
+    offsets (where neighbouring doubles are 2e-7 apart) and negative coordinates must not change
+    the pair set.  The oracle runs on the SAME transformed boxes."""
+    b = scenes.random_boxes(30_000, seed=13, max_extent=0.04)
+    b["min"] = b["min"] * scale + offset
+    b["max"] = b["max"] * scale + offset
+    assert (b["min"] <= b["max"]).all()
+    want, _, _ = orc.sort_and_sweep(b, nthreads=8)
+    assert len(want) > 1000
+    bp = sccd.BroadPhase(ctx)
+    bp.build(sccd.DeviceAABBs(b, ctx))
+    assert np.array_equal(_sorted(bp.detect_overlaps()), want)
+    # two lists built from the same boxes, every second box flipped onto one plane (zero extent)
+    a2, b2 = b[::2].copy(), b[1::2].copy()
+    a2["max"][:, 2] = a2["min"][:, 2]
+    b2["vertex_ids"] += 10_000_000
+    want, _, _ = orc.sort_and_sweep(a2, b2, nthreads=8)
+    bp.build(sccd.DeviceAABBs(a2, ctx), sccd.DeviceAABBs(b2, ctx))
+    assert np.array_equal(_sorted(bp.detect_overlaps()), want)
+
+
+def test_degenerate_box_lists(sccd, ctx, orc):
+    """Point boxes, thousands of identical boxes, one box covering everything."""
+    n = 3000
+    b = np.zeros(n, sccd.AABB_DTYPE)
+    rng = np.random.default_rng(4)
+    p = rng.random((n, 3))
+    b["min"] = p
+    b["max"] = p  # zero extent on every axis: the mean extent the grid is sized from is 0
+    b["vertex_ids"] = np.arange(3 * n).reshape(n, 3)
+    b["element_id"] = np.arange(n)
+    b["min"][:500] = 0.5
+    b["max"][:500] = 0.5  # 500 coincident points: 124,750 pairs from one spot
+    b["min"][-1] = -1.0
+    b["max"][-1] = 2.0  # and one box that contains all the others
+    want, _, _ = orc.sort_and_sweep(b, nthreads=8)
+    assert len(want) == 500 * 499 // 2 + (n - 1)
+    bp = sccd.BroadPhase(ctx)
+    bp.build(sccd.DeviceAABBs(b, ctx))
+    assert np.array_equal(_sorted(bp.detect_overlaps()), want)
+
+
+def test_resting_and_grazing_contacts(sccd, ctx, orc):
+    """Queries that start in contact (TOI 0 with allow_zero_toi, > 0 without), parallel sliding,
+    and a mesh that does not move at all."""
+    V0, F = scenes.cloth_grid(6)  # (coplanar sliding is Tight-Inclusion's worst case: keep the oracle's work small)
+    V0 = V0.copy()
+    E = scenes.edges_from_faces(F)
+    # a second, identical sheet lying exactly on the first one, sliding sideways
+    Va0 = np.concatenate([V0, V0 + [0.013, 0.007, 0.0]])
+    Va1 = np.concatenate([V0, V0 + [0.113, 0.007, 0.0]])
+    Fa = np.concatenate([F, F + len(V0)]).astype(np.int32)
+    Ea = np.concatenate([E, E + len(V0)]).astype(np.int32)
+    for allow_zero in (True, False):
+        want, _, _ = orc.ccd(Va0, Va1, Ea, Fa, 0.0, -1, 1e-6, allow_zero, nthreads=8)
+        got = sccd.ccd(Va0, Va1, Ea, Fa, 0.0, -1, 1e-6, allow_zero, ctx=ctx)
+        assert got == want
+        if allow_zero:
+            assert got == 0.0
+    # nothing moves: every query is static (infinite time tolerance), still the oracle's answer
+    want, _, _ = orc.ccd(Va0, Va0, Ea, Fa, 0.0, -1, 1e-6, True, nthreads=8)
+    assert sccd.ccd(Va0, Va0, Ea, Fa, 0.0, -1, 1e-6, True, ctx=ctx) == want
+    # sheets 1e-3 apart moving in parallel: minimum separation decides
+    Vb0 = np.concatenate([V0, V0 + [0.013, 0.007, 1e-3]])
+    Vb1 = np.concatenate([V0 + [0.2, 0, 0], V0 + [0.213, 0.007, 1e-3]])
+    for ms in (0.0, 5e-4, 2e-3):
+        want, _, _ = orc.ccd(Vb0, Vb1, Ea, Fa, ms, -1, 1e-6, True, nthreads=8)
+        assert sccd.ccd(Vb0, Vb1, Ea, Fa, ms, -1, 1e-6, True, ctx=ctx) == want
+
+
 @pytest.mark.parametrize("ms", [0.0, 1e-3])
 @pytest.mark.parametrize("allow_zero", [True, False])
 def test_narrow_phase_parameters(sccd, ctx, orc, ms, allow_zero):
