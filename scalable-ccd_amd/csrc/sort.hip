@@ -408,11 +408,13 @@ bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
         SCCD_HIP(hipGetLastError());
         return (passes & 1) != 0;
     }
-    // onesweep: [4 tickets (padded to 64 B)] [status passes x tiles x 256] [bases 4x256] [partial hist blocks x 1024]
+    // onesweep: [4 tickets, one per 128-B line] [status passes x tiles x 256] [bases 4x256] [partial hist blocks x 1024]
+    // (Per-segment tickets + bases were tried: the bases of a segment are only known for the FIRST pass,
+    // later passes see permuted keys; and ticket streams without a global order can deadlock the look-back.)
     const int hist_blocks = std::min(num_tiles, c->num_cus);
     const int dbg = std::getenv("SCCD_SORT_DBG") ? std::atoi(std::getenv("SCCD_SORT_DBG")) : 0; // timing ablations only
     const size_t status_bytes = (size_t)passes * num_tiles * 256 * sizeof(uint32_t);
-    const size_t off_status = 64, off_bases = off_status + status_bytes, off_partial = off_bases + 4096;
+    const size_t off_status = 512, off_bases = off_status + status_bytes, off_partial = off_bases + 4096;
     c->sort_hist.ensure(off_partial + (size_t)hist_blocks * 4096);
     char* base = c->sort_hist.as<char>();
     uint32_t* tickets = reinterpret_cast<uint32_t*>(base);
@@ -421,13 +423,13 @@ bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
     uint32_t* status = reinterpret_cast<uint32_t*>(base + off_status);
     // every polled word (tickets and status, contiguous) is zeroed by os_hist_k before the passes
     hipLaunchKernelGGL(os_hist_k, dim3(hist_blocks), dim3(RS_THREADS), 0, c->stream, k_in, (long long)n, num_tiles,
-                       partial, reinterpret_cast<uint4*>(base), (long long)((64 + status_bytes) / 16));
+                       partial, reinterpret_cast<uint4*>(base), (long long)((512 + status_bytes) / 16));
     hipLaunchKernelGGL(os_bases_k, dim3(4), dim3(1024), 0, c->stream, partial, hist_blocks, bases);
     for (int pass = 0; pass < passes; pass++) {
         static const int pass_blocks = std::getenv("SCCD_SORT_BLOCKS") ? std::atoi(std::getenv("SCCD_SORT_BLOCKS")) : 3;
         hipLaunchKernelGGL(os_pass_k, dim3(std::min(num_tiles, c->num_cus * pass_blocks)), dim3(RS_THREADS), 0, c->stream, k_in,
                            v_in, k_out, v_out, (long long)n, 8 * pass, num_tiles, bases + 256 * pass,
-                           status + (size_t)pass * num_tiles * 256, tickets + pass, dbg);
+                           status + (size_t)pass * num_tiles * 256, tickets + pass * 32, dbg);
         std::swap(k_in, k_out);
         std::swap(v_in, v_out);
     }
