@@ -506,6 +506,8 @@ extern "C" int sccd_shard_bounds(const uint32_t* weights, int n, int parts, int*
     return SCCD_OK;
 }
 
+constexpr int SHARD_HIST_STRIDE = 8; // the shard histogram looks at every 8th box
+
 // One list: count -> scan | (host learns the totals of BOTH lists in one round trip) | fill ->
 // sort -> gather.
 static void list_count(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, int cell_lo, int cell_hi, SortedList* L,
@@ -525,21 +527,25 @@ static void list_count(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, i
         exclusive_scan_u32(c, counts, counts, n, d_total);
     }
 }
+// `filled`: key / idx already hold the entries (the one-pass append of the sharded build)
 static void list_finish(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, int cell_lo, int cell_hi, uint32_t total,
-                        int key_bits, SortedList* L)
+                        int key_bits, SortedList* L, bool filled = false)
 {
     const int n = b->n;
+    L->m = 0;
     if (n == 0 || total == 0) return; // (no box of this list touches the rank's cells)
     SCCD_REQUIRE(total < (1u << 31), "broad phase: too many cell entries");
     const size_t m = total, pad = 64; // the sweep streams whole 32-column blocks
     L->m = (int)m;
-    L->key.ensure(sizeof(uint32_t) * (m + pad));
+    if (!filled) {
+        L->key.ensure(sizeof(uint32_t) * (m + pad));
+        L->idx.ensure(sizeof(uint32_t) * (m + pad));
+    }
     L->kmax.ensure(sizeof(uint32_t) * (m + pad));
     L->filt.ensure(sizeof(float4) * (m + pad));
     L->box.ensure(sizeof(sccd_aabb) * (m + 8));
-    L->idx.ensure(sizeof(uint32_t) * (m + pad));
     L->lowcell.ensure(sizeof(uint32_t) * (m + pad));
-    {
+    if (!filled) {
         ProfScope ps(c, SCCD_PROF_BOXES);
         launch_cell_fill(c, b->raw.as<sccd_aabb>(), n, gp, cell_lo, cell_hi, L->offsets.as<uint32_t>(),
                          L->key.as<uint32_t>(), L->idx.as<uint32_t>());
@@ -596,6 +602,7 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     bp->cell_lo = 0;
     bp->cell_hi = 1 << 30;
     bp->row_shard = false;
+    unsigned long long window_est = 0; // entries of this rank's cell window, estimated from the sampled histogram
     for (int shrink = 0;; shrink++) {
         launch_grid_setup(c, A->stats_head(), A->stats_part(), A->n_part, B ? B->stats_head() : nullptr,
                           B ? B->stats_part() : nullptr, B ? B->n_part : 0, n_total, axis, cf, shrink, gp);
@@ -606,17 +613,17 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
         if (c->shard_count > 1) {
             uint32_t* d_hist = bp->grid.as<uint32_t>() + 1024; // bytes [4096, 8192) of the grid block
             SCCD_HIP(hipMemsetAsync(d_hist, 0, 4096, c->stream));
-            launch_cell_hist(c, A->raw.as<sccd_aabb>(), A->n, gp, d_hist);
-            if (B) launch_cell_hist(c, B->raw.as<sccd_aabb>(), B->n, gp, d_hist);
+            launch_cell_hist(c, A->raw.as<sccd_aabb>(), A->n, gp, SHARD_HIST_STRIDE, d_hist);
+            if (B) launch_cell_hist(c, B->raw.as<sccd_aabb>(), B->n, gp, SHARD_HIST_STRIDE, d_hist);
             uint32_t hist[1024];
             GridParams hgp;
             ReadBack rb(c);
             rb.add(hist, d_hist, sizeof hist);
             rb.add(&hgp, gp, sizeof hgp);
             rb.sync();
-            unsigned long long total = 0;
-            for (int k = 0; k < hgp.n_cells; k++) total += hist[k];
-            // same replication budget as build_sorted_list, decided on the whole grid so that
+            unsigned long long total = 0; // (estimate: the histogram counts every SHARD_HIST_STRIDE-th box)
+            for (int k = 0; k < hgp.n_cells; k++) total += (unsigned long long)hist[k] * SHARD_HIST_STRIDE;
+            // same replication budget as the single-GPU build, decided on the whole grid so that
             // every rank coarsens alike
             if (can_shrink && total > (unsigned long long)std::max<int64_t>(3 * (int64_t)n_total, (int64_t)n_total + 4096))
                 continue;
@@ -626,11 +633,54 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                 bp->cell_lo = bounds[c->shard_rank];
                 bp->cell_hi = bounds[c->shard_rank + 1];
                 bp->row_shard = false;
+                window_est = 0;
+                for (int k = bp->cell_lo; k < bp->cell_hi; k++) window_est += (unsigned long long)hist[k] * SHARD_HIST_STRIDE;
             } else {
                 bp->row_shard = true; // (almost) one cell: every rank sorts everything and takes a slice of the rows
             }
         }
         uint32_t* d_total = reinterpret_cast<uint32_t*>(c->scalars.as<char>() + 1536);
+        const bool windowed_build = c->shard_count > 1 && !bp->row_shard;
+        if (windowed_build) {
+            // One pass (count + fill by atomic append) over every box of the list instead of
+            // count, scan and fill: in a sharded run these replicated passes are what limits the
+            // scaling.  Room for the entries comes from the histogram estimate; an overflow is
+            // counted, never written, and the pass repeated with exactly enough room.
+            unsigned long long cap = window_est + window_est / 4 + 65536;
+            uint32_t total[2] = { 0, 0 };
+            GridParams hgp;
+            for (;;) {
+                SCCD_REQUIRE(cap < (1ull << 31), "broad phase: too many cell entries");
+                const size_t pad = 64;
+                SCCD_HIP(hipMemsetAsync(d_total, 0, 2 * sizeof(uint32_t), c->stream));
+                {
+                    ProfScope ps(c, SCCD_PROF_BOXES);
+                    bp->la.key.ensure(sizeof(uint32_t) * ((size_t)cap + pad));
+                    bp->la.idx.ensure(sizeof(uint32_t) * ((size_t)cap + pad));
+                    launch_cell_fill_append(c, A->raw.as<sccd_aabb>(), A->n, gp, bp->cell_lo, bp->cell_hi, d_total,
+                                            (uint32_t)cap, bp->la.key.as<uint32_t>(), bp->la.idx.as<uint32_t>());
+                    if (B) {
+                        bp->lb.key.ensure(sizeof(uint32_t) * ((size_t)cap + pad));
+                        bp->lb.idx.ensure(sizeof(uint32_t) * ((size_t)cap + pad));
+                        launch_cell_fill_append(c, B->raw.as<sccd_aabb>(), B->n, gp, bp->cell_lo, bp->cell_hi, d_total + 1,
+                                                (uint32_t)cap, bp->lb.key.as<uint32_t>(), bp->lb.idx.as<uint32_t>());
+                    }
+                }
+                {
+                    ProfScope ps(c, SCCD_PROF_SORT);
+                    ReadBack rb(c);
+                    rb.add(total, d_total, sizeof(uint32_t) * 2);
+                    rb.add(&hgp, gp, sizeof hgp);
+                    rb.sync();
+                }
+                const unsigned long long need = std::max<unsigned long long>(total[0], B ? total[1] : 0);
+                if (need <= cap) break;
+                cap = need + 1024; // estimate too low (the sample missed a crowded cell): once more, with room
+            }
+            list_finish(c, A, gp, bp->cell_lo, bp->cell_hi, total[0], hgp.key_bits, &bp->la, true);
+            if (B) list_finish(c, B, gp, bp->cell_lo, bp->cell_hi, total[1], hgp.key_bits, &bp->lb, true);
+            break;
+        }
         list_count(c, A, gp, bp->cell_lo, bp->cell_hi, &bp->la, d_total);
         if (B) list_count(c, B, gp, bp->cell_lo, bp->cell_hi, &bp->lb, d_total + 1);
         uint32_t total[2] = { 0, 0 };

@@ -367,15 +367,18 @@ __global__ void cell_fill_k(const sccd_aabb* __restrict__ raw, int n, const Grid
         }
 }
 
-// entries per cell (multi-GPU: the ranks take contiguous cell windows of equal entry counts)
-__global__ void cell_hist_k(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp,
+// Entries per cell, from every `stride`-th box (multi-GPU: the ranks take contiguous cell windows
+// of about equal entry counts; ANY partition of the cells is correct, so a sample is enough --
+// it only has to be the same sample on every rank).
+__global__ void cell_hist_k(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp, int stride,
                             uint32_t* __restrict__ hist /*[1024]*/)
 {
     __shared__ uint32_t h[1024];
     for (int k = threadIdx.x; k < 1024; k += blockDim.x) h[k] = 0;
     __syncthreads();
     const GridParams g = *gp;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (long long i = (long long)(blockIdx.x * blockDim.x + threadIdx.x) * stride; i < n;
+         i += (long long)gridDim.x * blockDim.x * stride) {
         const CellSpan s = cell_span(g, load_box_geom(raw + i));
         for (int ca = s.a0; ca <= s.a1; ca++)
             for (int cb = s.b0; cb <= s.b1; cb++) atomicAdd(&h[ca * g.Sb + cb], 1u);
@@ -383,6 +386,58 @@ __global__ void cell_hist_k(const sccd_aabb* __restrict__ raw, int n, const Grid
     __syncthreads();
     for (int k = threadIdx.x; k < 1024; k += blockDim.x)
         if (h[k]) atomicAdd(&hist[k], h[k]);
+}
+
+// Count + fill in ONE pass for a cell window (multi-GPU): a block of 1024 threads adds up the
+// entries of its boxes, reserves room with ONE atomic (the cursor is a single hot word: ~90
+// atomics/us chip-wide, so one per wave made the pass atomic-bound) and writes them.  The order of the entries depends on the
+// order the waves arrive in -- the radix sort that follows is stable, so only the order of EQUAL
+// keys (and with it the order, not the set, of the emitted pairs) varies.  Entries beyond
+// `capacity` are counted but not written (the host grows the buffers and runs the pass again).
+__global__ void cell_fill_append_k(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp,
+                                   int cell_lo, int cell_hi, uint32_t* __restrict__ cursor, uint32_t capacity,
+                                   uint32_t* __restrict__ key, uint32_t* __restrict__ idx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const GridParams g = *gp;
+    CellSpan s = { 0, -1, 0, -1 };
+    unsigned q = 0;
+    uint32_t cnt = 0;
+    if (i < n) {
+        const BoxLoad b = load_box_geom(raw + i);
+        s = cell_span(g, b);
+        q = grid_qx(g, b.lo[g.axis]);
+        for (int ca = s.a0; ca <= s.a1; ca++) {
+            const int c0 = max(ca * g.Sb + s.b0, cell_lo), c1 = min(ca * g.Sb + s.b1, cell_hi - 1);
+            cnt += c1 >= c0 ? (uint32_t)(c1 - c0 + 1) : 0u;
+        }
+    }
+    const uint32_t incl = (uint32_t)wave_incl_scan((int)cnt);
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+    __shared__ uint32_t wave_tot[16], wave_base[16];
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 63) wave_tot[w] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); k++) {
+            wave_base[k] = sum;
+            sum += wave_tot[k];
+        }
+        const uint32_t b0 = sum ? atomicAdd(cursor, sum) : 0u;
+        for (int k = 0; k < (int)(blockDim.x >> 6); k++) wave_base[k] += b0;
+    }
+    __syncthreads();
+    uint32_t at = wave_base[w] + incl - cnt;
+    if (cnt == 0 || (unsigned long long)at + cnt > capacity) return;
+    for (int ca = s.a0; ca <= s.a1; ca++)
+        for (int cb = s.b0; cb <= s.b1; cb++) {
+            const int cell = ca * g.Sb + cb;
+            if (cell < cell_lo || cell >= cell_hi) continue;
+            key[at] = (uint32_t)(((unsigned long long)cell << g.xb) | q); // xb may be 32
+            idx[at] = (uint32_t)i;
+            ++at;
+        }
 }
 
 // payload movement of thrust::sort_by_key (aabb.cu:107-109) as ONE gather after the index sort,
@@ -513,11 +568,20 @@ void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a,
                        n_total, axis, cell_factor, shrink, g);
     SCCD_HIP(hipGetLastError());
 }
-void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, uint32_t* hist)
+void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int stride, uint32_t* hist)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(cell_hist_k, dim3(std::min(grid_for(n), c->num_cus * 2)), dim3(TPB), 0, c->stream, raw, n, g,
-                       hist);
+    // few blocks: each flushes up to 1024 bins with global atomics
+    hipLaunchKernelGGL(cell_hist_k, dim3(std::min(grid_for((n + stride - 1) / stride), 64)), dim3(TPB), 0, c->stream, raw,
+                       n, g, stride, hist);
+    SCCD_HIP(hipGetLastError());
+}
+void launch_cell_fill_append(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
+                             uint32_t* cursor, uint32_t capacity, uint32_t* key, uint32_t* idx)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(cell_fill_append_k, dim3((n + 1023) / 1024), dim3(1024), 0, c->stream, raw, n, g, cell_lo, cell_hi,
+                       cursor, capacity, key, idx);
     SCCD_HIP(hipGetLastError());
 }
 void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,

@@ -86,7 +86,9 @@ int launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st, do
 void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a, int n_part_a, const GridStats* st_b,
                        const double* part_b, int n_part_b, int n_total, int axis, double cell_factor, int shrink,
                        GridParams* g);
-void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, uint32_t* hist);
+void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int stride, uint32_t* hist);
+void launch_cell_fill_append(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
+                             uint32_t* cursor, uint32_t capacity, uint32_t* key, uint32_t* idx);
 void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
                        uint32_t* counts);
 void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,

@@ -1,6 +1,6 @@
 # per-kernel device time of the 8 emulated shards of the cloth workload: bash tools/kstats_shard.sh [world]
 W=${1:-8}
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rm -rf gpurun_out/kshard && rocprofv3 --kernel-trace --stats -d gpurun_out/kshard --output-format csv -- python3 tools/shard_balance.py --worlds $W --reps 3 > gpurun_out/kshard.log 2>&1
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rm -rf gpurun_out/kshard && rocprofv3 --kernel-trace --stats -d gpurun_out/kshard --output-format csv -- python3 tools/shard_balance.py --worlds $W --reps 3 --n ${2:-708} > gpurun_out/kshard.log 2>&1
 python3 - <<PY
 import csv,glob
 f=sorted(glob.glob("gpurun_out/kshard/*/*kernel_stats.csv"))[-1]
