@@ -374,7 +374,6 @@ static void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline*
     // the builders also produce the bounds / extent sums the grid needs (no second pass over the boxes)
     auto begin_stats = [&](sccd_boxes& b) {
         b.stats.ensure(SCCD_STATS_BYTES);
-        SCCD_HIP(hipMemsetAsync(b.stats.p, 0, 128, c->stream));
         b.have_stats = false;
     };
     pl->vb.n = m->nV;
@@ -406,7 +405,6 @@ static void ensure_stats(sccd_ctx* c, const sccd_boxes* b)
 {
     if (b->have_stats) return;
     b->stats.ensure(SCCD_STATS_BYTES);
-    SCCD_HIP(hipMemsetAsync(b->stats.p, 0, 128, c->stream));
     b->n_part = launch_box_stats(c, b->raw.as<sccd_aabb>(), b->n, b->stats_head(), b->stats_part());
     b->have_stats = true;
 }

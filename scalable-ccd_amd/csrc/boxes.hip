@@ -111,9 +111,12 @@ struct StatsAcc {
                 h = fmax(h, red[j][3 + k]);
                 s += red[j][6 + k];
             }
-            atomicMax(&st->kmin[k], ~mono64(l)); // stored inverted: the block is zero-initialised by ONE memset
-            atomicMax(&st->kmax[k], mono64(h));
-            part[blockIdx.x * 3 + k] = s;
+            // one partial per block, no atomics (nine hot words shared by every block cost more than the
+            // reduction grid_setup_k does instead)
+            (void)st;
+            part[blockIdx.x * 9 + k] = l;
+            part[blockIdx.x * 9 + 3 + k] = h;
+            part[blockIdx.x * 9 + 6 + k] = s;
         }
     }
 };
@@ -228,30 +231,41 @@ __global__ void grid_setup_k(const GridStats* __restrict__ st_a, const double* _
 {
     // summed extents: lane l adds the block partials l, l + 64, ... of list A, then of list B, in
     // that order, then a fixed shuffle tree -- the same bits on every run and every rank (one wave)
-    double sumext[3];
+    double sumext[3], glo[3], ghi[3];
     {
         const int lane = lane_id();
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            double s = 0.0;
-            for (int j = lane; j < n_part_a; j += 64) s += part_a[j * 3 + k];
-            for (int j = lane; j < n_part_b; j += 64) s += part_b[j * 3 + k];
+            double s = 0.0, l = TI_INF, h = -TI_INF;
+            for (int j = lane; j < n_part_a; j += 64) {
+                l = fmin(l, part_a[j * 9 + k]);
+                h = fmax(h, part_a[j * 9 + 3 + k]);
+                s += part_a[j * 9 + 6 + k];
+            }
+            for (int j = lane; j < n_part_b; j += 64) {
+                l = fmin(l, part_b[j * 9 + k]);
+                h = fmax(h, part_b[j * 9 + 3 + k]);
+                s += part_b[j * 9 + 6 + k];
+            }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            for (int o = 32; o > 0; o >>= 1) {
+                s += __shfl_xor(s, o, 64);
+                l = fmin(l, __shfl_xor(l, o, 64));
+                h = fmax(h, __shfl_xor(h, o, 64));
+            }
             sumext[k] = s;
+            glo[k] = l;
+            ghi[k] = h;
         }
     }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int aa = (axis == 0) ? 1 : 0, ab = (axis == 2) ? 1 : 2;
     double lo[3], hi[3];
+    (void)st_a;
+    (void)st_b;
     for (int k = 0; k < 3; k++) {
-        unsigned long long kmin_inv = st_a->kmin[k], kmax = st_a->kmax[k];
-        if (st_b) {
-            kmin_inv = max(kmin_inv, st_b->kmin[k]);
-            kmax = max(kmax, st_b->kmax[k]);
-        }
-        lo[k] = mono64_inv(~kmin_inv);
-        hi[k] = mono64_inv(kmax);
+        lo[k] = glo[k] + 0.0; // (-0 -> +0, as the monotone integer image used to do)
+        hi[k] = ghi[k] + 0.0;
     }
     int S[2];
     const int ax2[2] = { aa, ab };

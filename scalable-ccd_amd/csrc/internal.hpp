@@ -37,9 +37,9 @@ struct sccd_boxes {
     mutable int n_part = 0;
     mutable bool have_stats = false;
     GridStats* stats_head() const { return stats.as<GridStats>(); }
-    double* stats_part() const { return reinterpret_cast<double*>(stats.as<char>() + 128); }
+    double* stats_part() const { return reinterpret_cast<double*>(stats.as<char>() + 128); } // [n_part][9]: lo, hi, extent sums
 };
-constexpr size_t SCCD_STATS_BYTES = 128 + sizeof(double) * 3 * SCCD_STATS_BLOCKS;
+constexpr size_t SCCD_STATS_BYTES = 128 + sizeof(double) * 9 * SCCD_STATS_BLOCKS;
 
 // one sweep list: an entry per (box, overlapped cell), sorted by the composite key of grid.hpp
 struct SortedList {
