@@ -410,7 +410,9 @@ bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
     }
     // onesweep: [4 tickets, one per 128-B line] [status passes x tiles x 256] [bases 4x256] [partial hist blocks x 1024]
     // (Per-segment tickets + bases were tried: the bases of a segment are only known for the FIRST pass,
-    // later passes see permuted keys; and ticket streams without a global order can deadlock the look-back.)
+    // later passes see permuted keys; ticket streams without a global order can deadlock the look-back; and a
+    // ticket worth two consecutive tiles serialises it -- the second tile publishes its count only after the
+    // first is finished, so every predecessor chain runs at one tile time per link: 70x slower.)
     const int hist_blocks = std::min(num_tiles, c->num_cus);
     const int dbg = std::getenv("SCCD_SORT_DBG") ? std::atoi(std::getenv("SCCD_SORT_DBG")) : 0; // timing ablations only
     const size_t status_bytes = (size_t)passes * num_tiles * 256 * sizeof(uint32_t);
