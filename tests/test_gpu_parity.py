@@ -106,6 +106,28 @@ def test_pair_set_independent_of_cell_grid(sccd, ctx, orc, cell_factor, monkeypa
     assert np.array_equal(_sorted(bp.detect_overlaps()), want)
 
 
+def test_scan_build_path(sccd, ctx, orc, monkeypatch):
+    """SCCD_BUILD=scan: count -> device-wide prefix scan -> fill instead of the one-pass append
+    (entries in box order).  Same pair sets, one and two lists."""
+    monkeypatch.setenv("SCCD_BUILD", "scan")
+    V0, V1, E, F = _scene("cloth_ball_10k")
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F)
+    bp = sccd.BroadPhase(ctx)
+    bp.build(sccd.DeviceAABBs(eb, ctx))
+    want, _, _ = orc.sort_and_sweep(eb, nthreads=8)
+    assert np.array_equal(_sorted(bp.detect_overlaps()), want)
+    bp.build(sccd.DeviceAABBs(vb, ctx), sccd.DeviceAABBs(fb, ctx))
+    want, _, _ = orc.sort_and_sweep(vb, fb, nthreads=8)
+    assert np.array_equal(_sorted(bp.detect_overlaps()), want)
+    b = scenes.random_boxes(50_000, seed=3, max_extent=0.5)  # big boxes: the replication budget coarsens the grid
+    want, _, _ = orc.sort_and_sweep(b[:4000], nthreads=8)
+    bp.build(sccd.DeviceAABBs(b[:4000], ctx))
+    assert np.array_equal(_sorted(bp.detect_overlaps()), want)
+    monkeypatch.delenv("SCCD_BUILD")
+    bp.build(sccd.DeviceAABBs(b[:4000], ctx))  # ... and the same through the append path
+    assert np.array_equal(_sorted(bp.detect_overlaps()), want)
+
+
 @pytest.mark.parametrize("axis", [0, 1, 2])
 def test_pair_set_independent_of_sort_axis(sccd, ctx, orc, axis):
     boxes = scenes.random_boxes(20000, seed=3, max_extent=0.06)
