@@ -60,7 +60,7 @@ __device__ __forceinline__ unsigned upper_bound_u32(const uint32_t* __restrict__
     return lo;
 }
 
-// One block = 256 consecutive sorted rows.  Their candidate ranges all lie inside one window of
+// One block = 1024 consecutive sorted rows.  Their candidate ranges all lie inside one window of
 // the column list ([lb(first row's key), ub(largest max-key of the block))), found with two
 // full binary searches by one lane; every row then searches only inside the window, which is a
 // few hundred entries that stay in this CU's L1.
@@ -110,11 +110,13 @@ template <bool UPPER> __device__ __forceinline__ unsigned wave_bound_u32(const u
     return lo + (unsigned)popc64(__ballot(before));
 }
 
-__global__ __launch_bounds__(256) void ranges_k(const uint32_t* __restrict__ key_r, const uint32_t* __restrict__ kmax_r,
+constexpr int RG_THREADS = 1024; // rows per block: one window search and one statistics atomic per block
+constexpr int RG_WAVES = RG_THREADS / 64;
+__global__ __launch_bounds__(RG_THREADS) void ranges_k(const uint32_t* __restrict__ key_r, const uint32_t* __restrict__ kmax_r,
                                                 int n_rows, const uint32_t* __restrict__ key_c, int n_cols, int mode,
                                                 uint2* __restrict__ ranges, unsigned long long* __restrict__ candidates)
 {
-    __shared__ uint32_t s_kmax[4];
+    __shared__ uint32_t s_kmax[RG_WAVES];
     __shared__ unsigned s_win[2];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n_rows;
@@ -124,7 +126,9 @@ __global__ __launch_bounds__(256) void ranges_k(const uint32_t* __restrict__ key
     if (lane_id() == 0) s_kmax[threadIdx.x >> 6] = wmax;
     __syncthreads();
     if (threadIdx.x < 64) { // the first wave finds the window, 64 probes per round
-        const uint32_t bmax = max(max(s_kmax[0], s_kmax[1]), max(s_kmax[2], s_kmax[3]));
+        uint32_t bmax = s_kmax[0];
+#pragma unroll
+        for (int k = 1; k < RG_WAVES; k++) bmax = max(bmax, s_kmax[k]);
         // rows are sorted: the first row of the block has the smallest key
         const uint32_t k_first = (uint32_t)__shfl((int)k_lo, 0, 64);
         const unsigned i_first = (unsigned)(blockIdx.x * blockDim.x);
@@ -159,11 +163,13 @@ __global__ __launch_bounds__(256) void ranges_k(const uint32_t* __restrict__ key
     // at ~90 atomics/us chip-wide, which used to cost more than the searches)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    __shared__ unsigned long long s_cnt[4];
+    __shared__ unsigned long long s_cnt[RG_WAVES];
     if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        unsigned long long tot = 0;
+#pragma unroll
+        for (int k = 0; k < RG_WAVES; k++) tot += s_cnt[k];
         if (tot) atomicAdd(candidates + (blockIdx.x & 31), tot);
     }
 }
@@ -487,8 +493,8 @@ void launch_ranges(sccd_ctx* c, const SortedList* rows, const SortedList* cols, 
                    unsigned long long* d_candidates)
 {
     if (rows->m == 0) return;
-    const int grid = (rows->m + 255) / 256;
-    hipLaunchKernelGGL(ranges_k, dim3(grid), dim3(256), 0, c->stream, rows->key.as<uint32_t>(),
+    const int grid = (rows->m + RG_THREADS - 1) / RG_THREADS;
+    hipLaunchKernelGGL(ranges_k, dim3(grid), dim3(RG_THREADS), 0, c->stream, rows->key.as<uint32_t>(),
                        rows->kmax.as<uint32_t>(), rows->m, cols->key.as<uint32_t>(), cols->m, mode, ranges,
                        d_candidates);
     SCCD_HIP(hipGetLastError());
