@@ -237,6 +237,36 @@ struct Emitter {
         wave_lds_fence();
         ocount = 0;
     }
+    // The last flush of a kernel, by ALL waves of the block together: one atomic per block.  (Every
+    // wave ends at about the same time, and the cursor is one hot word: ~90 atomics/us chip-wide --
+    // a flush per wave made the tail of each launch a queue of 4096 atomics.)
+    // `scratch`: 2 * SW_WAVES u64 of LDS no wave uses any more (the kernel's LDS budget is exactly
+    // 4 blocks per CU: not one byte may be added)
+    __device__ __forceinline__ void flush_block(unsigned long long* scratch)
+    {
+        unsigned long long* blk_cnt = scratch;
+        unsigned long long* blk_base = scratch + SW_WAVES;
+        const int w = (int)(threadIdx.x >> 6);
+        __syncthreads(); // every wave is done with the scratch area
+        if (lane_id() == 0) blk_cnt[w] = (unsigned long long)ocount;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long sum = 0;
+            for (int k = 0; k < SW_WAVES; k++) {
+                blk_base[k] = sum;
+                sum += blk_cnt[k];
+            }
+            const unsigned long long b0 = sum ? atomicAdd(n_pairs, sum) : 0ull;
+            for (int k = 0; k < SW_WAVES; k++) blk_base[k] += b0;
+        }
+        __syncthreads();
+        const unsigned long long base = blk_base[w];
+        for (int k = lane_id(); k < ocount; k += 64) {
+            const unsigned long long dst = base + (unsigned long long)k;
+            if ((long long)dst < capacity) out[dst] = stage[k];
+        }
+        ocount = 0;
+    }
     __device__ __forceinline__ void push(bool ok, int2 pr)
     {
         const unsigned long long mask = __ballot(ok);
@@ -393,7 +423,8 @@ __global__ __launch_bounds__(SW_THREADS, 4) void sweep_stq_k(
         const uint2 cand = act ? q[lane] : make_uint2(0u, 0u);
         confirm(act, cand, box_r, key_r, box_c, g, emit, em);
     }
-    em.flush();
+    wave_lds_fence();
+    em.flush_block(reinterpret_cast<unsigned long long*>(&q_s[0][0])); // (the candidate queues are empty now)
 }
 
 // Direct exact sweep: the kernel of choice once the cell grid has cut the candidates down to a
