@@ -156,8 +156,13 @@ struct NarrowCounters {
     unsigned long long pops_reg, pops_mem; // pops served by the register top / by the HBM stack
     unsigned long long wave_hist[16];      // waves by number of check steps, buckets of 16 (last: >= 240)
     unsigned long long xcd_steps[8], xcd_waves[8]; // check steps and waves per XCD (HW_REG_XCC_ID)
+    // check counts, striped over eight 128-byte lines: every wave adds its count when it ends, and they
+    // all end together -- 2048 atomics on one word were a 20 us tail on every launch
+    struct alignas(128) Stripe {
+        unsigned long long n;
+    } checks_part[8];
 };
-static_assert(sizeof(NarrowCounters) <= 1024, "NarrowCounters must fit its slot of the scalars block");
+static_assert(sizeof(NarrowCounters) <= 2048, "NarrowCounters must fit its slot of the scalars block");
 constexpr int SCCD_QUEUE_MIN_MAX_ITER = 4096; // smaller check limits are served by the level-synchronous kernel
 // runs the narrow phase on the stream; *toi in/out lives in d_cnt->toi_bits
 void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,

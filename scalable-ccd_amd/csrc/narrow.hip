@@ -223,6 +223,7 @@ void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
         rb.add(&h, d_cnt, sizeof h);
         rb.sync();
     }
+    for (int k = 0; k < 8; k++) h.n_checks += h.checks_part[k].n; // (the work-queue kernel counts in stripes)
     if (std::getenv("SCCD_NP_DIAG") && h.wave_steps)
         std::fprintf(stderr, "[sccd np] n=%lld checks=%llu wave_steps=%llu (waves %llu, mean %.1f, longest %llu) lane_util=%.3f refill_execs=%llu steals=%llu pops reg/mem=%llu/%llu\n",
                      n, h.n_checks, h.wave_steps, h.waves_run, (double)h.wave_steps / (double)std::max<unsigned long long>(1, h.waves_run),
