@@ -603,7 +603,8 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     unsigned long long window_est = 0; // entries of this rank's cell window, estimated from the sampled histogram
     for (int shrink = 0;; shrink++) {
         launch_grid_setup(c, A->stats_head(), A->stats_part(), A->n_part, B ? B->stats_head() : nullptr,
-                          B ? B->stats_part() : nullptr, B ? B->n_part : 0, n_total, axis, cf, shrink, gp);
+                          B ? B->stats_part() : nullptr, B ? B->n_part : 0, n_total, axis, cf, shrink, gp,
+                          reinterpret_cast<uint32_t*>(c->scalars.as<char>() + 1536));
         const bool can_shrink = shrink < 10;
         // Multi-GPU: every rank takes a contiguous window of cells with an equal share of the
         // entries, and builds / sorts / sweeps only that window.  A pair is reported from exactly
@@ -653,10 +654,10 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                                                     : (unsigned long long)std::max<int64_t>(3 * (int64_t)std::max(A->n, B ? B->n : 0), (int64_t)std::max(A->n, B ? B->n : 0) + 4096);
             uint32_t total[2] = { 0, 0 };
             GridParams hgp;
-            for (;;) {
+            for (int fill_round = 0;; fill_round++) {
                 SCCD_REQUIRE(cap < (1ull << 31), "broad phase: too many cell entries");
                 const size_t pad = 64;
-                SCCD_HIP(hipMemsetAsync(d_total, 0, 2 * sizeof(uint32_t), c->stream));
+                if (fill_round > 0) SCCD_HIP(hipMemsetAsync(d_total, 0, 2 * sizeof(uint32_t), c->stream)); // (grid_setup_k zeroed them for round 0)
                 {
                     ProfScope ps(c, SCCD_PROF_BOXES);
                     bp->la.key.ensure(sizeof(uint32_t) * ((size_t)cap + pad));
@@ -817,7 +818,8 @@ static void bp_detect_partial(sccd_broad_phase* bp)
         shard_rows(c, bp->row_shard, a_lo, a_hi, &a_lo, &a_hi);
         if (B) shard_rows(c, bp->row_shard, b_lo, b_hi, &b_lo, &b_hi);
 
-        SCCD_HIP(hipMemsetAsync(&d_cnt->n_pairs, 0, sizeof(unsigned long long), c->stream));
+        if (attempt > 0 || chunk_lo != 0) // (the first chunk's counters were just zeroed as a whole)
+            SCCD_HIP(hipMemsetAsync(&d_cnt->n_pairs, 0, sizeof(unsigned long long), c->stream));
         {
             ProfScope ps(c, SCCD_PROF_SWEEP);
             if (!B) {

@@ -227,8 +227,10 @@ __global__ void box_stats_k(const sccd_aabb* __restrict__ raw, int n, GridStats*
 // cell size = cell_factor x mean box extent on that axis; at most 2^10 cells in total
 __global__ void grid_setup_k(const GridStats* __restrict__ st_a, const double* __restrict__ part_a, int n_part_a,
                              const GridStats* __restrict__ st_b, const double* __restrict__ part_b, int n_part_b,
-                             int n_total, int axis, double cell_factor, int shrink, GridParams* __restrict__ g)
+                             int n_total, int axis, double cell_factor, int shrink, GridParams* __restrict__ g,
+                             uint32_t* __restrict__ cursors /* the two list cursors of the fill pass: zeroed here */)
 {
+    if (threadIdx.x < 2) cursors[threadIdx.x] = 0u;
     // summed extents: lane l adds the block partials l, l + 64, ... of list A, then of list B, in
     // that order, then a fixed shuffle tree -- the same bits on every run and every rank (one wave)
     double sumext[3], glo[3], ghi[3];
@@ -576,10 +578,10 @@ int launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st, do
 }
 void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a, int n_part_a, const GridStats* st_b,
                        const double* part_b, int n_part_b, int n_total, int axis, double cell_factor, int shrink,
-                       GridParams* g)
+                       GridParams* g, uint32_t* cursors)
 {
     hipLaunchKernelGGL(grid_setup_k, dim3(1), dim3(64), 0, c->stream, st_a, part_a, n_part_a, st_b, part_b, n_part_b,
-                       n_total, axis, cell_factor, shrink, g);
+                       n_total, axis, cell_factor, shrink, g, cursors);
     SCCD_HIP(hipGetLastError());
 }
 void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int stride, uint32_t* hist)
