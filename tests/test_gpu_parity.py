@@ -477,6 +477,26 @@ def test_ccd_matches_golden(sccd, ctx, name, arith):
     assert st["n_vf_pairs"] == G["n_vf"] and st["n_ee_pairs"] == G["n_ee"]
 
 
+def test_odd_meshes(sccd, ctx, orc):
+    """One triangle, no faces, no edges, nothing at all, an absurdly fast vertex, and one context
+    reused for scenes of very different sizes."""
+    V0 = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0.2, 0.2, 1.0]], float)
+    V1 = V0.copy()
+    V1[3, 2] = -1
+    F = np.array([[0, 1, 2]], np.int32)
+    E = np.array([[0, 1], [1, 2], [0, 2]], np.int32)
+    noE, noF = np.zeros((0, 2), np.int32), np.zeros((0, 3), np.int32)
+    for e, f in ((E, F), (E, noF), (noE, F), (noE, noF)):
+        assert sccd.ccd(V0, V1, e, f, ctx=ctx) == orc.ccd(V0, V1, e, f)[0]
+    assert sccd.ccd(np.zeros((0, 3)), np.zeros((0, 3)), noE, noF, ctx=ctx) == 1.0
+    Vfast = V0.copy()
+    Vfast[3] = [1e8, -1e8, -1e8]
+    assert sccd.ccd(V0, Vfast, E, F, ctx=ctx) == orc.ccd(V0, Vfast, E, F)[0]
+    for n in (3, 40, 7, 90):
+        scene = scenes.cloth_ball(n, 1, seed=n)
+        assert sccd.ccd(*scene, ctx=ctx) == orc.ccd(*scene, nthreads=8)[0]
+
+
 def test_ccd_argument_errors(sccd, ctx):
     V0, V1, E, F = _scene("cloth_ball_small")
     with pytest.raises(RuntimeError):
