@@ -106,6 +106,7 @@ void sccd_destroy(sccd_ctx* c)
     c->pipeline = nullptr;
     sccd_collect_profile(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->rb_event) (void)hipEventDestroy(c->rb_event);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
