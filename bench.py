@@ -180,7 +180,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": dict(wl, queries_per_step=queries_per_step, toi=toi, arith=["strict", "fma"][args.arith],
                            checks_per_step=float(qq[1].item()), candidates_per_step=float(qq[2].item()),
-                           parallelism=f"pairs sharded over {world} GPU(s), RCCL min-reduce of TOI"),
+                           parallelism=f"cell windows sharded over {world} GPU(s), one RCCL all-reduce(min) of the TOI per step"),
             "min_toi_latency_ms": dt / args.steps * 1e3,
             "roofline": roofline,
         }

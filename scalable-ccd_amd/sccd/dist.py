@@ -45,12 +45,15 @@ def allreduce_min(value, group=None, device=None):
     return float(t.item())
 
 
-def ccd_sharded(run_pass, rank, world, group=None, device=None, prepare=None):
+def ccd_sharded(run_pass, rank, world, group=None, device=None, prepare=None, reduce_between_passes=False):
     """ccd() across `world` ranks.
 
     run_pass(is_vf, toi) -> (toi, stats) runs this rank's share of the VF or EE pass starting
     from the bound `toi` (sccd.ccd_mesh_pass on a context configured with SHARD_RANK/COUNT).
-    The VF result seeds the EE pass on every rank (ccd.cu:125-143), hence two reductions.
+    The result is the minimum over all accepted domains of all ranks, so ONE all-reduce(min) at
+    the end is enough: a rank's own VF result seeds its EE pass (ccd.cu:125-143) and only prunes.
+    reduce_between_passes=True also shares the VF result before the EE pass (a tighter pruning
+    bound on every rank for the price of a second collective -- not worth it at millisecond steps).
     """
     if prepare is not None:
         prepare()
@@ -60,7 +63,7 @@ def ccd_sharded(run_pass, rank, world, group=None, device=None, prepare=None):
         toi, st = run_pass(is_vf, toi)
         for k, v in (st or {}).items():
             stats[k] = stats.get(k, 0) + v
-        toi = allreduce_min(toi, group=group, device=device)
-        if toi <= 0:  # nothing can beat 0 (narrow_phase.cu:136)
-            pass
+        if reduce_between_passes and is_vf:
+            toi = allreduce_min(toi, group=group, device=device)
+    toi = allreduce_min(toi, group=group, device=device)
     return toi, stats

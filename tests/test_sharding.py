@@ -121,7 +121,7 @@ def test_single_rank_needs_no_process_group():
 @pytest.mark.gpu
 def test_bench_two_ranks_share_one_gpu_and_agree_with_one_rank():
     """bench.py's N > 1 path end to end on the GPU box: two processes (gloo, both on cuda:0), each
-    building / sorting / sweeping / narrowing its window of grid cells, two all-reduce(min).
+    building / sorting / sweeping / narrowing its window of grid cells, one all-reduce(min).
     Queries must add up to the single-rank count and the TOI must be the same."""
     import json
     import subprocess
