@@ -6,10 +6,9 @@
 A step = one full pass of the hot path over one batch of synthetic input already resident in
 HBM: box build -> radix sort -> candidate ranges -> STQ sweep -> Tight-Inclusion narrow phase,
 for the VF list pair then the EE list (scalable_ccd::cuda::ccd(), ccd.cu:80-146).  With N > 1
-(one process per GPU, launched by torch.distributed.run) every rank sweeps its share of the
-candidates and runs the narrow phase on the pairs it found; the only exchange is the
-all-reduce(min) of the time of impact after each pass (RCCL) -- total work is fixed: strong
-scaling.
+(one process per GPU, launched by torch.distributed.run) every rank builds, sorts, sweeps and
+narrows its window of grid cells; the only exchange is one all-reduce(min) of the time of impact
+per step (RCCL) -- total work is fixed: strong scaling.
 
 Prints ONE JSON line (rank 0) with the contract keys plus `roofline` (dominant kernel class,
 algorithmic bytes / measured device time) and `cpu_baseline` (the CPU oracle on this box's
