@@ -222,6 +222,13 @@ def bench_boxes(args, ctx, sccd, scenes, torch):
     prof = ctx.profile()
     ms_sweep, launches = prof["sweep"]
     achieved = (BYTES_SWEEP_PER_BOX * n + 8.0 * pairs) * args.steps / (ms_sweep * 1e-3) / 1e9
+    traffic = None  # HBM bytes per sweep launch from the committed PMC passes (tools/pmc_traffic.sh boxes1m)
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_boxes1m.json")))["kernels"]["sweep_stq_k"][
+            "hbm_bytes_per_launch_corrected"]
+    except Exception:
+        traffic = None
+    cls = {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[0] > 0}
     return {
         "metric": "broad-phase boxes/sec", "value": n * args.steps / dt, "unit": "boxes/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -229,8 +236,8 @@ def bench_boxes(args, ctx, sccd, scenes, torch):
         "config": {"workload": "1M random AABBs, one list, sweep only (BASELINE configs[2])", "pairs": pairs,
                    "candidates": bp.candidates()},
         "roofline": {"bound": "hbm", "kernel": "sweep_stq_k", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                     "avg_launch_ms": round(ms_sweep / max(1, launches), 4),
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "avg_launch_ms": round(ms_sweep / max(1, launches), 4), "class_ms_per_step": cls,
                      "candidate_tests_per_s": bp.candidates() * args.steps / (ms_sweep * 1e-3)},
     }
 

@@ -18,6 +18,8 @@ bash tools/pmc_traffic.sh cloth1m > gpurun_out/prof/pmc_traffic_cloth1m.txt 2>&1
 cp gpurun_out/pmc_traffic_cloth1m.json gpurun_out/prof/r01_pmc_traffic_cloth1m.json
 bash tools/pmc_traffic.sh sort16m > gpurun_out/prof/pmc_traffic_sort16m.txt 2>&1
 cp gpurun_out/pmc_traffic_sort16m.json gpurun_out/prof/r01_pmc_traffic_sort16m.json
+bash tools/pmc_traffic.sh boxes1m > gpurun_out/prof/pmc_traffic_boxes1m.txt 2>&1
+cp gpurun_out/pmc_traffic_boxes1m.json gpurun_out/prof/r01_pmc_traffic_boxes1m.json
 bash tools/pmc_sq.sh cloth1m > gpurun_out/prof/pmc_sq_cloth1m.txt 2>&1
 cp gpurun_out/pmc_sq_cloth1m.json gpurun_out/prof/r01_pmc_sq_cloth1m.json
 python3 tools/shard_balance.py --profile > gpurun_out/prof/r01_shard_balance.log 2>&1
