@@ -587,7 +587,7 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     // two lists with an empty side produce nothing (sort_and_sweep.cpp:221-223)
     if (A->n == 0 || (B && B->n == 0)) return;
 
-    bp->grid.ensure(8192); // (unused) | params @512 | cell histogram @4096
+    bp->grid.ensure(4096 + sizeof(uint32_t) * SCCD_MAX_CELLS); // (unused) | params @512 | cell histogram @4096
     GridParams* gp = reinterpret_cast<GridParams*>(bp->grid.as<char>() + 512);
     int axis = c->sort_axis;
     if (axis < 0) axis = pick_sort_axis(c, A->raw.as<sccd_aabb>(), A->n);
@@ -612,15 +612,19 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
         // one cell (owns_pair), hence by exactly one rank: no exchange of boxes or pairs.
         if (c->shard_count > 1) {
             uint32_t* d_hist = bp->grid.as<uint32_t>() + 1024; // bytes [4096, 8192) of the grid block
-            SCCD_HIP(hipMemsetAsync(d_hist, 0, 4096, c->stream));
+            SCCD_HIP(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * SCCD_MAX_CELLS, c->stream));
             launch_cell_hist(c, A->raw.as<sccd_aabb>(), A->n, gp, SHARD_HIST_STRIDE, d_hist);
             if (B) launch_cell_hist(c, B->raw.as<sccd_aabb>(), B->n, gp, SHARD_HIST_STRIDE, d_hist);
-            uint32_t hist[1024];
+            static thread_local std::vector<uint32_t> hist_v(SCCD_MAX_CELLS);
+            uint32_t* hist = hist_v.data();
             GridParams hgp;
-            ReadBack rb(c);
-            rb.add(hist, d_hist, sizeof hist);
-            rb.add(&hgp, gp, sizeof hgp);
-            rb.sync();
+            {
+                // (64 KB: too big for the pinned mirror's small-read area; a plain copy, once per sharded build)
+                SCCD_HIP(hipMemcpyAsync(hist, d_hist, sizeof(uint32_t) * SCCD_MAX_CELLS, hipMemcpyDeviceToHost, c->stream));
+                ReadBack rb(c);
+                rb.add(&hgp, gp, sizeof hgp);
+                rb.sync();
+            }
             unsigned long long total = 0; // (estimate: the histogram counts every SHARD_HIST_STRIDE-th box)
             for (int k = 0; k < hgp.n_cells; k++) total += (unsigned long long)hist[k] * SHARD_HIST_STRIDE;
             // same replication budget as the single-GPU build, decided on the whole grid so that

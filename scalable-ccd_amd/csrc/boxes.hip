@@ -228,7 +228,8 @@ __global__ void box_stats_k(const sccd_aabb* __restrict__ raw, int n, GridStats*
 __global__ void grid_setup_k(const GridStats* __restrict__ st_a, const double* __restrict__ part_a, int n_part_a,
                              const GridStats* __restrict__ st_b, const double* __restrict__ part_b, int n_part_b,
                              int n_total, int axis, double cell_factor, int shrink, GridParams* __restrict__ g,
-                             uint32_t* __restrict__ cursors /* the two list cursors of the fill pass: zeroed here */)
+                             uint32_t* __restrict__ cursors /* the two list cursors of the fill pass: zeroed here */,
+                             int max_cells)
 {
     if (threadIdx.x < 2) cursors[threadIdx.x] = 0u;
     // summed extents: lane l adds the block partials l, l + 64, ... of list A, then of list B, in
@@ -278,10 +279,10 @@ __global__ void grid_setup_k(const GridStats* __restrict__ st_a, const double* _
         const double h = cell_factor * mean;
         double s = (h > 0.0 && range > 0.0 && range < TI_INF) ? floor(range / h) : 1.0;
         if (!(s >= 1.0)) s = 1.0;
-        if (s > 1024.0) s = 1024.0;
+        if (s > (double)SCCD_MAX_CELLS) s = (double)SCCD_MAX_CELLS;
         S[t] = (int)s;
     }
-    while ((long long)S[0] * S[1] > 1024) { // keep 2^10 cells at most, shrinking the finer axis
+    while ((long long)S[0] * S[1] > max_cells) { // cap the number of cells, shrinking the finer axis
         if (S[0] >= S[1]) S[0] = (S[0] + 1) / 2;
         else S[1] = (S[1] + 1) / 2;
     }
@@ -387,12 +388,12 @@ __global__ void cell_fill_k(const sccd_aabb* __restrict__ raw, int n, const Grid
 // of about equal entry counts; ANY partition of the cells is correct, so a sample is enough --
 // it only has to be the same sample on every rank).
 __global__ void cell_hist_k(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp, int stride,
-                            uint32_t* __restrict__ hist /*[1024]*/)
+                            uint32_t* __restrict__ hist /*[n_cells]*/)
 {
-    __shared__ uint32_t h[1024];
-    for (int k = threadIdx.x; k < 1024; k += blockDim.x) h[k] = 0;
-    __syncthreads();
+    __shared__ uint32_t h[SCCD_MAX_CELLS];
     const GridParams g = *gp;
+    for (int k = threadIdx.x; k < g.n_cells; k += blockDim.x) h[k] = 0;
+    __syncthreads();
     for (long long i = (long long)(blockIdx.x * blockDim.x + threadIdx.x) * stride; i < n;
          i += (long long)gridDim.x * blockDim.x * stride) {
         const CellSpan s = cell_span(g, load_box_geom(raw + i));
@@ -400,7 +401,7 @@ __global__ void cell_hist_k(const sccd_aabb* __restrict__ raw, int n, const Grid
             for (int cb = s.b0; cb <= s.b1; cb++) atomicAdd(&h[ca * g.Sb + cb], 1u);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < 1024; k += blockDim.x)
+    for (int k = threadIdx.x; k < g.n_cells; k += blockDim.x)
         if (h[k]) atomicAdd(&hist[k], h[k]);
 }
 
@@ -580,8 +581,11 @@ void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a,
                        const double* part_b, int n_part_b, int n_total, int axis, double cell_factor, int shrink,
                        GridParams* g, uint32_t* cursors)
 {
+    // SCCD_MAX_CELLS_ENV: experiments with coarser grids (<= SCCD_MAX_CELLS)
+    const char* mc = std::getenv("SCCD_MAX_CELLS");
+    const int max_cells = mc ? std::max(1, std::min(SCCD_MAX_CELLS, std::atoi(mc))) : SCCD_DEFAULT_CELLS;
     hipLaunchKernelGGL(grid_setup_k, dim3(1), dim3(64), 0, c->stream, st_a, part_a, n_part_a, st_b, part_b, n_part_b,
-                       n_total, axis, cell_factor, shrink, g, cursors);
+                       n_total, axis, cell_factor, shrink, g, cursors, max_cells);
     SCCD_HIP(hipGetLastError());
 }
 void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int stride, uint32_t* hist)

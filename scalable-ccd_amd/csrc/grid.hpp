@@ -17,6 +17,8 @@ struct GridStats { // device, filled by box_stats_k
     unsigned long long kmax[3];
     double sumext[3];           // (unused: the extent sums travel as per-block partials, see box_stats_k)
 };
+constexpr int SCCD_MAX_CELLS = 16384;  // cells of the two-axis grid (14 of the 32 key bits at most)
+constexpr int SCCD_DEFAULT_CELLS = SCCD_MAX_CELLS; // default cap (the SCCD_MAX_CELLS environment variable lowers it)
 constexpr int SCCD_STATS_BLOCKS = 512; // blocks of box_stats_k per list (fixed: the partial sums must not depend on the device)
 
 struct GridParams { // device, written by grid_setup_k
