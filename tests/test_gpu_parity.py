@@ -361,6 +361,33 @@ def test_pair_set_under_translation_and_scale(sccd, ctx, orc, scale, offset):
     assert np.array_equal(_sorted(bp.detect_overlaps()), want)
 
 
+@pytest.mark.parametrize("world", [1, 5])
+def test_many_small_boxes_use_thousands_of_cells(sccd, ctx, orc, world):
+    """A volumetric scene of small boxes: the grid wants ~15,000 cells (more than the 1024 the first
+    version allowed).  One and two lists, unsharded and as 5 cell windows."""
+    b = scenes.random_boxes(200_000, seed=21, max_extent=0.004)
+    a2 = scenes.random_boxes(60_000, seed=22, max_extent=0.006)
+    a2["vertex_ids"] += 10_000_000
+    want1, _, _ = orc.sort_and_sweep(b, nthreads=8)
+    want2, _, _ = orc.sort_and_sweep(a2, b, nthreads=8)
+    assert len(want1) > 1000 and len(want2) > 1000
+    got1, got2 = [], []
+    try:
+        for r in range(world):
+            ctx.set_option(sccd.OPT_SHARD_COUNT, world)
+            ctx.set_option(sccd.OPT_SHARD_RANK, r)
+            bp = sccd.BroadPhase(ctx)
+            bp.build(sccd.DeviceAABBs(b, ctx))
+            got1.append(bp.detect_overlaps().reshape(-1, 2))
+            bp.build(sccd.DeviceAABBs(a2, ctx), sccd.DeviceAABBs(b, ctx))
+            got2.append(bp.detect_overlaps().reshape(-1, 2))
+    finally:
+        ctx.set_option(sccd.OPT_SHARD_COUNT, 1)
+        ctx.set_option(sccd.OPT_SHARD_RANK, 0)
+    assert np.array_equal(_sorted(np.concatenate(got1)), want1)
+    assert np.array_equal(_sorted(np.concatenate(got2)), want2)
+
+
 def test_degenerate_box_lists(sccd, ctx, orc):
     """Point boxes, thousands of identical boxes, one box covering everything."""
     n = 3000
