@@ -504,6 +504,37 @@ def test_ccd_matches_golden(sccd, ctx, name, arith):
     assert st["n_vf_pairs"] == G["n_vf"] and st["n_ee_pairs"] == G["n_ee"]
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_randomised_scenes_against_the_oracle(sccd, ctx, orc, seed):
+    """Triangle soups and cloth-ball scenes with seeded random size, density, motion, minimum
+    separation, zero-TOI policy and arithmetic contract: pair sets and TOI against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    if seed % 3 == 2:
+        V0, V1, E, F = scenes.cloth_ball(int(rng.integers(8, 40)), 1, seed=int(rng.integers(1, 10**6)))
+    else:
+        V0, V1, E, F = scenes.triangle_soup(int(rng.integers(50, 900)), seed=int(rng.integers(1, 10**6)),
+                                            size=float(rng.uniform(0.03, 0.2)), motion=float(rng.uniform(0.0, 0.4)))
+    ms = float(rng.choice([0.0, 0.0, 1e-4, 3e-3]))
+    allow_zero = bool(rng.integers(0, 2))
+    arith = int(rng.integers(0, 2))
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F, ms)
+    want_vf, _, _ = orc.sort_and_sweep(vb, fb, nthreads=8)
+    want_ee, _, _ = orc.sort_and_sweep(eb, nthreads=8)
+    want, _, _ = orc.ccd(V0, V1, E, F, ms, -1, 1e-6, allow_zero, arith=arith, nthreads=8)
+    try:
+        ctx.set_option(sccd.OPT_ARITH, arith)
+        mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+        dv, de, df = sccd.DeviceAABBs.from_mesh(mesh, ms)
+        bp = sccd.BroadPhase(ctx)
+        bp.build(dv, df)
+        assert np.array_equal(_sorted(bp.detect_overlaps()), want_vf)
+        bp.build(de)
+        assert np.array_equal(_sorted(bp.detect_overlaps()), want_ee)
+        assert sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero) == want
+    finally:
+        ctx.set_option(sccd.OPT_ARITH, 0)
+
+
 def test_odd_meshes(sccd, ctx, orc):
     """One triangle, no faces, no edges, nothing at all, an absurdly fast vertex, and one context
     reused for scenes of very different sizes."""
