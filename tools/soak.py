@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Randomised soak: many seeded scenes through every path (sweep algorithms, sharding, both list
+builds, both narrow kernels, both arithmetic contracts) against the CPU oracle.
+    python tools/soak.py [cases] [first seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scalable-ccd_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import orc
+import sccd
+from sccd import scenes
+
+
+def srt(p):
+    p = np.asarray(p, np.int32).reshape(-1, 2)
+    return p[np.lexsort((p[:, 1], p[:, 0]))] if len(p) else p
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    ctx = sccd.default_context()
+    bad = 0
+    t0 = time.time()
+    for seed in range(first, first + cases):
+        rng = np.random.default_rng(77_000 + seed)
+        kind = seed % 4
+        if kind == 0:
+            V0, V1, E, F = scenes.cloth_ball(int(rng.integers(6, 60)), int(rng.integers(1, 3)), seed=int(rng.integers(1, 10**6)))
+        elif kind == 1:
+            V0, V1, E, F = scenes.folded_cloth(int(rng.integers(10, 120)), seed=int(rng.integers(1, 10**6)))
+        else:
+            V0, V1, E, F = scenes.triangle_soup(int(rng.integers(20, 1500)), seed=int(rng.integers(1, 10**6)),
+                                                size=float(rng.uniform(0.02, 0.3)), motion=float(rng.uniform(0.0, 0.5)))
+        scale, shift = float(10.0 ** rng.uniform(-3, 3)), float(rng.uniform(-1, 1) * 10.0 ** rng.uniform(0, 4))
+        V0, V1 = V0 * scale + shift, V1 * scale + shift
+        ms = float(rng.choice([0.0, 0.0, 1e-4, 3e-3])) * scale
+        allow_zero = bool(rng.integers(0, 2))
+        arith = int(rng.integers(0, 2))
+        world = int(rng.choice([1, 1, 2, 3, 8]))
+        sweep_algo = int(rng.choice([0, 0, 1, 3]))
+        scan_build = bool(rng.integers(0, 4) == 0)
+        narrow_algo = int(rng.integers(0, 8) == 0)
+        tag = f"seed {seed} kind {kind} nF {len(F)} scale {scale:.3g} shift {shift:.3g} ms {ms:.3g} zero {allow_zero} arith {arith} world {world} sweep {sweep_algo} scan {scan_build} narrow {narrow_algo}"
+        vb, eb, fb = orc.build_boxes(V0, V1, E, F, ms)
+        want_vf, _, _ = orc.sort_and_sweep(vb, fb, nthreads=8)
+        want_ee, _, _ = orc.sort_and_sweep(eb, nthreads=8)
+        want, _, _ = orc.ccd(V0, V1, E, F, ms, -1, 1e-6, allow_zero, arith=arith, nthreads=8)
+        if scan_build:
+            os.environ["SCCD_BUILD"] = "scan"
+        else:
+            os.environ.pop("SCCD_BUILD", None)
+        try:
+            ctx.set_option(sccd.OPT_ARITH, arith)
+            ctx.set_option(sccd.OPT_SWEEP_ALGO, sweep_algo)
+            ctx.set_option(sccd.OPT_NARROW_ALGO, narrow_algo)
+            mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+            dv, de, df = sccd.DeviceAABBs.from_mesh(mesh, ms)
+            got_vf, got_ee, tois = [], [], []
+            for r in range(world):
+                ctx.set_option(sccd.OPT_SHARD_COUNT, world)
+                ctx.set_option(sccd.OPT_SHARD_RANK, r)
+                bp = sccd.BroadPhase(ctx)
+                bp.build(dv, df)
+                got_vf.append(bp.detect_overlaps().reshape(-1, 2))
+                bp.build(de)
+                got_ee.append(bp.detect_overlaps().reshape(-1, 2))
+                tois.append(sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero))
+            ok = (np.array_equal(srt(np.concatenate(got_vf)), want_vf) and np.array_equal(srt(np.concatenate(got_ee)), want_ee)
+                  and min(tois) == want)
+        finally:
+            ctx.set_option(sccd.OPT_SHARD_COUNT, 1)
+            ctx.set_option(sccd.OPT_SHARD_RANK, 0)
+            ctx.set_option(sccd.OPT_ARITH, 0)
+            ctx.set_option(sccd.OPT_SWEEP_ALGO, 0)
+            ctx.set_option(sccd.OPT_NARROW_ALGO, 0)
+        if not ok:
+            bad += 1
+            print("MISMATCH", tag, "toi", min(tois), "want", want, "vf", sum(map(len, got_vf)), len(want_vf), "ee",
+                  sum(map(len, got_ee)), len(want_ee), flush=True)
+    print(f"soak: {cases} cases, {bad} mismatches, {time.time() - t0:.1f} s")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
