@@ -20,6 +20,7 @@ template <class Fn> static int guarded(sccd_ctx* c, Fn&& fn)
         fn();
         return SCCD_OK;
     } catch (const SccdError& e) {
+        (void)hipGetLastError(); // (sticky: a later launch check must not trip over this call's failure)
         if (c) c->err = e.msg;
         else g_create_error = e.msg;
         return e.code;

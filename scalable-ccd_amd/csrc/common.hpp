@@ -27,6 +27,7 @@ struct SccdError {
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \
         if (_e != hipSuccess) {                                                                \
+            (void)hipGetLastError(); /* the runtime's last-error is sticky: do not leave it to the next call */ \
             throw SccdError { _e == hipErrorOutOfMemory ? SCCD_E_NOMEM : SCCD_E_HIP,           \
                               std::string(#expr) + ": " + hipGetErrorString(_e) + " ("         \
                                   + __FILE__ + ":" + std::to_string(__LINE__) + ")" };         \
