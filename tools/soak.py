@@ -41,7 +41,7 @@ def main():
         world = int(rng.choice([1, 1, 2, 3, 8]))
         sweep_algo = int(rng.choice([0, 0, 1, 3]))
         scan_build = bool(rng.integers(0, 4) == 0)
-        narrow_algo = int(rng.integers(0, 8) == 0)
+        narrow_algo = int(rng.integers(0, 8) == 0 and len(F) < 300)  # (level order explodes on big contact-rich scenes)
         tag = f"seed {seed} kind {kind} nF {len(F)} scale {scale:.3g} shift {shift:.3g} ms {ms:.3g} zero {allow_zero} arith {arith} world {world} sweep {sweep_algo} scan {scan_build} narrow {narrow_algo}"
         vb, eb, fb = orc.build_boxes(V0, V1, E, F, ms)
         want_vf, _, _ = orc.sort_and_sweep(vb, fb, nthreads=8)
