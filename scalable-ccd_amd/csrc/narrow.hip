@@ -54,11 +54,13 @@ struct LvlDomain { // CCDDomain (interval.cuh:30-44)
 
 template <bool VF>
 __global__ void np_level_init_k(const double* __restrict__ V, const int2* __restrict__ E, const int4* __restrict__ F,
-                                const int2* __restrict__ pairs, long long n, double tol, bool use_ms,
+                                const int2* __restrict__ pairs, long long first, long long n, double tol, bool use_ms,
                                 LvlData* __restrict__ data, LvlDomain* __restrict__ dom)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    // queries [first, first + n) of the call: data[] is indexed by query, dom[] by position in the slice
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const long long i = first + j;
     TIQuery q;
     ti_gather<VF>(V, E, F, pairs[i], q.v);
     ti_tolerance<VF>(q.v, tol, q.tol);
@@ -85,7 +87,7 @@ __global__ void np_level_init_k(const double* __restrict__ V, const int2* __rest
     }
     r.query_id = (int)i;
     r.pad = 0;
-    dom[i] = r;
+    dom[j] = r;
 }
 
 template <bool VF, int ARITH>
@@ -144,33 +146,61 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
     const bool use_ms = p.ms > 0; // narrow_phase.cu:128
     c->np_scratch0.ensure(sizeof(LvlData) * (size_t)n);
     LvlData* data = c->np_scratch0.as<LvlData>();
-    c->np_scratch1.ensure(sizeof(LvlDomain) * (size_t)n);
     c->tmp0.ensure(sizeof(unsigned long long));
     unsigned long long* d_n = c->tmp0.as<unsigned long long>();
     const int TPB = 256;
-    hipLaunchKernelGGL((np_level_init_k<VF>), dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, p.V,
-                       p.E, p.F, p.pairs, n, p.tol, use_ms, data, c->np_scratch1.as<LvlDomain>());
-    long long n_cur = n;
-    DevBuf* cur = &c->np_scratch1;
-    DevBuf* nxt = &c->np_scratch2;
-    while (n_cur > 0) { // root_finder.cu:431-447
-        nxt->ensure(sizeof(LvlDomain) * (size_t)(2 * n_cur));
-        SCCD_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream));
-        const dim3 grid((unsigned)((n_cur + TPB - 1) / TPB));
-        if (p.arith == 1)
-            hipLaunchKernelGGL((np_level_k<VF, 1>), grid, dim3(TPB), 0, c->stream, cur->as<LvlDomain>(), n_cur,
-                               nxt->as<LvlDomain>(), d_n, data, p.ms, p.tol, p.max_iter, (bool)p.allow_zero_toi,
-                               d_per_query_toi != nullptr, d_cnt);
-        else
-            hipLaunchKernelGGL((np_level_k<VF, 0>), grid, dim3(TPB), 0, c->stream, cur->as<LvlDomain>(), n_cur,
-                               nxt->as<LvlDomain>(), d_n, data, p.ms, p.tol, p.max_iter, (bool)p.allow_zero_toi,
-                               d_per_query_toi != nullptr, d_cnt);
-        SCCD_HIP(hipGetLastError());
-        unsigned long long h_n = 0;
-        SCCD_HIP(hipMemcpyAsync(&h_n, d_n, sizeof h_n, hipMemcpyDeviceToHost, c->stream));
-        SCCD_HIP(hipStreamSynchronize(c->stream));
-        n_cur = (long long)h_n;
-        std::swap(cur, nxt);
+    // Level order keeps every live domain of a level in HBM, and a contact-rich scene doubles them
+    // level after level.  The queries are therefore taken in slices (the reference batches too,
+    // narrow_phase.cu:141-200): a slice whose level would not fit the budget is started again at
+    // half the size -- what it found so far stays valid (accepted domains only ever lower a TOI).
+    size_t free_b = 0, total_b = 0;
+    SCCD_HIP(hipMemGetInfo(&free_b, &total_b));
+    // (8 GB per level buffer = 1.4e8 live domains: beyond that a slice is cut; 4096 queries that still need
+    // more are hopeless in level order, and failing early beats filling 288 GB first)
+    const size_t budget = std::min<size_t>((size_t)8 << 30,
+                                           std::max<size_t>((free_b + c->np_scratch1.cap + c->np_scratch2.cap) / 3, (size_t)64 << 20));
+    long long slice = n;
+    for (long long q0 = 0; q0 < n;) {
+        const long long len = std::min(slice, n - q0);
+        c->np_scratch1.ensure(sizeof(LvlDomain) * (size_t)len);
+        hipLaunchKernelGGL((np_level_init_k<VF>), dim3((unsigned)((len + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, p.V,
+                           p.E, p.F, p.pairs, q0, len, p.tol, use_ms, data, c->np_scratch1.as<LvlDomain>());
+        long long n_cur = len;
+        DevBuf* cur = &c->np_scratch1;
+        DevBuf* nxt = &c->np_scratch2;
+        bool fits = true;
+        while (n_cur > 0) { // root_finder.cu:431-447
+            if (sizeof(LvlDomain) * (size_t)(2 * n_cur) > budget) {
+                // (a single contact-rich query can have ~(1/tolerance)^2 live domains in level order: no
+                // slice size helps then.  The depth-first work-queue kernel, or a check limit, is the way out.)
+                if (len <= 4096)
+                    throw SccdError { SCCD_E_NOMEM, "level-synchronous narrow phase: the live domains of one level exceed the memory budget" };
+                fits = false;
+                break;
+            }
+            nxt->ensure(sizeof(LvlDomain) * (size_t)(2 * n_cur));
+            SCCD_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream));
+            const dim3 grid((unsigned)((n_cur + TPB - 1) / TPB));
+            if (p.arith == 1)
+                hipLaunchKernelGGL((np_level_k<VF, 1>), grid, dim3(TPB), 0, c->stream, cur->as<LvlDomain>(), n_cur,
+                                   nxt->as<LvlDomain>(), d_n, data, p.ms, p.tol, p.max_iter, (bool)p.allow_zero_toi,
+                                   d_per_query_toi != nullptr, d_cnt);
+            else
+                hipLaunchKernelGGL((np_level_k<VF, 0>), grid, dim3(TPB), 0, c->stream, cur->as<LvlDomain>(), n_cur,
+                                   nxt->as<LvlDomain>(), d_n, data, p.ms, p.tol, p.max_iter, (bool)p.allow_zero_toi,
+                                   d_per_query_toi != nullptr, d_cnt);
+            SCCD_HIP(hipGetLastError());
+            unsigned long long h_n = 0;
+            SCCD_HIP(hipMemcpyAsync(&h_n, d_n, sizeof h_n, hipMemcpyDeviceToHost, c->stream));
+            SCCD_HIP(hipStreamSynchronize(c->stream));
+            n_cur = (long long)h_n;
+            std::swap(cur, nxt);
+        }
+        if (!fits) {
+            slice = std::max<long long>(4096, len / 8);
+            continue; // the same queries again, fewer at a time
+        }
+        q0 += len;
     }
     if (d_per_query_toi) {
         hipLaunchKernelGGL(np_copy_per_query_k, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, data,
