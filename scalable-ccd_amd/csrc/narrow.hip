@@ -134,6 +134,12 @@ __global__ void np_level_k(const LvlDomain* __restrict__ cur, long long n_cur, L
     }
 }
 
+__global__ void np_fill_u64_k(unsigned long long* __restrict__ p, long long n, unsigned long long v)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 __global__ void np_copy_per_query_k(const LvlData* __restrict__ data, long long n, double* __restrict__ out)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -239,13 +245,17 @@ void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
         // A check limit is exact only in the reference's level order.  Limits that no query comes near
         // (the IPC Toolkit passes 1e7) run on the work-queue kernel, which counts per query and hands the
         // whole call to the level-synchronous kernel if any query does get there; small limits go there directly.
-        const bool level_sync = c->narrow_algo == 1 || d_per_query_toi != nullptr
-            || (p.max_iter >= 0 && p.max_iter < SCCD_QUEUE_MIN_MAX_ITER);
+        const bool level_sync = c->narrow_algo == 1 || (p.max_iter >= 0 && p.max_iter < SCCD_QUEUE_MIN_MAX_ITER);
         if (level_sync) {
             if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi);
             else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi);
         } else {
-            run_queue(c, p, d_cnt, n);
+            if (d_per_query_toi) { // every query starts at +inf (narrow_phase.cu:70)
+                hipLaunchKernelGGL(np_fill_u64_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                                   reinterpret_cast<unsigned long long*>(d_per_query_toi), n, 0x7FF0000000000000ull);
+                SCCD_HIP(hipGetLastError());
+            }
+            run_queue(c, p, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi));
         }
     }
     {
@@ -279,8 +289,8 @@ void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
         std::memset(&h2, 0, sizeof h2);
         std::memcpy(&h2.toi_bits, h_toi_inout, 8);
         SCCD_HIP(hipMemcpyAsync(d_cnt, &h2, sizeof h2, hipMemcpyHostToDevice, c->stream));
-        if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, nullptr);
-        else run_level_sync<false>(c, p, d_cnt, n, nullptr);
+        if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi);
+        else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi);
         SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
         SCCD_HIP(hipStreamSynchronize(c->stream));
         if (h.overflow) throw SccdError { SCCD_E_OVERFLOW, "narrow phase: work queue capacity exhausted" };

@@ -469,18 +469,26 @@ def test_narrow_phase_known_answers(sccd, ctx):
     assert sccd.narrow_phase(mesh, [[0, 0]], True) == 1.0
 
 
-def test_per_query_collisions(sccd, ctx, orc):
-    V0, V1, E, F = scenes.triangle_soup(120, seed=6)
+@pytest.mark.parametrize("algo", [0, 1])  # work-queue kernel (per-lane bound, atomicMin per query), level order
+@pytest.mark.parametrize("is_vf", [True, False])
+def test_per_query_collisions(sccd, ctx, orc, algo, is_vf):
+    """SCALABLE_CCD_TOI_PER_QUERY: (aid, bid, toi) of every query with toi < 1; a query is pruned by
+    its own earliest impact only (root_finder.cu:297), so every value is the oracle's, bit for bit."""
+    V0, V1, E, F = scenes.triangle_soup(300, seed=6, size=0.12, motion=0.35)
     vb, eb, fb = orc.build_boxes(V0, V1, E, F)
-    vf, _, _ = orc.sort_and_sweep(vb, fb)
-    want_t, want_pq, _ = orc.narrow_phase(V0, V1, E, F, vf, True, per_query=True)
+    pairs, _, _ = orc.sort_and_sweep(vb, fb) if is_vf else orc.sort_and_sweep(eb)
+    want_t, want_pq, _ = orc.narrow_phase(V0, V1, E, F, pairs, is_vf, per_query=True)
     mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
-    t, col = sccd.narrow_phase(mesh, vf, True, want_collisions=True)
+    try:
+        ctx.set_option(sccd.OPT_NARROW_ALGO, algo)
+        t, col = sccd.narrow_phase(mesh, pairs, is_vf, want_collisions=True)
+    finally:
+        ctx.set_option(sccd.OPT_NARROW_ALGO, 0)
     assert t == want_t
     hits = want_pq < 1
-    assert len(col) == hits.sum()
+    assert hits.sum() > 10 and len(col) == hits.sum()
     got = {(int(a), int(b)): float(x) for a, b, x in zip(col["aid"], col["bid"], col["toi"])}
-    for (a, b), x in zip(vf[hits], want_pq[hits]):
+    for (a, b), x in zip(pairs[hits], want_pq[hits]):
         assert got[(int(a), int(b))] == x
     assert all(t <= x for x in got.values())  # tests/test_narrow_phase.cu:60-62
 
