@@ -287,6 +287,39 @@ inline Scalar ccd(const MatrixXdView& vertices_t0, const MatrixXdView& vertices_
     return toi;
 }
 
+/// ccd() of a SCALABLE_CCD_TOI_PER_QUERY build (ccd.cuh:26-38 with the `collisions` argument, ccd.cu:14-78):
+/// also returns (aid, bid, toi) of every query with toi < 1 -- vertex-face pairs first, then edge-edge.
+inline Scalar ccd(const MatrixXdView& vertices_t0, const MatrixXdView& vertices_t1, const MatrixXiView& edges,
+                  const MatrixXiView& faces, const Scalar minimum_separation_distance, const int max_iterations,
+                  const Scalar tolerance, const bool allow_zero_toi,
+                  std::vector<std::tuple<int, int, Scalar>>& collisions, const int memory_limit_GB = 0,
+                  Context& ctx = Context::default_context())
+{
+    collisions.clear();
+    DeviceMesh mesh(vertices_t0, vertices_t1, edges, faces, ctx);
+    std::vector<AABB> vertex_boxes, edge_boxes, face_boxes;
+    build_vertex_boxes(vertices_t0, vertices_t1, vertex_boxes, minimum_separation_distance, ctx); // ccd.cu:112
+    build_edge_boxes(vertex_boxes, edges, edge_boxes, ctx);
+    build_face_boxes(vertex_boxes, faces, face_boxes, ctx);
+    const int64_t saved = sccd_get_option(ctx.get(), SCCD_OPT_MEMORY_LIMIT_MB);
+    if (memory_limit_GB > 0) ctx.set_option(SCCD_OPT_MEMORY_LIMIT_MB, (int64_t)memory_limit_GB * 1024);
+    Scalar toi = 1; // ccd.cu:125
+    try {
+        BroadPhase broad_phase(ctx);
+        broad_phase.build(std::make_shared<DeviceAABBs>(vertex_boxes, ctx), std::make_shared<DeviceAABBs>(face_boxes, ctx));
+        narrow_phase<true>(mesh, broad_phase.detect_overlaps(), max_iterations, tolerance, minimum_separation_distance,
+                           allow_zero_toi, toi, &collisions);
+        broad_phase.build(std::make_shared<DeviceAABBs>(edge_boxes, ctx));
+        narrow_phase<false>(mesh, broad_phase.detect_overlaps(), max_iterations, tolerance, minimum_separation_distance,
+                            allow_zero_toi, toi, &collisions);
+    } catch (...) {
+        ctx.set_option(SCCD_OPT_MEMORY_LIMIT_MB, saved);
+        throw;
+    }
+    ctx.set_option(SCCD_OPT_MEMORY_LIMIT_MB, saved);
+    return toi;
+}
+
 /// ipc_ccd_strategy() (ipc_ccd_strategy.hpp:17-24).
 inline Scalar ipc_ccd_strategy(const MatrixXdView& V0, const MatrixXdView& V1, const MatrixXiView& E,
                                const MatrixXiView& F, const Scalar min_distance, const int max_iter,

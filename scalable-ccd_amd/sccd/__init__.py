@@ -417,9 +417,14 @@ def narrow_phase(mesh, overlaps, is_vf, max_iter=-1, tol=1e-6, ms=0.0, allow_zer
     return t.value, col
 
 
-def ccd(V0, V1, E, F, min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow_zero_toi=True, memory_limit_GB=0, ctx=None):
-    """scalable_ccd::cuda::ccd() of ccd.cuh:26-38: earliest time of impact in [0,1] (1 = none)."""
+def ccd(V0, V1, E, F, min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow_zero_toi=True, memory_limit_GB=0, ctx=None,
+        want_collisions=False):
+    """scalable_ccd::cuda::ccd() of ccd.cuh:26-38: earliest time of impact in [0,1] (1 = none).
+    want_collisions: the SCALABLE_CCD_TOI_PER_QUERY signature -- returns (toi, collisions) with
+    the (aid, bid, toi) records of the vertex-face pass followed by those of the edge-edge pass."""
     ctx = ctx or default_context()
+    if want_collisions:
+        return _ccd_collisions(V0, V1, E, F, min_distance, max_iterations, tolerance, allow_zero_toi, memory_limit_GB, ctx)
     V0c, V1c, Ec, Fc = _f64cm(V0), _f64cm(V1), _i32cm(E), _i32cm(F)
     if V0c.ndim != 2 or V0c.shape[1] != 3 or V0c.shape != V1c.shape:
         raise RuntimeError("V0, V1 must both be n x 3")
@@ -433,6 +438,29 @@ def ccd(V0, V1, E, F, min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow
         _ptr(Fc) if nF else None, C.c_int(nF), C.c_double(min_distance), C.c_int(max_iterations),
         C.c_double(tolerance), C.c_int(int(allow_zero_toi)), C.c_int(memory_limit_GB), C.byref(t)))
     return t.value
+
+
+def _ccd_collisions(V0, V1, E, F, min_distance, max_iterations, tolerance, allow_zero_toi, memory_limit_GB, ctx):
+    """ccd.cu:14-78 with the per-query list: both passes through the public pieces."""
+    saved = ctx.get_option(OPT_MEMORY_LIMIT_MB)
+    if memory_limit_GB > 0:
+        ctx.set_option(OPT_MEMORY_LIMIT_MB, int(memory_limit_GB) * 1024)
+    mesh = Mesh(V0, V1, E, F, ctx=ctx)
+    bp = BroadPhase(ctx)
+    try:
+        vb, eb, fb = DeviceAABBs.from_mesh(mesh, min_distance)
+        toi, out = 1.0, []
+        for is_vf, a, b in ((True, vb, fb), (False, eb, None)):
+            bp.build(a, b)
+            ov = bp.detect_overlaps()
+            toi, col = narrow_phase(mesh, ov, is_vf, max_iterations, tolerance, min_distance, allow_zero_toi, toi,
+                                    want_collisions=True)
+            out.append(col)
+        return toi, np.concatenate(out)
+    finally:
+        bp.close()
+        mesh.close()
+        ctx.set_option(OPT_MEMORY_LIMIT_MB, saved)
 
 
 def ccd_mesh(mesh, min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow_zero_toi=True, want_stats=False):

@@ -187,6 +187,22 @@ int main()
     for (const auto& [i, j, _toi] : collisions) CHECK(t2 <= _toi); // tests/test_narrow_phase.cu:60-62
     narrow_phase<false>(mesh, ee_overlaps, max_iterations, tolerance, min_distance, allow_zero_toi, t2);
     CHECK(t2 == toi);
+    {
+        // ccd() with the per-query list (the TOI_PER_QUERY build's signature): same TOI, the union of both passes' lists
+        std::vector<std::tuple<int, int, Scalar>> all, vf_only;
+        const Scalar t3 = ccd(vertices_t0, vertices_t1, edges, faces, min_distance, max_iterations, tolerance, allow_zero_toi, all);
+        CHECK(t3 == toi);
+        Scalar t4 = 1;
+        narrow_phase<true>(mesh, vf_overlaps, max_iterations, tolerance, min_distance, allow_zero_toi, t4, &vf_only);
+        std::vector<std::tuple<int, int, Scalar>> ee_only;
+        Scalar t5 = 1; // (per query: no pruning by the running minimum, so the seed does not matter)
+        narrow_phase<false>(mesh, ee_overlaps, max_iterations, tolerance, min_distance, allow_zero_toi, t5, &ee_only);
+        CHECK(all.size() == vf_only.size() + ee_only.size());
+        CHECK(!all.empty());
+        Scalar mn = 1;
+        for (const auto& [i, j, _t] : all) mn = _t < mn ? _t : mn;
+        CHECK(mn == toi);
+    }
 
     threw = false;
     try {

@@ -740,3 +740,23 @@ def test_full_size_sharded_passes_reduce_to_the_same_toi(sccd, ctx, cloth1m):
         ctx.set_option(sccd.OPT_SHARD_RANK, 0)
     assert n_pairs == G["n_vf"] + G["n_ee"]
     assert toi == float.fromhex(G["toi_strict"])
+
+
+def test_ccd_with_collisions(sccd, ctx, orc):
+    """ccd() of a TOI_PER_QUERY build (ccd.cu:14-78 with `collisions`): vertex-face records, then
+    edge-edge; the running minimum of the list is the returned TOI, bit for bit."""
+    V0, V1, E, F = scenes.cloth_ball(20, 1, seed=3)
+    toi, col = sccd.ccd(V0, V1, E, F, 0.0, -1, 1e-6, True, ctx=ctx, want_collisions=True)
+    assert toi == sccd.ccd(V0, V1, E, F, 0.0, -1, 1e-6, True, ctx=ctx)
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F)
+    want = []
+    for is_vf, sweep in ((True, orc.sort_and_sweep(vb, fb)), (False, orc.sort_and_sweep(eb))):
+        pairs = sweep[0]
+        _, pq, _ = orc.narrow_phase(V0, V1, E, F, pairs, is_vf, per_query=True)
+        hit = pq < 1.0
+        want.append(sorted((int(a), int(b), float(t)) for (a, b), t in zip(np.asarray(pairs)[hit], pq[hit])))
+    n_vf = len(want[0])
+    got_vf = sorted((int(r["aid"]), int(r["bid"]), float(r["toi"])) for r in col[:n_vf])
+    got_ee = sorted((int(r["aid"]), int(r["bid"]), float(r["toi"])) for r in col[n_vf:])
+    assert got_vf == want[0] and got_ee == want[1]
+    assert len(col) and min(float(r["toi"]) for r in col) == toi
