@@ -224,8 +224,9 @@ template <bool VF> __device__ __forceinline__ void ti_error(const double v[8][3]
 // origin_in_inclusion_function (root_finder.cu:157-198) with calculate_vf / calculate_ee
 // (:137-155).  The reference evaluates all eight corners from scratch; the values that do not
 // depend on u or v are computed once per t here -- the same operations on the same operands,
-// hence the same bits.
-template <bool VF, int ARITH>
+// hence the same bits.  DIFF: v[4..7] already hold the displacements v_e - v_s (np_queue_k computes
+// them once per query instead of once per check).
+template <bool VF, int ARITH, bool DIFF = false>
 __device__ __forceinline__ bool ti_inclusion(const double v[8][3], const double lo[3], const double hi[3],
                                              const double err[3], double ms, double& true_tol, bool& box_in)
 {
@@ -237,16 +238,18 @@ __device__ __forceinline__ bool ti_inclusion(const double v[8][3], const double 
         for (int it = 0; it < 2; it++) {
             const double t = it ? hi[0] : lo[0];
             double a0, a1, a2, a3; // the four vertices at time t
+            const double e0 = DIFF ? v[4][k] : v[4][k] - v[0][k], e1 = DIFF ? v[5][k] : v[5][k] - v[1][k],
+                         e2 = DIFF ? v[6][k] : v[6][k] - v[2][k], e3 = DIFF ? v[7][k] : v[7][k] - v[3][k];
             if (ARITH == 1) {
-                a0 = __builtin_fma(v[4][k] - v[0][k], t, v[0][k]);
-                a1 = __builtin_fma(v[5][k] - v[1][k], t, v[1][k]);
-                a2 = __builtin_fma(v[6][k] - v[2][k], t, v[2][k]);
-                a3 = __builtin_fma(v[7][k] - v[3][k], t, v[3][k]);
+                a0 = __builtin_fma(e0, t, v[0][k]);
+                a1 = __builtin_fma(e1, t, v[1][k]);
+                a2 = __builtin_fma(e2, t, v[2][k]);
+                a3 = __builtin_fma(e3, t, v[3][k]);
             } else {
-                a0 = (v[4][k] - v[0][k]) * t + v[0][k];
-                a1 = (v[5][k] - v[1][k]) * t + v[1][k];
-                a2 = (v[6][k] - v[2][k]) * t + v[2][k];
-                a3 = (v[7][k] - v[3][k]) * t + v[3][k];
+                a0 = e0 * t + v[0][k];
+                a1 = e1 * t + v[1][k];
+                a2 = e2 * t + v[2][k];
+                a3 = e3 * t + v[3][k];
             }
             if (VF) { // v - (t1 - t0)*u - (t2 - t0)*v - t0   with v=a0, t0=a1, t1=a2, t2=a3
                 const double d1 = a2 - a1, d2 = a3 - a1;
