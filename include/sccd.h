@@ -74,7 +74,7 @@ int sccd_synchronize(sccd_ctx* ctx);
 #define SCCD_OPT_SHARD_RANK 5       /* multi-GPU: this rank's index ...                                                  */
 #define SCCD_OPT_SHARD_COUNT 6      /* ... of this many ranks; a rank sorts and sweeps only its window of grid cells      */
 #define SCCD_OPT_OVERLAP_CAPACITY 7 /* initial overlap buffer capacity in pairs (0 = automatic)                           */
-#define SCCD_OPT_PROFILE 8          /* 1: record hipEvents around every kernel class (sccd_get_profile)                   */
+#define SCCD_OPT_PROFILE 8          /* hipEvents around kernel classes (sccd_get_profile): 1 = all, (class mask) << 1 = some  */
 #define SCCD_OPT_MAX_OVERLAP_CUTOFF 9 /* boxes swept per detect_overlaps_partial call (0 = all; memory_handler.hpp:9)      */
 #define SCCD_OPT_MEMORY_LIMIT_MB 10 /* memory budget of the overlap list in MiB (0 = none; MemoryHandler::memory_limit_GB)  */
 int sccd_set_option(sccd_ctx* ctx, int option, int64_t value);

@@ -156,7 +156,7 @@ int sccd_set_option(sccd_ctx* c, int opt, int64_t v)
         c->shard_count = (int)v;
         break;
     case SCCD_OPT_OVERLAP_CAPACITY: c->overlap_capacity = v; break;
-    case SCCD_OPT_PROFILE: c->profile = v ? 1 : 0; break;
+    case SCCD_OPT_PROFILE: c->profile = (int)v; break; // 0 off, 1 every class, else (mask of classes) << 1
     case SCCD_OPT_MAX_OVERLAP_CUTOFF: c->max_overlap_cutoff = v; break;
     case SCCD_OPT_MEMORY_LIMIT_MB: c->memory_limit_mb = v; break;
     default: c->err = "unknown option"; return SCCD_E_INVALID;

@@ -112,7 +112,9 @@ struct SweepCounters { // lives in device memory (ctx->scalars)
     unsigned int tile_ticket;      // (unused: tiles are dealt statically)
     unsigned int pad;
     unsigned long long cand_parts[32]; // sum of (end-start) over the rows, spread to avoid one hot word
+    unsigned long long pad2[29];       // 512 bytes: hipMemsetAsync clears an aligned size with ONE fill kernel (280 B took two)
 };
+static_assert(sizeof(SweepCounters) == 512, "SweepCounters: keep the size a multiple of 256 bytes");
 // ranges for rows of `rows` against columns `cols` (see sweep.hip for the three modes)
 void launch_ranges(sccd_ctx* c, const SortedList* rows, const SortedList* cols, int mode, uint2* ranges,
                    unsigned long long* d_candidates);
