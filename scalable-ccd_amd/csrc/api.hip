@@ -590,6 +590,14 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
 
     bp->grid.ensure(4096 + sizeof(uint32_t) * SCCD_MAX_CELLS); // (unused) | params @512 | cell histogram @4096
     GridParams* gp = reinterpret_cast<GridParams*>(bp->grid.as<char>() + 512);
+    // the two list totals sit right behind the grid parameters: ONE copy brings both back (two copies in a
+    // row cost a 12 us bubble between them)
+    struct GridReadBack {
+        GridParams gp;
+        uint32_t total[2];
+    };
+    uint32_t* d_total = reinterpret_cast<uint32_t*>(bp->grid.as<char>() + 512 + offsetof(GridReadBack, total));
+    static_assert(512 + sizeof(GridReadBack) <= 4096, "grid buffer layout");
     int axis = c->sort_axis;
     if (axis < 0) axis = pick_sort_axis(c, A->raw.as<sccd_aabb>(), A->n);
     {
@@ -606,7 +614,7 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     for (int shrink = 0;; shrink++) {
         launch_grid_setup(c, A->stats_head(), A->stats_part(), A->n_part, B ? B->stats_head() : nullptr,
                           B ? B->stats_part() : nullptr, B ? B->n_part : 0, n_total, axis, cf, shrink, gp,
-                          reinterpret_cast<uint32_t*>(c->scalars.as<char>() + 1536));
+                          d_total);
         const bool can_shrink = shrink < 10;
         // Multi-GPU: every rank takes a contiguous window of cells with an equal share of the
         // entries, and builds / sorts / sweeps only that window.  A pair is reported from exactly
@@ -644,7 +652,15 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                 bp->row_shard = true; // (almost) one cell: every rank sorts everything and takes a slice of the rows
             }
         }
-        uint32_t* d_total = reinterpret_cast<uint32_t*>(c->scalars.as<char>() + 1536);
+        auto read_totals = [&](uint32_t (&total)[2], GridParams& hgp) {
+            GridReadBack g;
+            ReadBack rb(c);
+            rb.add(&g, gp, sizeof g);
+            rb.sync();
+            hgp = g.gp;
+            total[0] = g.total[0];
+            total[1] = g.total[1];
+        };
         const bool windowed_build = c->shard_count > 1 && !bp->row_shard;
         // SCCD_BUILD=scan selects count -> device-wide prefix scan -> fill (entries in box order: a
         // reproducible entry order, 0.15 ms slower per step on the 1M-triangle cloth)
@@ -679,10 +695,7 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                 }
                 {
                     ProfScope ps(c, SCCD_PROF_SORT);
-                    ReadBack rb(c);
-                    rb.add(total, d_total, sizeof(uint32_t) * 2);
-                    rb.add(&hgp, gp, sizeof hgp);
-                    rb.sync();
+                    read_totals(total, hgp);
                 }
                 const unsigned long long need = std::max<unsigned long long>(total[0], B ? total[1] : 0);
                 if (need <= cap) break;
@@ -703,10 +716,7 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
         GridParams hgp;
         {
             ProfScope ps(c, SCCD_PROF_SORT);
-            ReadBack rb(c);
-            rb.add(total, d_total, sizeof(uint32_t) * (B ? 2 : 1));
-            rb.add(&hgp, gp, sizeof hgp);
-            rb.sync();
+            read_totals(total, hgp);
         }
         // replication into cells beyond the budget: coarsen the grid (decided per list, whole grid only)
         const bool windowed = bp->cell_lo > 0 || bp->cell_hi < (1 << 30);
@@ -1015,6 +1025,7 @@ static void ccd_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, bool vf, dou
     if (vf) bp_build(&pl->bp, &pl->vb, &pl->fb);
     else bp_build(&pl->bp, &pl->eb, nullptr);
     while (pl->bp.cursor < pl->bp.total_rows) {
+        narrow_counters_upload(c, narrow_counters(c), *toi); // ahead of the sweep: one copy less between sweep and narrow phase
         bp_detect_partial(&pl->bp);
         const NarrowResult r = run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, vf ? 1 : 0, max_iter,
                                           tol, ms, allow_zero_toi, toi, nullptr);

@@ -101,6 +101,10 @@ struct sccd_ctx {
     int shard_count = 1;
     int64_t overlap_capacity = 0;
     int profile = 0;
+    // narrow_counters_upload() already put {zeros, this TOI} into the narrow phase's counters (it rides ahead of
+    // the sweep in ccd(), so that the narrow kernel can start right behind the sweep's read-back)
+    bool np_uploaded = false;
+    double np_uploaded_toi = 0;
     int64_t max_overlap_cutoff = 0;
     int64_t memory_limit_mb = 0;
 

@@ -137,6 +137,8 @@ struct NarrowParams {
     int allow_zero_toi;
     int arith;
 };
+struct NarrowCounters;
+void narrow_counters_upload(sccd_ctx* c, NarrowCounters* d_cnt, double toi);
 struct NarrowCounters {
     // The three hot words sit on separate 128-byte lines: sharing one line, the ticket atomics
     // queued behind every wave's TOI polls and cost tens of microseconds each.

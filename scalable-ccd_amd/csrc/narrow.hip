@@ -219,6 +219,17 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
 
 #include "narrow_queue.inc"
 
+// counters = {zeros, toi}: from the pinned mirror [12 KB, 16 KB)
+void narrow_counters_upload(sccd_ctx* c, NarrowCounters* d_cnt, double toi)
+{
+    NarrowCounters* const h_up = reinterpret_cast<NarrowCounters*>(c->h_scalars.as<char>() + 12288);
+    std::memset(h_up, 0, sizeof(NarrowCounters));
+    std::memcpy(&h_up->toi_bits, &toi, 8);
+    SCCD_HIP(hipMemcpyAsync(d_cnt, h_up, sizeof(NarrowCounters), hipMemcpyHostToDevice, c->stream));
+    c->np_uploaded = true;
+    c->np_uploaded_toi = toi;
+}
+
 void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
                       double* d_per_query_toi)
 {
@@ -226,10 +237,8 @@ void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
     SCCD_REQUIRE(*h_toi_inout >= 0, "narrow_phase: toi must be >= 0");
     // pinned mirror: [8 KB, 12 KB) the counters handed to the caller, [12 KB, 16 KB) the upload source
     NarrowCounters h;
-    NarrowCounters* const h_up = reinterpret_cast<NarrowCounters*>(c->h_scalars.as<char>() + 12288);
-    std::memset(h_up, 0, sizeof h);
-    std::memcpy(&h_up->toi_bits, h_toi_inout, 8);
-    SCCD_HIP(hipMemcpyAsync(d_cnt, h_up, sizeof h, hipMemcpyHostToDevice, c->stream));
+    if (!(c->np_uploaded && std::memcmp(&c->np_uploaded_toi, h_toi_inout, 8) == 0)) narrow_counters_upload(c, d_cnt, *h_toi_inout);
+    c->np_uploaded = false;
     // the reference's outer loop runs only while toi > 0 (narrow_phase.cu:136); in the
     // per-query build the guard is absent (:138)
     const bool run = (*h_toi_inout > 0) || d_per_query_toi != nullptr;
