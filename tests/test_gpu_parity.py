@@ -760,3 +760,21 @@ def test_ccd_with_collisions(sccd, ctx, orc):
     got_ee = sorted((int(r["aid"]), int(r["bid"]), float(r["toi"])) for r in col[n_vf:])
     assert got_vf == want[0] and got_ee == want[1]
     assert len(col) and min(float(r["toi"]) for r in col) == toi
+
+
+@pytest.mark.parametrize("tol", [1e-9, 1e-11, 1e-13])
+def test_bisection_deeper_than_the_compressed_entries(sccd, ctx, orc, tol):
+    """The work-queue kernel holds an interval as (numerator, level <= 31); a tolerance that needs deeper
+    bisection makes it hand the call to the level-synchronous kernel (NQ_OVF_INTERVAL) -- same bits either way."""
+    V0 = np.array([[0.3, 0.3, 0.7], [0, 0, 0], [1, 0, 0], [0, 1, 0], [0.1, 0.2, 0.9], [0.9, 0.2, 0.8]], float)
+    V1 = V0.copy()
+    V1[0, 2] = -0.45
+    V1[4] = [0.15, 0.25, -0.3]
+    V1[5] = [0.85, 0.15, -0.2]
+    E = np.array([[1, 2], [2, 3], [1, 3], [4, 5]], np.int32)
+    F = np.array([[1, 2, 3]], np.int32)
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    for is_vf, pairs in ((True, [[0, 0], [4, 0], [5, 0]]), (False, [[0, 3], [1, 3], [2, 3]])):
+        want, _, _ = orc.narrow_phase(V0, V1, E, F, pairs, is_vf, tol=tol)
+        got = sccd.narrow_phase(mesh, pairs, is_vf, tol=tol)
+        assert got == want and got < 1.0
