@@ -107,9 +107,14 @@ def main():
         params = dict(min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow_zero_toi=True)
 
         def step():
-            return sdist.ccd_sharded(
-                lambda is_vf, toi: sccd.ccd_mesh_pass(mesh, is_vf, toi, **params),
-                rank, world, device=red_dev, prepare=lambda: sccd.ccd_mesh_prepare(mesh, 0.0))
+            # one ccd() per rank on its shard of the cell grid (SHARD_RANK / SHARD_COUNT options of the context),
+            # then ONE all-reduce(min) of the 8-byte TOI; SCCD_BENCH_SPLIT=1 runs the pass-by-pass protocol instead
+            if os.environ.get("SCCD_BENCH_SPLIT") == "1":
+                return sdist.ccd_sharded(
+                    lambda is_vf, toi: sccd.ccd_mesh_pass(mesh, is_vf, toi, **params),
+                    rank, world, device=red_dev, prepare=lambda: sccd.ccd_mesh_prepare(mesh, 0.0))
+            t, st = sccd.ccd_mesh(mesh, want_stats=True, **params)
+            return sdist.allreduce_min(t, device=red_dev), st
 
         # Warm-up, then two more untimed steps with hipEvents around EVERY kernel class: the per-class breakdown,
         # and which class dominates.  The timed region keeps events on that one class only -- two event records

@@ -108,6 +108,8 @@ void sccd_destroy(sccd_ctx* c)
     sccd_collect_profile(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->rb_event) (void)hipEventDestroy(c->rb_event);
+    if (c->side_event) (void)hipEventDestroy(c->side_event);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -938,15 +940,14 @@ struct NarrowResult {
     unsigned long long n_checks;
 };
 
-static NarrowResult run_narrow(sccd_ctx* c, const sccd_mesh* m, const int2* d_pairs, int64_t n, int is_vf, int max_iter,
-                               double tol, double ms, int allow_zero_toi, double* toi, double* d_per_query)
+static NarrowParams narrow_params(sccd_ctx* c, const sccd_mesh* m, const int2* d_pairs, int64_t n, int is_vf, int max_iter,
+                                  double tol, double ms, int allow_zero_toi)
 {
     NarrowParams p;
     p.V = m->V.as<double>();
     p.E = m->E.as<int2>();
     p.F = m->F.as<int4>();
     p.pairs = d_pairs;
-    p.d_npairs = nullptr;
     p.n_pairs = n;
     p.is_vf = is_vf;
     p.max_iter = max_iter;
@@ -954,10 +955,20 @@ static NarrowResult run_narrow(sccd_ctx* c, const sccd_mesh* m, const int2* d_pa
     p.ms = ms;
     p.allow_zero_toi = allow_zero_toi;
     p.arith = c->arith;
-    narrow_phase_run(c, p, narrow_counters(c), toi, d_per_query);
+    return p;
+}
+static NarrowResult narrow_result(sccd_ctx* c)
+{
     NarrowCounters h;
     std::memcpy(&h, c->h_scalars.as<char>() + 8192, sizeof h);
     return NarrowResult { h.n_checks };
+}
+static NarrowResult run_narrow(sccd_ctx* c, const sccd_mesh* m, const int2* d_pairs, int64_t n, int is_vf, int max_iter,
+                               double tol, double ms, int allow_zero_toi, double* toi, double* d_per_query)
+{
+    const NarrowParams p = narrow_params(c, m, d_pairs, n, is_vf, max_iter, tol, ms, allow_zero_toi);
+    narrow_phase_run(c, p, narrow_counters(c), toi, d_per_query);
+    return narrow_result(c);
 }
 
 extern "C" int sccd_narrow_phase(sccd_ctx* c, const sccd_mesh* m, const int32_t* pairs, int64_t n, int pairs_on_device,
@@ -1020,9 +1031,10 @@ extern "C" int sccd_narrow_phase(sccd_ctx* c, const sccd_mesh* m, const int32_t*
 
 // partial_ccd<run_vf> (ccd.cu:14-78): build, then alternate detect_overlaps_partial / narrow_phase
 static void ccd_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, bool vf, double ms, int max_iter, double tol,
-                     int allow_zero_toi, double* toi, sccd_stats* st)
+                     int allow_zero_toi, double* toi, sccd_stats* st, bool built = false)
 {
-    if (vf) bp_build(&pl->bp, &pl->vb, &pl->fb);
+    if (built) {} // (ccd() built the lists already, on the side stream)
+    else if (vf) bp_build(&pl->bp, &pl->vb, &pl->fb);
     else bp_build(&pl->bp, &pl->eb, nullptr);
     while (pl->bp.cursor < pl->bp.total_rows) {
         narrow_counters_upload(c, narrow_counters(c), *toi); // ahead of the sweep: one copy less between sweep and narrow phase
@@ -1043,22 +1055,76 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
     Pipeline* pl = pipeline_of(c);
     if (st) std::memset(st, 0, sizeof *st);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (st && c->profile) {
+    if (st && c->profile == 1) {
         SCCD_HIP(hipEventCreate(&e0));
         SCCD_HIP(hipEventCreate(&e1));
         SCCD_HIP(hipEventRecord(e0, c->stream));
     }
     double before[SCCD_PROF_COUNT];
-    if (st && c->profile) {
+    if (st && c->profile == 1) {
         sccd_collect_profile(c);
         std::memcpy(before, c->prof_ms, sizeof before);
     }
     boxes_from_mesh(c, m, ms, pl, true, true, true); // inflation radius = min_distance (ccd.cu:112)
     double toi = 1; // ccd.cu:125
-    ccd_pass(c, m, pl, true, ms, max_iter, tol, allow_zero_toi, &toi, st);
-    ccd_pass(c, m, pl, false, ms, max_iter, tol, allow_zero_toi, &toi, st);
+    // The edge-edge lists do not depend on the vertex-face result: build them on a second stream while the
+    // vertex-face narrow phase (issue-bound, 2 waves/SIMD: it leaves wave slots and most of the HBM bandwidth free)
+    // still runs.  Only when the vertex-face pairs fit one sweep chunk; SCCD_OVERLAP=0 keeps the passes apart.
+    static const bool overlap_env = !(std::getenv("SCCD_OVERLAP") && std::atoi(std::getenv("SCCD_OVERLAP")) == 0);
+    bool overlapped = false;
+    if (overlap_env) {
+        bp_build(&pl->bp, &pl->vb, &pl->fb);
+        if (pl->bp.cursor < pl->bp.total_rows) {
+            narrow_counters_upload(c, narrow_counters(c), toi);
+            bp_detect_partial(&pl->bp);
+            if (st) st->n_vf_pairs += pl->bp.n_overlaps;
+            if (pl->bp.cursor >= pl->bp.total_rows) { // the whole list in one chunk
+                const NarrowParams p = narrow_params(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, 1, max_iter, tol,
+                                                     ms, allow_zero_toi);
+                if (st) st->n_vf_candidates = pl->bp.candidates;
+                narrow_phase_begin(c, p, narrow_counters(c), &toi, nullptr);
+                if (!c->side_stream) {
+                    SCCD_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+                    SCCD_HIP(hipEventCreateWithFlags(&c->side_event, hipEventDisableTiming));
+                }
+                hipStream_t const main_stream = c->stream;
+                c->stream = c->side_stream;
+                try {
+                    bp_build(&pl->bp, &pl->eb, nullptr); // (touches neither the pair list nor the narrow phase's buffers)
+                    SCCD_HIP(hipEventRecord(c->side_event, c->side_stream));
+                } catch (...) {
+                    c->stream = main_stream;
+                    (void)hipStreamSynchronize(c->side_stream);
+                    (void)hipStreamSynchronize(main_stream);
+                    throw;
+                }
+                c->stream = main_stream;
+                narrow_phase_end(c, p, narrow_counters(c), &toi, nullptr);
+                if (st) st->n_vf_checks += (int64_t)narrow_result(c).n_checks;
+                SCCD_HIP(hipStreamWaitEvent(c->stream, c->side_event, 0));
+                overlapped = true;
+            } else { // chunked: the plain loop for the rest
+                NarrowResult r = run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, 1, max_iter, tol, ms,
+                                            allow_zero_toi, &toi, nullptr);
+                if (st) st->n_vf_checks += (int64_t)r.n_checks;
+                while (pl->bp.cursor < pl->bp.total_rows) {
+                    bp_detect_partial(&pl->bp);
+                    r = run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, 1, max_iter, tol, ms, allow_zero_toi,
+                                   &toi, nullptr);
+                    if (st) {
+                        st->n_vf_pairs += pl->bp.n_overlaps;
+                        st->n_vf_checks += (int64_t)r.n_checks;
+                    }
+                }
+                if (st) st->n_vf_candidates = pl->bp.candidates;
+            }
+        }
+    } else {
+        ccd_pass(c, m, pl, true, ms, max_iter, tol, allow_zero_toi, &toi, st);
+    }
+    ccd_pass(c, m, pl, false, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/overlapped);
     *toi_out = toi;
-    if (st && c->profile) {
+    if (st && c->profile == 1) {
         SCCD_HIP(hipEventRecord(e1, c->stream));
         SCCD_HIP(hipEventSynchronize(e1));
         float msf = 0;

@@ -126,6 +126,9 @@ struct sccd_ctx {
     DevBuf tmp0, tmp1, tmp2;
     void* pipeline = nullptr; // cached pipeline objects (api.hip)
     hipEvent_t rb_event = nullptr; // ReadBack: polled, not waited for
+    // ccd(): the edge-edge lists are built on a second stream while the vertex-face narrow phase runs on `stream`
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_event = nullptr;
 };
 
 // RAII profile scope: records a hipEvent pair on the context's stream around a kernel class

@@ -128,8 +128,7 @@ struct NarrowParams {
     const int2* E;
     const int4* F;
     const int2* pairs;
-    const unsigned long long* d_npairs; // device-resident count (no host round trip) or nullptr
-    long long n_pairs;                  // used when d_npairs == nullptr
+    long long n_pairs;
     int is_vf;
     int max_iter;
     double tol;
@@ -169,5 +168,9 @@ struct NarrowCounters {
 static_assert(sizeof(NarrowCounters) <= 2048, "NarrowCounters must fit its slot of the scalars block");
 constexpr int SCCD_QUEUE_MIN_MAX_ITER = 4096; // smaller check limits are served by the level-synchronous kernel
 // runs the narrow phase on the stream; *toi in/out lives in d_cnt->toi_bits
+void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, const double* h_toi_inout,
+                        double* d_per_query_toi);
+void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
+                      double* d_per_query_toi);
 void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
                       double* d_per_query_toi);

@@ -230,25 +230,21 @@ void narrow_counters_upload(sccd_ctx* c, NarrowCounters* d_cnt, double toi)
     c->np_uploaded_toi = toi;
 }
 
-void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
-                      double* d_per_query_toi)
+// begin: upload the counters (unless narrow_counters_upload() already did) and launch; end: read the counters
+// back, handle the work-queue kernel's overflow flags, hand the TOI over.  Between the two the caller may enqueue
+// unrelated work on ANOTHER stream (ccd() builds the edge-edge lists while the vertex-face queries run).
+void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, const double* h_toi_inout,
+                        double* d_per_query_toi)
 {
     // toi is in/out and must be >= 0 (narrow_phase.cu:126)
     SCCD_REQUIRE(*h_toi_inout >= 0, "narrow_phase: toi must be >= 0");
     // pinned mirror: [8 KB, 12 KB) the counters handed to the caller, [12 KB, 16 KB) the upload source
-    NarrowCounters h;
     if (!(c->np_uploaded && std::memcmp(&c->np_uploaded_toi, h_toi_inout, 8) == 0)) narrow_counters_upload(c, d_cnt, *h_toi_inout);
     c->np_uploaded = false;
     // the reference's outer loop runs only while toi > 0 (narrow_phase.cu:136); in the
     // per-query build the guard is absent (:138)
     const bool run = (*h_toi_inout > 0) || d_per_query_toi != nullptr;
-    long long n = p.n_pairs;
-    if (p.d_npairs) {
-        unsigned long long hn = 0;
-        SCCD_HIP(hipMemcpyAsync(&hn, p.d_npairs, sizeof hn, hipMemcpyDeviceToHost, c->stream));
-        SCCD_HIP(hipStreamSynchronize(c->stream));
-        n = (long long)hn;
-    }
+    const long long n = p.n_pairs;
     if (run && n > 0) {
         ProfScope ps(c, p.is_vf ? SCCD_PROF_NARROW_VF : SCCD_PROF_NARROW_EE);
         // A check limit is exact only in the reference's level order.  Limits that no query comes near
@@ -267,6 +263,13 @@ void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
             run_queue(c, p, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi));
         }
     }
+}
+
+void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
+                      double* d_per_query_toi)
+{
+    NarrowCounters h;
+    const long long n = p.n_pairs;
     {
         ReadBack rb(c);
         rb.add(&h, d_cnt, sizeof h);
@@ -307,4 +310,11 @@ void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
     std::memcpy(h_toi_inout, &h.toi_bits, 8);
     // n_checks is read by the caller through d_cnt mirror
     std::memcpy(c->h_scalars.as<char>() + 8192, &h, sizeof h);
+}
+
+void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
+                      double* d_per_query_toi)
+{
+    narrow_phase_begin(c, p, d_cnt, h_toi_inout, d_per_query_toi);
+    narrow_phase_end(c, p, d_cnt, h_toi_inout, d_per_query_toi);
 }
