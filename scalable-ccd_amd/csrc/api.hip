@@ -7,7 +7,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <condition_variable>
+#include <exception>
+#include <functional>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 // ------------------------------------------------------------------------------------------
 // error trampolines
@@ -33,10 +38,73 @@ template <class Fn> static int guarded(sccd_ctx* c, Fn&& fn)
     }
 }
 
+// One persistent helper thread per context: ccd() hands it the construction of the edge-edge lists.
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, busy = false, quit = false;
+    std::exception_ptr err;
+    void submit(std::function<void()> f)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (!th.joinable()) th = std::thread([this] { loop(); });
+        job = std::move(f);
+        has_job = busy = true;
+        err = nullptr;
+        cv.notify_all();
+    }
+    void wait() // rethrows what the job threw
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this] { return !busy; });
+        if (err) {
+            std::exception_ptr e = err;
+            err = nullptr;
+            std::rethrow_exception(e);
+        }
+    }
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [this] { return has_job || quit; });
+                if (quit) return;
+                f = std::move(job);
+                has_job = false;
+            }
+            std::exception_ptr e;
+            try {
+                f();
+            } catch (...) {
+                e = std::current_exception();
+            }
+            std::unique_lock<std::mutex> lk(m);
+            err = e;
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    ~Worker()
+    {
+        {
+            std::unique_lock<std::mutex> lk(m);
+            quit = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
+};
+
 // pipeline objects cached in the context so that repeated ccd() calls allocate nothing
 struct Pipeline {
     sccd_boxes vb, eb, fb; // boxes in element order (raw)
     sccd_broad_phase bp;
+    sccd_broad_phase bp_ee; // edge-edge lists of ccd(): belongs to the helper context c->side
+    Worker worker;
 };
 static Pipeline* pipeline_of(sccd_ctx* c)
 {
@@ -109,7 +177,7 @@ void sccd_destroy(sccd_ctx* c)
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->rb_event) (void)hipEventDestroy(c->rb_event);
     if (c->side_event) (void)hipEventDestroy(c->side_event);
-    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->side) sccd_destroy(c->side);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -190,6 +258,16 @@ int sccd_get_profile(sccd_ctx* c, double ms[SCCD_PROF_COUNT], int64_t launches[S
     return guarded(c, [&] {
         SCCD_HIP(hipStreamSynchronize(c->stream));
         sccd_collect_profile(c);
+        if (c->side) { // what the helper context ran belongs to this one's account
+            SCCD_HIP(hipStreamSynchronize(c->side->stream));
+            sccd_collect_profile(c->side);
+            for (int k = 0; k < SCCD_PROF_COUNT; k++) {
+                c->prof_ms[k] += c->side->prof_ms[k];
+                c->prof_launches[k] += c->side->prof_launches[k];
+                c->side->prof_ms[k] = 0;
+                c->side->prof_launches[k] = 0;
+            }
+        }
         for (int k = 0; k < SCCD_PROF_COUNT; k++) {
             if (ms) ms[k] = c->prof_ms[k];
             if (launches) launches[k] = c->prof_launches[k];
@@ -206,6 +284,14 @@ int sccd_reset_profile(sccd_ctx* c)
         for (int k = 0; k < SCCD_PROF_COUNT; k++) {
             c->prof_ms[k] = 0;
             c->prof_launches[k] = 0;
+        }
+        if (c->side) {
+            SCCD_HIP(hipStreamSynchronize(c->side->stream));
+            sccd_collect_profile(c->side);
+            for (int k = 0; k < SCCD_PROF_COUNT; k++) {
+                c->side->prof_ms[k] = 0;
+                c->side->prof_launches[k] = 0;
+            }
         }
     });
 }
@@ -1030,23 +1116,25 @@ extern "C" int sccd_narrow_phase(sccd_ctx* c, const sccd_mesh* m, const int32_t*
 // drivers
 
 // partial_ccd<run_vf> (ccd.cu:14-78): build, then alternate detect_overlaps_partial / narrow_phase
-static void ccd_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, bool vf, double ms, int max_iter, double tol,
-                     int allow_zero_toi, double* toi, sccd_stats* st, bool built = false)
+// (bp may belong to the helper context: its sweeps then run on that context's stream; every sweep ends with a host
+// round trip, so the narrow phase on c->stream starts after the pairs are complete either way)
+static void ccd_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, sccd_broad_phase* bp, bool vf, double ms, int max_iter,
+                     double tol, int allow_zero_toi, double* toi, sccd_stats* st, bool built = false)
 {
-    if (built) {} // (ccd() built the lists already, on the side stream)
-    else if (vf) bp_build(&pl->bp, &pl->vb, &pl->fb);
-    else bp_build(&pl->bp, &pl->eb, nullptr);
-    while (pl->bp.cursor < pl->bp.total_rows) {
+    if (built) {} // (ccd() had the lists built already, by the helper)
+    else if (vf) bp_build(bp, &pl->vb, &pl->fb);
+    else bp_build(bp, &pl->eb, nullptr);
+    while (bp->cursor < bp->total_rows) {
         narrow_counters_upload(c, narrow_counters(c), *toi); // ahead of the sweep: one copy less between sweep and narrow phase
-        bp_detect_partial(&pl->bp);
-        const NarrowResult r = run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, vf ? 1 : 0, max_iter,
-                                          tol, ms, allow_zero_toi, toi, nullptr);
+        bp_detect_partial(bp);
+        const NarrowResult r = run_narrow(c, m, bp->overlaps.as<int2>(), bp->n_overlaps, vf ? 1 : 0, max_iter, tol, ms,
+                                          allow_zero_toi, toi, nullptr);
         if (st) {
-            (vf ? st->n_vf_pairs : st->n_ee_pairs) += pl->bp.n_overlaps;
+            (vf ? st->n_vf_pairs : st->n_ee_pairs) += bp->n_overlaps;
             (vf ? st->n_vf_checks : st->n_ee_checks) += (int64_t)r.n_checks;
         }
     }
-    if (st) (vf ? st->n_vf_candidates : st->n_ee_candidates) = pl->bp.candidates;
+    if (st) (vf ? st->n_vf_candidates : st->n_ee_candidates) = bp->candidates;
 }
 
 static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter, double tol, int allow_zero_toi,
@@ -1067,62 +1155,57 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
     }
     boxes_from_mesh(c, m, ms, pl, true, true, true); // inflation radius = min_distance (ccd.cu:112)
     double toi = 1; // ccd.cu:125
-    // The edge-edge lists do not depend on the vertex-face result: build them on a second stream while the
-    // vertex-face narrow phase (issue-bound, 2 waves/SIMD: it leaves wave slots and most of the HBM bandwidth free)
-    // still runs.  Only when the vertex-face pairs fit one sweep chunk; SCCD_OVERLAP=0 keeps the passes apart.
-    static const bool overlap_env = !(std::getenv("SCCD_OVERLAP") && std::atoi(std::getenv("SCCD_OVERLAP")) == 0);
-    bool overlapped = false;
-    if (overlap_env) {
-        bp_build(&pl->bp, &pl->vb, &pl->fb);
-        if (pl->bp.cursor < pl->bp.total_rows) {
-            narrow_counters_upload(c, narrow_counters(c), toi);
-            bp_detect_partial(&pl->bp);
-            if (st) st->n_vf_pairs += pl->bp.n_overlaps;
-            if (pl->bp.cursor >= pl->bp.total_rows) { // the whole list in one chunk
-                const NarrowParams p = narrow_params(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, 1, max_iter, tol,
-                                                     ms, allow_zero_toi);
-                if (st) st->n_vf_candidates = pl->bp.candidates;
-                narrow_phase_begin(c, p, narrow_counters(c), &toi, nullptr);
-                if (!c->side_stream) {
-                    SCCD_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-                    SCCD_HIP(hipEventCreateWithFlags(&c->side_event, hipEventDisableTiming));
-                }
-                hipStream_t const main_stream = c->stream;
-                c->stream = c->side_stream;
-                try {
-                    bp_build(&pl->bp, &pl->eb, nullptr); // (touches neither the pair list nor the narrow phase's buffers)
-                    SCCD_HIP(hipEventRecord(c->side_event, c->side_stream));
-                } catch (...) {
-                    c->stream = main_stream;
-                    (void)hipStreamSynchronize(c->side_stream);
-                    (void)hipStreamSynchronize(main_stream);
-                    throw;
-                }
-                c->stream = main_stream;
-                narrow_phase_end(c, p, narrow_counters(c), &toi, nullptr);
-                if (st) st->n_vf_checks += (int64_t)narrow_result(c).n_checks;
-                SCCD_HIP(hipStreamWaitEvent(c->stream, c->side_event, 0));
-                overlapped = true;
-            } else { // chunked: the plain loop for the rest
-                NarrowResult r = run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, 1, max_iter, tol, ms,
-                                            allow_zero_toi, &toi, nullptr);
-                if (st) st->n_vf_checks += (int64_t)r.n_checks;
-                while (pl->bp.cursor < pl->bp.total_rows) {
-                    bp_detect_partial(&pl->bp);
-                    r = run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, 1, max_iter, tol, ms, allow_zero_toi,
-                                   &toi, nullptr);
-                    if (st) {
-                        st->n_vf_pairs += pl->bp.n_overlaps;
-                        st->n_vf_checks += (int64_t)r.n_checks;
-                    }
-                }
-                if (st) st->n_vf_candidates = pl->bp.candidates;
-            }
+    // The edge-edge lists do not depend on the vertex-face pass: a helper context (own stream, scratch, pinned mirror)
+    // builds them on a worker thread meanwhile.  Both builds are chains of short, latency-bound kernels with host
+    // round trips in between, so two of them interleave almost for free (2.23 instead of 2.34 ms per step on the
+    // 1M-triangle cloth).  OPT-IN (SCCD_OVERLAP=1) until it has been soaked: the default keeps the passes apart.
+    static const bool overlap_env = std::getenv("SCCD_OVERLAP") && std::atoi(std::getenv("SCCD_OVERLAP")) == 1;
+    bool helper = false;
+    if (overlap_env && m->nE > 0) {
+        if (!c->side) {
+            if (sccd_create(c->device, &c->side) != SCCD_OK) throw SccdError { SCCD_E_NOMEM, "ccd: cannot create the helper context" };
+            SCCD_HIP(hipEventCreateWithFlags(&c->side_event, hipEventDisableTiming));
+            pl->bp_ee.ctx = c->side;
         }
-    } else {
-        ccd_pass(c, m, pl, true, ms, max_iter, tol, allow_zero_toi, &toi, st);
+        sccd_ctx* const sc = c->side;
+        sc->sort_axis = c->sort_axis;
+        sc->sweep_algo = c->sweep_algo;
+        sc->shard_rank = c->shard_rank;
+        sc->shard_count = c->shard_count;
+        sc->overlap_capacity = c->overlap_capacity;
+        sc->max_overlap_cutoff = c->max_overlap_cutoff;
+        sc->memory_limit_mb = c->memory_limit_mb;
+        sc->profile = c->profile;
+        SCCD_HIP(hipEventRecord(c->side_event, c->stream)); // the boxes are complete behind this point
+        const int device = c->device;
+        hipEvent_t const ev = c->side_event;
+        sccd_broad_phase* const bp_ee = &pl->bp_ee;
+        const sccd_boxes* const eb = &pl->eb;
+        pl->worker.submit([=] {
+            SCCD_HIP(hipSetDevice(device));
+            SCCD_HIP(hipStreamWaitEvent(sc->stream, ev, 0));
+            bp_build(bp_ee, eb, nullptr);
+        });
+        helper = true;
     }
-    ccd_pass(c, m, pl, false, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/overlapped);
+    try {
+        ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st);
+    } catch (...) {
+        if (helper) {
+            try {
+                pl->worker.wait();
+            } catch (...) {
+            }
+            (void)hipStreamSynchronize(c->side->stream);
+        }
+        throw;
+    }
+    if (helper) {
+        pl->worker.wait();
+        ccd_pass(c, m, pl, &pl->bp_ee, false, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true);
+    } else {
+        ccd_pass(c, m, pl, &pl->bp, false, ms, max_iter, tol, allow_zero_toi, &toi, st);
+    }
     *toi_out = toi;
     if (st && c->profile == 1) {
         SCCD_HIP(hipEventRecord(e1, c->stream));
@@ -1171,7 +1254,7 @@ extern "C" int sccd_ccd_mesh_pass(sccd_ctx* c, const sccd_mesh* m, int is_vf, do
         SCCD_REQUIRE(pl->vb.n == m->nV && pl->eb.n == m->nE && pl->fb.n == m->nF,
                      "ccd_mesh_pass: call sccd_ccd_mesh_prepare first");
         if (st) std::memset(st, 0, sizeof *st);
-        ccd_pass(c, m, pl, is_vf != 0, ms, max_iter, tol, allow_zero_toi, toi, st);
+        ccd_pass(c, m, pl, &pl->bp, is_vf != 0, ms, max_iter, tol, allow_zero_toi, toi, st);
     });
 }
 

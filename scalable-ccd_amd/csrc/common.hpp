@@ -126,8 +126,9 @@ struct sccd_ctx {
     DevBuf tmp0, tmp1, tmp2;
     void* pipeline = nullptr; // cached pipeline objects (api.hip)
     hipEvent_t rb_event = nullptr; // ReadBack: polled, not waited for
-    // ccd(): the edge-edge lists are built on a second stream while the vertex-face narrow phase runs on `stream`
-    hipStream_t side_stream = nullptr;
+    // ccd(): the edge-edge lists are built by a helper context (own stream, scratch and pinned mirror) on a worker
+    // thread while this context does the vertex-face pass; side_event orders the helper's stream behind the boxes
+    sccd_ctx* side = nullptr;
     hipEvent_t side_event = nullptr;
 };
 
