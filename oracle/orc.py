@@ -133,11 +133,13 @@ def narrow_phase(V0, V1, E, F, pairs, is_vf, ms=0.0, max_iter=-1, tol=1e-6, allo
     t = C.c_double(toi)
     st = NPStats()
     pq = np.full(len(pairs), np.inf) if per_query else None
-    L.orc_narrow_phase(
+    rc = L.orc_narrow_phase(
         _p(V0c), _p(V1c), C.c_int(V0c.shape[0]), _p(Ec), C.c_int(Ec.shape[0]), _p(Fc), C.c_int(Fc.shape[0]),
         _p(pairs), C.c_int64(len(pairs)), C.c_int(int(is_vf)), C.c_double(ms), C.c_int(max_iter), C.c_double(tol),
         C.c_int(int(allow_zero_toi)), C.c_int(arith), C.byref(t), _p(pq) if per_query else None, C.byref(st),
     )
+    if rc != 0:  # ORC_E_BUDGET: a level of the (level-order) restatement outgrew its domain budget
+        raise MemoryError("oracle narrow phase: level exceeds the live-domain budget (contact-rich queries in level order)")
     return t.value, pq, st.as_dict()
 
 
@@ -162,11 +164,13 @@ def ccd(V0, V1, E, F, ms=0.0, max_iter=-1, tol=1e-6, allow_zero_toi=True, arith=
     V0c, V1c, Ec, Fc = _f64cm(V0), _f64cm(V1), _i32cm(E), _i32cm(F)
     t = C.c_double(1.0)
     nvf, nee = C.c_int64(0), C.c_int64(0)
-    L.orc_ccd(
+    rc = L.orc_ccd(
         _p(V0c), _p(V1c), C.c_int(V0c.shape[0]), _p(Ec), C.c_int(Ec.shape[0]), _p(Fc), C.c_int(Fc.shape[0]),
         C.c_double(ms), C.c_int(max_iter), C.c_double(tol), C.c_int(int(allow_zero_toi)), C.c_int(arith),
         C.c_int(nthreads), C.byref(t), C.byref(nvf), C.byref(nee),
     )
+    if rc != 0:
+        raise MemoryError("oracle ccd: a level of the serial (level-order) narrow phase exceeds the live-domain budget")
     return t.value, nvf.value, nee.value
 
 

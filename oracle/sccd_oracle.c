@@ -534,6 +534,9 @@ static int ccd_step(const ccd_data* d, const ccd_domain* dom, int is_vf, int ari
     return 0;
 }
 
+static int64_t g_level_budget = ORC_MAX_LEVEL_DOMAINS;
+void orc_set_level_budget(int64_t domains) { g_level_budget = domains > 0 ? domains : ORC_MAX_LEVEL_DOMAINS; }
+
 int orc_narrow_phase(const double* V0, const double* V1, int nV, const int32_t* E, int nE,
                      const int32_t* F, int nF, const int32_t* pairs, int64_t n, int is_vf, double ms,
                      int max_iter, double tol, int allow_zero_toi, int arith, double* toi_io,
@@ -584,6 +587,17 @@ int orc_narrow_phase(const double* V0, const double* V1, int nV, const int32_t* 
                 }
                 if (nk && level == 0) st.n_root_survive++;
                 if (n_nxt + 2 > cap_nxt) {
+                    /* Level order keeps every live domain of a level: a contact-rich query set grows like
+                     * (1/tolerance)^2 (per-query mode has no global bound to prune by).  Give up at a fixed
+                     * budget instead of taking the host's memory (that took two test machines down). */
+                    if (cap_nxt >= g_level_budget) {
+                        free(cur);
+                        free(nxt);
+                        free(data);
+                        *toi_io = NAN;
+                        if (stats) *stats = st;
+                        return ORC_E_BUDGET;
+                    }
                     cap_nxt *= 2;
                     nxt = (ccd_domain*)realloc(nxt, sizeof(ccd_domain) * (size_t)cap_nxt);
                 }
@@ -683,18 +697,21 @@ int orc_ccd(const double* V0, const double* V1, int nV, const int32_t* E, int nE
     int axis = 0;   /* device path always sorts on x: aabb.cu:85-86 */
     int32_t* pairs = NULL;
     int64_t nvf = orc_sort_and_sweep_two_lists(vb, nV, fb, nF, &axis, &pairs, nthreads);
+    int rc = 0;
     if (nthreads > 1)
         orc_narrow_phase_mt(V0, V1, nV, E, nE, F, nF, pairs, nvf, 1, ms, max_iter, tol, allow_zero_toi, arith, &toi, NULL, nthreads);
     else
-        orc_narrow_phase(V0, V1, nV, E, nE, F, nF, pairs, nvf, 1, ms, max_iter, tol, allow_zero_toi, arith, &toi, NULL, NULL);
+        rc = orc_narrow_phase(V0, V1, nV, E, nE, F, nF, pairs, nvf, 1, ms, max_iter, tol, allow_zero_toi, arith, &toi, NULL, NULL);
     free(pairs);
     pairs = NULL;
     axis = 0;
     int64_t nee = orc_sort_and_sweep(eb, nE, &axis, &pairs, nthreads);
-    if (nthreads > 1)
-        orc_narrow_phase_mt(V0, V1, nV, E, nE, F, nF, pairs, nee, 0, ms, max_iter, tol, allow_zero_toi, arith, &toi, NULL, nthreads);
-    else
-        orc_narrow_phase(V0, V1, nV, E, nE, F, nF, pairs, nee, 0, ms, max_iter, tol, allow_zero_toi, arith, &toi, NULL, NULL);
+    if (rc == 0) { /* (a vertex-face pass that ran out of its level budget leaves nothing to seed the edge-edge pass with) */
+        if (nthreads > 1)
+            orc_narrow_phase_mt(V0, V1, nV, E, nE, F, nF, pairs, nee, 0, ms, max_iter, tol, allow_zero_toi, arith, &toi, NULL, nthreads);
+        else
+            rc = orc_narrow_phase(V0, V1, nV, E, nE, F, nF, pairs, nee, 0, ms, max_iter, tol, allow_zero_toi, arith, &toi, NULL, NULL);
+    }
     free(pairs);
     free(vb);
     free(eb);
@@ -702,5 +719,5 @@ int orc_ccd(const double* V0, const double* V1, int nV, const int32_t* E, int nE
     *toi_out = toi;
     if (n_vf) *n_vf = nvf;
     if (n_ee) *n_ee = nee;
-    return 0;
+    return rc;
 }

@@ -75,7 +75,11 @@ typedef struct {
  * toi is in/out (narrow_phase.cu:124-136).  per_query_toi (may be NULL): INFINITY-initialised
  * per-query minimum as in SCALABLE_CCD_TOI_PER_QUERY (narrow_phase.cu:69-73) -- when non-NULL
  * pruning uses the per-query value like the reference does in that build.
- * Returns 0 on success. */
+ * Returns 0 on success, ORC_E_BUDGET (toi = NaN) when one level would hold more than ORC_MAX_LEVEL_DOMAINS
+ * live domains (1.9 GB): contact-rich query sets grow without bound in level order. */
+#define ORC_MAX_LEVEL_DOMAINS ((int64_t)1 << 25)
+#define ORC_E_BUDGET (-2)
+void orc_set_level_budget(int64_t domains); /* tests: a smaller budget (<= 0 restores the default) */
 int orc_narrow_phase(const double* V0, const double* V1, int nV, const int32_t* E, int nE,
                      const int32_t* F, int nF, const int32_t* pairs, int64_t n, int is_vf,
                      double ms, int max_iter, double tol, int allow_zero_toi, int arith,

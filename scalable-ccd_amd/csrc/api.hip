@@ -661,6 +661,50 @@ static void list_finish(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, 
 // BroadPhase::build (broad_phase.cu:29-101) together with the key split + sort the reference
 // does in the DeviceAABBs constructor (aabb.cu:75-111): the lists are sorted HERE because the
 // cell grid is derived from both lists of the build.
+// Both lists of a two-list build in one sort: list B's entries (their keys carry the tag bit, the top bit of the
+// sorted key) are copied behind list A's, the pairs are sorted once, and the result is list A followed by list B.
+// list A keeps the merged key array (its first total_a entries); list B gets its keys back without the tag from the
+// gather.  Lists that were filled by the one-pass append only (entries already in key / idx).
+static void lists_finish_merged(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B, const GridParams* gp, uint32_t total_a,
+                                uint32_t total_b, int key_bits, SortedList* LA, SortedList* LB)
+{
+    const size_t ma = total_a, mb = total_b, m = ma + mb, pad = 64;
+    SCCD_REQUIRE(m < (1u << 31), "broad phase: too many cell entries");
+    LA->m = (int)ma;
+    LB->m = (int)mb;
+    SCCD_REQUIRE(LA->key.cap >= sizeof(uint32_t) * (m + pad) && LA->idx.cap >= sizeof(uint32_t) * (m + pad),
+                 "broad phase: merged list buffers too small");
+    for (SortedList* L : { LA, LB }) {
+        const size_t k = (size_t)L->m;
+        L->kmax.ensure(sizeof(uint32_t) * (k + pad));
+        L->filt.ensure(sizeof(float4) * (k + pad));
+        L->box.ensure(sizeof(sccd_aabb) * (k + 8));
+        L->lowcell.ensure(sizeof(uint32_t) * (k + pad));
+    }
+    {
+        ProfScope ps(c, SCCD_PROF_SORT);
+        SCCD_HIP(hipMemcpyAsync(LA->key.as<uint32_t>() + ma, LB->key.p, sizeof(uint32_t) * mb, hipMemcpyDeviceToDevice, c->stream));
+        SCCD_HIP(hipMemcpyAsync(LA->idx.as<uint32_t>() + ma, LB->idx.p, sizeof(uint32_t) * mb, hipMemcpyDeviceToDevice, c->stream));
+        c->sort_tmp_keys.ensure(sizeof(uint32_t) * (m + pad));
+        c->sort_tmp_vals.ensure(sizeof(uint32_t) * (m + pad));
+        if (radix_sort_pairs_u32(c, LA->key.as<uint32_t>(), LA->idx.as<uint32_t>(), (int64_t)m, key_bits)) {
+            std::swap(LA->key.p, c->sort_tmp_keys.p);
+            std::swap(LA->key.cap, c->sort_tmp_keys.cap);
+            std::swap(LA->idx.p, c->sort_tmp_vals.p);
+            std::swap(LA->idx.cap, c->sort_tmp_vals.cap);
+        }
+    }
+    {
+        ProfScope ps(c, SCCD_PROF_BOXES);
+        launch_entry_gather(c, A->raw.as<sccd_aabb>(), LA->key.as<uint32_t>(), LA->idx.as<uint32_t>(), (int)ma, gp,
+                            LA->box.as<sccd_aabb>(), LA->filt.as<float4>(), LA->kmax.as<uint32_t>(),
+                            LA->lowcell.as<uint32_t>());
+        launch_entry_gather(c, B->raw.as<sccd_aabb>(), LA->key.as<uint32_t>() + ma, LA->idx.as<uint32_t>() + ma, (int)mb, gp,
+                            LB->box.as<sccd_aabb>(), LB->filt.as<float4>(), LB->kmax.as<uint32_t>(),
+                            LB->lowcell.as<uint32_t>(), LB->key.as<uint32_t>());
+    }
+}
+
 static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes* B)
 {
     sccd_ctx* c = bp->ctx;
@@ -699,10 +743,16 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     bp->cell_hi = 1 << 30;
     bp->row_shard = false;
     unsigned long long window_est = 0; // entries of this rank's cell window, estimated from the sampled histogram
+    // Two lists are sorted in ONE go: the entries of list B carry a tag bit on top of the key, so the sorted array
+    // is list A followed by list B (one histogram and one set of radix passes instead of two; SCCD_MERGED_SORT=0
+    // sorts them apart).  Only the one-pass append build can do it.
+    static const bool merged_env = !(std::getenv("SCCD_MERGED_SORT") && std::atoi(std::getenv("SCCD_MERGED_SORT")) == 0);
+    const bool scan_build_env = std::getenv("SCCD_BUILD") && std::string(std::getenv("SCCD_BUILD")) == "scan";
+    const bool want_merged = merged_env && B != nullptr && !scan_build_env;
     for (int shrink = 0;; shrink++) {
         launch_grid_setup(c, A->stats_head(), A->stats_part(), A->n_part, B ? B->stats_head() : nullptr,
                           B ? B->stats_part() : nullptr, B ? B->n_part : 0, n_total, axis, cf, shrink, gp,
-                          d_total);
+                          d_total, want_merged);
         const bool can_shrink = shrink < 10;
         // Multi-GPU: every rank takes a contiguous window of cells with an equal share of the
         // entries, and builds / sorts / sweeps only that window.  A pair is reported from exactly
@@ -770,15 +820,16 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                 if (fill_round > 0) SCCD_HIP(hipMemsetAsync(d_total, 0, 2 * sizeof(uint32_t), c->stream)); // (grid_setup_k zeroed them for round 0)
                 {
                     ProfScope ps(c, SCCD_PROF_BOXES);
-                    bp->la.key.ensure(sizeof(uint32_t) * ((size_t)cap + pad));
-                    bp->la.idx.ensure(sizeof(uint32_t) * ((size_t)cap + pad));
+                    // (merged sort: list A's buffers also take list B's entries behind its own)
+                    bp->la.key.ensure(sizeof(uint32_t) * ((want_merged ? 2 : 1) * (size_t)cap + pad));
+                    bp->la.idx.ensure(sizeof(uint32_t) * ((want_merged ? 2 : 1) * (size_t)cap + pad));
                     launch_cell_fill_append(c, A->raw.as<sccd_aabb>(), A->n, gp, bp->cell_lo, bp->cell_hi, d_total,
                                             (uint32_t)cap, bp->la.key.as<uint32_t>(), bp->la.idx.as<uint32_t>());
                     if (B) {
                         bp->lb.key.ensure(sizeof(uint32_t) * ((size_t)cap + pad));
                         bp->lb.idx.ensure(sizeof(uint32_t) * ((size_t)cap + pad));
                         launch_cell_fill_append(c, B->raw.as<sccd_aabb>(), B->n, gp, bp->cell_lo, bp->cell_hi, d_total + 1,
-                                                (uint32_t)cap, bp->lb.key.as<uint32_t>(), bp->lb.idx.as<uint32_t>());
+                                                (uint32_t)cap, bp->lb.key.as<uint32_t>(), bp->lb.idx.as<uint32_t>(), want_merged);
                     }
                 }
                 {
@@ -794,8 +845,12 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                 auto over = [&](uint32_t t, int n) { return (int64_t)t > std::max<int64_t>(3 * (int64_t)n, (int64_t)n + 4096); };
                 if (over(total[0], A->n) || (B && over(total[1], B->n))) continue;
             }
-            list_finish(c, A, gp, bp->cell_lo, bp->cell_hi, total[0], hgp.key_bits, &bp->la, true);
-            if (B) list_finish(c, B, gp, bp->cell_lo, bp->cell_hi, total[1], hgp.key_bits, &bp->lb, true);
+            if (want_merged && total[0] > 0 && total[1] > 0) {
+                lists_finish_merged(c, A, B, gp, total[0], total[1], hgp.key_bits, &bp->la, &bp->lb);
+            } else {
+                list_finish(c, A, gp, bp->cell_lo, bp->cell_hi, total[0], hgp.key_bits, &bp->la, true);
+                if (B) list_finish(c, B, gp, bp->cell_lo, bp->cell_hi, total[1], hgp.key_bits, &bp->lb, true);
+            }
             break;
         }
         list_count(c, A, gp, bp->cell_lo, bp->cell_hi, &bp->la, d_total);

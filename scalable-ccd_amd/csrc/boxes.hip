@@ -229,7 +229,7 @@ __global__ void grid_setup_k(const GridStats* __restrict__ st_a, const double* _
                              const GridStats* __restrict__ st_b, const double* __restrict__ part_b, int n_part_b,
                              int n_total, int axis, double cell_factor, int shrink, GridParams* __restrict__ g,
                              uint32_t* __restrict__ cursors /* the two list cursors of the fill pass: zeroed here */,
-                             int max_cells)
+                             int max_cells, int reserve_tag)
 {
     if (threadIdx.x < 2) cursors[threadIdx.x] = 0u;
     // summed extents: lane l adds the block partials l, l + 64, ... of list A, then of list B, in
@@ -309,14 +309,19 @@ __global__ void grid_setup_k(const GridStats* __restrict__ st_a, const double* _
         need = 1;
         while (need < 32 && (double)(1ull << need) < ratio) need++;
     }
-    int total = cb + need;
+    // (reserve_tag: one more bit on top marks the entries of list B, so that ONE sort orders both lists and
+    // leaves them behind each other.  If that bit alone would cost a whole radix pass, the sort coordinate gives one up.)
+    if (reserve_tag && need > 8 && (cb + need) % 8 == 0) need -= 1;
+    int total = cb + need + reserve_tag;
     total = ((total + 7) / 8) * 8;
     if (total > 32) total = 32;
     if (total < 8) total = 8;
-    const int xb = total - cb;
+    const int xb = total - reserve_tag - cb;
     g->xb = xb;
     g->n_cells = S[0] * S[1];
     g->key_bits = total;
+    g->tag_bit = reserve_tag ? total - 1 : -1;
+    g->pad_ = 0;
     const double qmax = (double)((1ull << xb) - 1ull);
     g->x0 = lo[axis];
     g->xscale = (xr > 0.0 && xr < TI_INF) ? qmax / xr : 0.0;
@@ -413,10 +418,11 @@ __global__ void cell_hist_k(const sccd_aabb* __restrict__ raw, int n, const Grid
 // `capacity` are counted but not written (the host grows the buffers and runs the pass again).
 __global__ void cell_fill_append_k(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp,
                                    int cell_lo, int cell_hi, uint32_t* __restrict__ cursor, uint32_t capacity,
-                                   uint32_t* __restrict__ key, uint32_t* __restrict__ idx)
+                                   uint32_t* __restrict__ key, uint32_t* __restrict__ idx, int tagged)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const GridParams g = *gp;
+    const uint32_t tag = (tagged && g.tag_bit >= 0) ? (1u << g.tag_bit) : 0u; // list B of a merged two-list sort
     CellSpan s = { 0, -1, 0, -1 };
     unsigned q = 0;
     uint32_t cnt = 0;
@@ -451,7 +457,7 @@ __global__ void cell_fill_append_k(const sccd_aabb* __restrict__ raw, int n, con
         for (int cb = s.b0; cb <= s.b1; cb++) {
             const int cell = ca * g.Sb + cb;
             if (cell < cell_lo || cell >= cell_hi) continue;
-            key[at] = (uint32_t)(((unsigned long long)cell << g.xb) | q); // xb may be 32
+            key[at] = (uint32_t)(((unsigned long long)cell << g.xb) | q) | tag; // xb may be 32
             idx[at] = (uint32_t)i;
             ++at;
         }
@@ -462,11 +468,14 @@ __global__ void cell_fill_append_k(const sccd_aabb* __restrict__ raw, int n, con
 __global__ void entry_gather_k(const sccd_aabb* __restrict__ raw, const uint32_t* __restrict__ key,
                                const uint32_t* __restrict__ idx, int m, const GridParams* __restrict__ gp,
                                sccd_aabb* __restrict__ sorted, float4* __restrict__ filt,
-                               uint32_t* __restrict__ kmax, uint32_t* __restrict__ lowcell)
+                               uint32_t* __restrict__ kmax, uint32_t* __restrict__ lowcell,
+                               uint32_t* __restrict__ key_out /* list B of a merged sort: the keys without the tag */)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= m) return;
     const GridParams g = *gp;
+    const uint32_t k_e = key_out ? key[e] & ~(1u << g.tag_bit) : key[e];
+    if (key_out) key_out[e] = k_e;
     const sccd_aabb* src = raw + idx[e];
     const double4 q0 = reinterpret_cast<const double4*>(src)[0];
     const double4 q1 = reinterpret_cast<const double4*>(src)[1];
@@ -478,7 +487,7 @@ __global__ void entry_gather_k(const sccd_aabb* __restrict__ raw, const uint32_t
     // outward rounding keeps the filter conservative: filt.min <= min, filt.max >= max
     filt[e] = make_float4(__double2float_rd(lo[g.aa]), __double2float_ru(hi[g.aa]), __double2float_rd(lo[g.ab]),
                           __double2float_ru(hi[g.ab]));
-    const uint32_t cellbits = (uint32_t)((((unsigned long long)key[e]) >> g.xb) << g.xb);
+    const uint32_t cellbits = (uint32_t)((((unsigned long long)k_e) >> g.xb) << g.xb);
     kmax[e] = cellbits | grid_qx(g, hi[g.axis]);
     lowcell[e] = (uint32_t)grid_cell_a(g, lo[g.aa]) | ((uint32_t)grid_cell_b(g, lo[g.ab]) << 16);
 }
@@ -579,13 +588,13 @@ int launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st, do
 }
 void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a, int n_part_a, const GridStats* st_b,
                        const double* part_b, int n_part_b, int n_total, int axis, double cell_factor, int shrink,
-                       GridParams* g, uint32_t* cursors)
+                       GridParams* g, uint32_t* cursors, bool reserve_tag)
 {
     // SCCD_MAX_CELLS_ENV: experiments with coarser grids (<= SCCD_MAX_CELLS)
     const char* mc = std::getenv("SCCD_MAX_CELLS");
     const int max_cells = mc ? std::max(1, std::min(SCCD_MAX_CELLS, std::atoi(mc))) : SCCD_DEFAULT_CELLS;
     hipLaunchKernelGGL(grid_setup_k, dim3(1), dim3(64), 0, c->stream, st_a, part_a, n_part_a, st_b, part_b, n_part_b,
-                       n_total, axis, cell_factor, shrink, g, cursors, max_cells);
+                       n_total, axis, cell_factor, shrink, g, cursors, max_cells, reserve_tag ? 1 : 0);
     SCCD_HIP(hipGetLastError());
 }
 void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int stride, uint32_t* hist)
@@ -597,11 +606,11 @@ void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams
     SCCD_HIP(hipGetLastError());
 }
 void launch_cell_fill_append(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
-                             uint32_t* cursor, uint32_t capacity, uint32_t* key, uint32_t* idx)
+                             uint32_t* cursor, uint32_t capacity, uint32_t* key, uint32_t* idx, bool tagged)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(cell_fill_append_k, dim3((n + 1023) / 1024), dim3(1024), 0, c->stream, raw, n, g, cell_lo, cell_hi,
-                       cursor, capacity, key, idx);
+                       cursor, capacity, key, idx, tagged ? 1 : 0);
     SCCD_HIP(hipGetLastError());
 }
 void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
@@ -620,11 +629,12 @@ void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams
     SCCD_HIP(hipGetLastError());
 }
 void launch_entry_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,
-                         const GridParams* g, sccd_aabb* sorted, float4* filt, uint32_t* kmax, uint32_t* lowcell)
+                         const GridParams* g, sccd_aabb* sorted, float4* filt, uint32_t* kmax, uint32_t* lowcell,
+                         uint32_t* key_out)
 {
     if (m == 0) return;
     hipLaunchKernelGGL(entry_gather_k, dim3(grid_for(m)), dim3(TPB), 0, c->stream, raw, key, idx, m, g, sorted, filt,
-                       kmax, lowcell);
+                       kmax, lowcell, key_out);
     SCCD_HIP(hipGetLastError());
 }
 

@@ -26,7 +26,9 @@ struct GridParams { // device, written by grid_setup_k
     int Sa, Sb;       // cells along aa and ab (>= 1)
     int xb;           // bits of the quantised sort coordinate (sized from range / mean extent)
     int n_cells;
-    int key_bits;     // cell bits + xb, a multiple of 8: the radix sort runs key_bits / 8 passes
+    int key_bits;     // (tag bit +) cell bits + xb, a multiple of 8: the radix sort runs key_bits / 8 passes
+    int tag_bit;      // two-list builds that sort both lists at once: bit key_bits - 1 marks list B; else -1
+    int pad_;
     double x0, xscale, xqmax;
     double a0, inv_ha, b0, inv_hb;
 };

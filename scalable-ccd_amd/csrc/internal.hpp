@@ -85,16 +85,17 @@ struct GridParams;
 int launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st, double* part);
 void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a, int n_part_a, const GridStats* st_b,
                        const double* part_b, int n_part_b, int n_total, int axis, double cell_factor, int shrink,
-                       GridParams* g, uint32_t* cursors);
+                       GridParams* g, uint32_t* cursors, bool reserve_tag = false);
 void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int stride, uint32_t* hist);
 void launch_cell_fill_append(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
-                             uint32_t* cursor, uint32_t capacity, uint32_t* key, uint32_t* idx);
+                             uint32_t* cursor, uint32_t capacity, uint32_t* key, uint32_t* idx, bool tagged = false);
 void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
                        uint32_t* counts);
 void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
                       const uint32_t* offsets, uint32_t* key, uint32_t* idx);
 void launch_entry_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,
-                         const GridParams* g, sccd_aabb* sorted, float4* filt, uint32_t* kmax, uint32_t* lowcell);
+                         const GridParams* g, sccd_aabb* sorted, float4* filt, uint32_t* kmax, uint32_t* lowcell,
+                         uint32_t* key_out = nullptr);
 
 // scan.hip
 void exclusive_scan_u32(sccd_ctx* c, const uint32_t* in, uint32_t* out, int n, uint32_t* d_total);

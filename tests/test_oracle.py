@@ -2,6 +2,7 @@
 libm nextafter semantics, and the committed golden vectors (tests/golden/, made by
 tests/golden/make_golden.py from the oracle itself -- parity vs the reference is UNPINNED, see
 oracle/sccd_oracle.h)."""
+import ctypes as C
 import json
 import os
 
@@ -202,3 +203,21 @@ def test_golden_vectors(orc):
             continue
         got = compute_case(orc, name)
         assert got == want, name
+
+
+def test_level_order_gives_up_at_its_domain_budget(orc):
+    """A vertex sliding inside the plane of a triangle with allow_zero_toi off: in level order one query keeps
+    1.5 M live domains.  The restatement must report that it ran out of budget, not take the host's memory."""
+    V0 = np.array([[0.2, 0.2, 0.0], [0, 0, 0], [1, 0, 0], [0, 1, 0]], float)
+    V1 = V0.copy()
+    V1[0] = [0.3, 0.25, 0.0]
+    E = np.array([[1, 2], [2, 3], [1, 3]], np.int32)
+    F = np.array([[1, 2, 3]], np.int32)
+    orc.lib().orc_set_level_budget(C.c_int64(1 << 16))
+    try:
+        with pytest.raises(MemoryError):
+            orc.narrow_phase(V0, V1, E, F, [[0, 0]], True, allow_zero_toi=False, per_query=True)
+    finally:
+        orc.lib().orc_set_level_budget(C.c_int64(0))
+    toi, _, st = orc.narrow_phase(V0, V1, E, F, [[0, 0]], True, allow_zero_toi=False, per_query=True)
+    assert toi == 0.0 and st["max_queue"] > 1 << 20
