@@ -231,8 +231,8 @@ void narrow_counters_upload(sccd_ctx* c, NarrowCounters* d_cnt, double toi)
 }
 
 // begin: upload the counters (unless narrow_counters_upload() already did) and launch; end: read the counters
-// back, handle the work-queue kernel's overflow flags, hand the TOI over.  Between the two the caller may enqueue
-// unrelated work on ANOTHER stream (ccd() builds the edge-edge lists while the vertex-face queries run).
+// back, handle the work-queue kernel's overflow flags, hand the TOI over.  (Split so that a caller can enqueue
+// unrelated work on another stream in between; narrow_phase_run() is the two back to back.)
 void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, const double* h_toi_inout,
                         double* d_per_query_toi)
 {
