@@ -69,15 +69,25 @@ def _i32cm(M):
     return np.asfortranarray(np.asarray(M, dtype=np.int32))
 
 
-def build_boxes(V0, V1, E, F, inflation=0.0):
+# scalar="f32": the SCALABLE_CCD_USE_DOUBLE = OFF twin (Scalar = float): vertices are cast to float first
+def _rcm(M, scalar):
+    return np.asfortranarray(np.asarray(M, dtype=np.float32 if scalar == "f32" else np.float64))
+
+
+def _rty(scalar):
+    return (C.c_float, np.float32, "_f32") if scalar == "f32" else (C.c_double, np.float64, "")
+
+
+def build_boxes(V0, V1, E, F, inflation=0.0, scalar="f64"):
     """(vertex_boxes, edge_boxes, face_boxes) as structured arrays (64-byte cuda::AABB layout)."""
     L = lib()
-    V0c, V1c, Ec, Fc = _f64cm(V0), _f64cm(V1), _i32cm(E), _i32cm(F)
+    c_real, _, sfx = _rty(scalar)
+    V0c, V1c, Ec, Fc = _rcm(V0, scalar), _rcm(V1, scalar), _i32cm(E), _i32cm(F)
     nV, nE, nF = V0c.shape[0], Ec.shape[0], Fc.shape[0]
     vb = np.zeros(nV, AABB_DTYPE)
     eb = np.zeros(nE, AABB_DTYPE)
     fb = np.zeros(nF, AABB_DTYPE)
-    L.orc_build_vertex_boxes(_p(V0c), _p(V1c), C.c_int(nV), C.c_double(inflation), _p(vb))
+    getattr(L, "orc_build_vertex_boxes" + sfx)(_p(V0c), _p(V1c), C.c_int(nV), c_real(inflation), _p(vb))
     L.orc_build_edge_boxes(_p(vb), _p(Ec), C.c_int(nE), _p(eb))
     L.orc_build_face_boxes(_p(vb), _p(Fc), C.c_int(nF), _p(fb))
     return vb, eb, fb
@@ -125,17 +135,18 @@ def brute_force(boxes, boxes_b=None):
 
 
 def narrow_phase(V0, V1, E, F, pairs, is_vf, ms=0.0, max_iter=-1, tol=1e-6, allow_zero_toi=True,
-                 arith=ARITH_STRICT, toi=1.0, per_query=False):
+                 arith=ARITH_STRICT, toi=1.0, per_query=False, scalar="f64"):
     """Level-synchronous restatement.  Returns (toi, per_query_toi|None, stats dict)."""
     L = lib()
-    V0c, V1c, Ec, Fc = _f64cm(V0), _f64cm(V1), _i32cm(E), _i32cm(F)
+    c_real, np_real, sfx = _rty(scalar)
+    V0c, V1c, Ec, Fc = _rcm(V0, scalar), _rcm(V1, scalar), _i32cm(E), _i32cm(F)
     pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
-    t = C.c_double(toi)
+    t = c_real(toi)
     st = NPStats()
-    pq = np.full(len(pairs), np.inf) if per_query else None
-    rc = L.orc_narrow_phase(
+    pq = np.full(len(pairs), np.inf, dtype=np_real) if per_query else None
+    rc = getattr(L, "orc_narrow_phase" + sfx)(
         _p(V0c), _p(V1c), C.c_int(V0c.shape[0]), _p(Ec), C.c_int(Ec.shape[0]), _p(Fc), C.c_int(Fc.shape[0]),
-        _p(pairs), C.c_int64(len(pairs)), C.c_int(int(is_vf)), C.c_double(ms), C.c_int(max_iter), C.c_double(tol),
+        _p(pairs), C.c_int64(len(pairs)), C.c_int(int(is_vf)), c_real(ms), C.c_int(max_iter), c_real(tol),
         C.c_int(int(allow_zero_toi)), C.c_int(arith), C.byref(t), _p(pq) if per_query else None, C.byref(st),
     )
     if rc != 0:  # ORC_E_BUDGET: a level of the (level-order) restatement outgrew its domain budget
@@ -144,29 +155,31 @@ def narrow_phase(V0, V1, E, F, pairs, is_vf, ms=0.0, max_iter=-1, tol=1e-6, allo
 
 
 def narrow_phase_mt(V0, V1, E, F, pairs, is_vf, ms=0.0, max_iter=-1, tol=1e-6, allow_zero_toi=True,
-                    arith=ARITH_STRICT, toi=1.0, nthreads=1, want_checks=False):
+                    arith=ARITH_STRICT, toi=1.0, nthreads=1, want_checks=False, scalar="f64"):
     L = lib()
-    V0c, V1c, Ec, Fc = _f64cm(V0), _f64cm(V1), _i32cm(E), _i32cm(F)
+    c_real, _, sfx = _rty(scalar)
+    V0c, V1c, Ec, Fc = _rcm(V0, scalar), _rcm(V1, scalar), _i32cm(E), _i32cm(F)
     pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
-    t = C.c_double(toi)
+    t = c_real(toi)
     chk = np.zeros(len(pairs), np.int32) if want_checks else None
-    L.orc_narrow_phase_mt(
+    getattr(L, "orc_narrow_phase_mt" + sfx)(
         _p(V0c), _p(V1c), C.c_int(V0c.shape[0]), _p(Ec), C.c_int(Ec.shape[0]), _p(Fc), C.c_int(Fc.shape[0]),
-        _p(pairs), C.c_int64(len(pairs)), C.c_int(int(is_vf)), C.c_double(ms), C.c_int(max_iter), C.c_double(tol),
+        _p(pairs), C.c_int64(len(pairs)), C.c_int(int(is_vf)), c_real(ms), C.c_int(max_iter), c_real(tol),
         C.c_int(int(allow_zero_toi)), C.c_int(arith), C.byref(t), _p(chk) if want_checks else None, C.c_int(nthreads),
     )
     return t.value, chk
 
 
-def ccd(V0, V1, E, F, ms=0.0, max_iter=-1, tol=1e-6, allow_zero_toi=True, arith=ARITH_STRICT, nthreads=1):
+def ccd(V0, V1, E, F, ms=0.0, max_iter=-1, tol=1e-6, allow_zero_toi=True, arith=ARITH_STRICT, nthreads=1, scalar="f64"):
     """Restatement of scalable_ccd::cuda::ccd (ccd.cu:80-146).  Returns (toi, n_vf, n_ee)."""
     L = lib()
-    V0c, V1c, Ec, Fc = _f64cm(V0), _f64cm(V1), _i32cm(E), _i32cm(F)
-    t = C.c_double(1.0)
+    c_real, _, sfx = _rty(scalar)
+    V0c, V1c, Ec, Fc = _rcm(V0, scalar), _rcm(V1, scalar), _i32cm(E), _i32cm(F)
+    t = c_real(1.0)
     nvf, nee = C.c_int64(0), C.c_int64(0)
-    rc = L.orc_ccd(
+    rc = getattr(L, "orc_ccd" + sfx)(
         _p(V0c), _p(V1c), C.c_int(V0c.shape[0]), _p(Ec), C.c_int(Ec.shape[0]), _p(Fc), C.c_int(Fc.shape[0]),
-        C.c_double(ms), C.c_int(max_iter), C.c_double(tol), C.c_int(int(allow_zero_toi)), C.c_int(arith),
+        c_real(ms), C.c_int(max_iter), c_real(tol), C.c_int(int(allow_zero_toi)), C.c_int(arith),
         C.c_int(nthreads), C.byref(t), C.byref(nvf), C.byref(nee),
     )
     if rc != 0:

@@ -284,440 +284,57 @@ static int cmp_pair(const void* pa, const void* pb)
 void orc_sort_pairs(int32_t* pairs, int64_t n) { qsort(pairs, (size_t)n, 8, cmp_pair); }
 
 /* ------------------------------------------------------------------------------------------ */
-/* Narrow phase                                                                               */
-
-/* CCDData: src/scalable_ccd/cuda/narrow_phase/ccd_data.cuh:8-26 */
-typedef struct {
-    double v[8][3]; /* v0s v1s v2s v3s v0e v1e v2e v3e */
-    double err[3];
-    double tol[3];
-    double ms;
-    double toi; /* TOI_PER_QUERY */
-    int nbr_checks;
-} ccd_data;
-
-/* CCDDomain: interval.cuh:30-44 */
-typedef struct {
-    double lo[3], hi[3]; /* t,u,v */
-    int query_id;
-} ccd_domain;
-
-/* add_data<is_vf>: narrow_phase.cu:24-74 */
-static void gather_query(const double* V0, const double* V1, int nV, const int32_t* E, int nE,
-                         const int32_t* F, int nF, int a, int b, int is_vf, double v[8][3])
-{
-    int id[4];
-    if (is_vf) { /* :41-53 */
-        id[0] = a;
-        id[1] = F[b];
-        id[2] = F[b + (size_t)nF];
-        id[3] = F[b + 2 * (size_t)nF];
-    } else { /* :54-66 */
-        id[0] = E[a];
-        id[1] = E[a + (size_t)nE];
-        id[2] = E[b];
-        id[3] = E[b + (size_t)nE];
-    }
-    for (int k = 0; k < 4; k++)
-        for (int c = 0; c < 3; c++) {
-            v[k][c] = V0[id[k] + (size_t)c * nV];
-            v[k + 4][c] = V1[id[k] + (size_t)c * nV];
-        }
-}
-
-static inline double linf_diff(const double a[3], const double b[3])
-{
-    /* (b - a).lpNorm<Infinity>() */
-    double m = fabs(b[0] - a[0]);
-    m = dmax(m, fabs(b[1] - a[1]));
-    m = dmax(m, fabs(b[2] - a[2]));
-    return m;
-}
-
-/* max_Linf_4: root_finder.cu:31-46 */
-static double max_linf_4(const double* p1, const double* p2, const double* p3, const double* p4,
-                         const double* p1e, const double* p2e, const double* p3e, const double* p4e)
-{
-    return dmax(dmax(linf_diff(p1, p1e), linf_diff(p2, p2e)), dmax(linf_diff(p3, p3e), linf_diff(p4, p4e)));
-}
-
-/* compute_face_vertex_tolerance / compute_edge_edge_tolerance (root_finder.cu:48-88) and
- * get_numerical_error (root_finder.cu:90-135). v = v0s..v3s,v0e..v3e */
-void orc_query_constants(const double* vv, int is_vf, int use_ms, double co_domain_tol, double* tol,
-                         double* err)
-{
-    const double(*v)[3] = (const double(*)[3])vv;
-    const double *v0s = v[0], *v1s = v[1], *v2s = v[2], *v3s = v[3];
-    const double *v0e = v[4], *v1e = v[5], *v2e = v[6], *v3e = v[7];
-    double p000[3], p001[3], p011[3], p010[3], p100[3], p101[3], p111[3], p110[3];
-    if (is_vf) { /* :50-59 */
-        for (int k = 0; k < 3; k++) {
-            p000[k] = v0s[k] - v1s[k];
-            p001[k] = v0s[k] - v3s[k];
-            p011[k] = v0s[k] - (v2s[k] + v3s[k] - v1s[k]);
-            p010[k] = v0s[k] - v2s[k];
-            p100[k] = v0e[k] - v1e[k];
-            p101[k] = v0e[k] - v3e[k];
-            p111[k] = v0e[k] - (v2e[k] + v3e[k] - v1e[k]);
-            p110[k] = v0e[k] - v2e[k];
-        }
-        tol[0] = co_domain_tol / (3 * max_linf_4(p000, p001, p011, p010, p100, p101, p111, p110));
-        tol[1] = co_domain_tol / (3 * max_linf_4(p000, p100, p101, p001, p010, p110, p111, p011));
-        tol[2] = co_domain_tol / (3 * max_linf_4(p000, p100, p110, p010, p001, p101, p111, p011));
-    } else { /* :73-87 -- tol[1] deliberately repeats the tol[0] pairing, as the reference does */
-        for (int k = 0; k < 3; k++) {
-            p000[k] = v0s[k] - v2s[k];
-            p001[k] = v0s[k] - v3s[k];
-            p010[k] = v1s[k] - v2s[k];
-            p011[k] = v1s[k] - v3s[k];
-            p100[k] = v0e[k] - v2e[k];
-            p101[k] = v0e[k] - v3e[k];
-            p110[k] = v1e[k] - v2e[k];
-            p111[k] = v1e[k] - v3e[k];
-        }
-        tol[0] = co_domain_tol / (3 * max_linf_4(p000, p001, p011, p010, p100, p101, p111, p110));
-        tol[1] = co_domain_tol / (3 * max_linf_4(p000, p001, p011, p010, p100, p101, p111, p110));
-        tol[2] = co_domain_tol / (3 * max_linf_4(p000, p100, p101, p001, p010, p110, p111, p011));
-    }
-    /* get_numerical_error: :93-134 (double constants) */
-    double filter;
-    if (!use_ms) {
-        filter = is_vf ? 6.661338147750939e-15 : 6.217248937900877e-15;
-    } else {
-        filter = is_vf ? 7.549516567451064e-15 : 7.105427357601002e-15;
-    }
-    for (int k = 0; k < 3; k++) {
-        double m = fabs(v0s[k]);
-        m = dmax(m, fabs(v1s[k]));
-        m = dmax(m, fabs(v2s[k]));
-        m = dmax(m, fabs(v3s[k]));
-        m = dmax(m, fabs(v0e[k]));
-        m = dmax(m, fabs(v1e[k]));
-        m = dmax(m, fabs(v2e[k]));
-        m = dmax(m, fabs(v3e[k]));
-        m = dmax(m, 1.0);
-        err[k] = m * m * m * filter;
-    }
-}
-
-/* calculate_vf / calculate_ee: root_finder.cu:137-155.  One coordinate. */
-static inline double lerp_strict(double s, double e, double t) { return (e - s) * t + s; }
-static inline double lerp_fma(double s, double e, double t) { return fma(e - s, t, s); }
-
-static inline double eval_vf(const double (*v)[3], int k, double t, double u, double w, int arith)
-{
-    if (arith == ORC_ARITH_FMA) {
-        const double p = lerp_fma(v[0][k], v[4][k], t);
-        const double t0 = lerp_fma(v[1][k], v[5][k], t);
-        const double t1 = lerp_fma(v[2][k], v[6][k], t);
-        const double t2 = lerp_fma(v[3][k], v[7][k], t);
-        /* v - (t1-t0)*u - (t2-t0)*v - t0 with both products fused into the subtraction */
-        double r = fma(-(t1 - t0), u, p);
-        r = fma(-(t2 - t0), w, r);
-        return r - t0;
-    } else {
-        const double p = lerp_strict(v[0][k], v[4][k], t);
-        const double t0 = lerp_strict(v[1][k], v[5][k], t);
-        const double t1 = lerp_strict(v[2][k], v[6][k], t);
-        const double t2 = lerp_strict(v[3][k], v[7][k], t);
-        return p - (t1 - t0) * u - (t2 - t0) * w - t0;
-    }
-}
-
-static inline double eval_ee(const double (*v)[3], int k, double t, double u, double w, int arith)
-{
-    if (arith == ORC_ARITH_FMA) {
-        const double ea0 = lerp_fma(v[0][k], v[4][k], t);
-        const double ea1 = lerp_fma(v[1][k], v[5][k], t);
-        const double eb0 = lerp_fma(v[2][k], v[6][k], t);
-        const double eb1 = lerp_fma(v[3][k], v[7][k], t);
-        return fma(ea1 - ea0, u, ea0) - fma(eb1 - eb0, w, eb0);
-    } else {
-        const double ea0 = lerp_strict(v[0][k], v[4][k], t);
-        const double ea1 = lerp_strict(v[1][k], v[5][k], t);
-        const double eb0 = lerp_strict(v[2][k], v[6][k], t);
-        const double eb1 = lerp_strict(v[3][k], v[7][k], t);
-        return ((ea1 - ea0) * u + ea0) - ((eb1 - eb0) * w + eb0);
-    }
-}
-
-/* origin_in_inclusion_function: root_finder.cu:157-198 */
-static int origin_in_inclusion(const double (*v)[3], const double* lo, const double* hi,
-                               const double* err, double ms, int is_vf, int arith, double* true_tol,
-                               int* box_in)
-{
-    double cmin[3] = { DBL_MAX, DBL_MAX, DBL_MAX }, cmax[3] = { -DBL_MAX, -DBL_MAX, -DBL_MAX };
-    for (int corner = 0; corner < 8; corner++) { /* DomainCorner::update_tuv interval.cuh:51-56 */
-        const double t = (corner & 1) ? hi[0] : lo[0];
-        const double u = (corner & 2) ? hi[1] : lo[1];
-        const double w = (corner & 4) ? hi[2] : lo[2];
-        for (int k = 0; k < 3; k++) {
-            const double c = is_vf ? eval_vf(v, k, t, u, w, arith) : eval_ee(v, k, t, u, w, arith);
-            cmin[k] = dmin(cmin[k], c);
-            cmax[k] = dmax(cmax[k], c);
-        }
-    }
-    double w = cmax[0] - cmin[0];
-    w = dmax(w, cmax[1] - cmin[1]);
-    w = dmax(w, cmax[2] - cmin[2]);
-    *true_tol = dmax(0.0, w); /* :183 */
-    *box_in = 1;
-    for (int k = 0; k < 3; k++) /* :187-190 */
-        if (cmin[k] - ms > err[k] || cmax[k] + ms < -err[k]) return 0;
-    for (int k = 0; k < 3; k++) /* :192-195 */
-        if (cmin[k] + ms < -err[k] || cmax[k] - ms > err[k]) *box_in = 0;
-    return 1;
-}
-
-int orc_origin_in_inclusion_function(const double* v, const double* dom, const double* err, double ms,
-                                     int is_vf, int arith, double* true_tol, int* box_in)
-{
-    const double lo[3] = { dom[0], dom[2], dom[4] }, hi[3] = { dom[1], dom[3], dom[5] };
-    return origin_in_inclusion((const double(*)[3])v, lo, hi, err, ms, is_vf, arith, true_tol, box_in);
-}
-
-/* split_dimension: root_finder.cu:200-211 */
-static int split_dimension(const double* tol, const double* w)
-{
-    const double r0 = w[0] / tol[0], r1 = w[1] / tol[1], r2 = w[2] / tol[2];
-    if (r0 >= r1 && r0 >= r2) return 0;
-    if (r1 >= r0 && r1 >= r2) return 1;
-    return 2;
-}
-
-/* sum_less_than_one: root_finder.cu:21-29 */
-static inline int sum_less_than_one(double a, double b) { return a + b <= 1 / (1 - DBL_EPSILON); }
-
-/* One ccd_kernel invocation (root_finder.cu:277-370) on `dom`.
- * prune_toi = the value the reference compares against (*toi, or data.toi in TOI_PER_QUERY).
- * Returns: bit0 = accepted (min_t is a TOI candidate); children written to kids[], *nk = 0..2.
- * *checked = 1 if the inclusion function was evaluated. */
-static int ccd_step(const ccd_data* d, const ccd_domain* dom, int is_vf, int arith, double tol,
-                    int allow_zero_toi, int max_iter, int checks_before, double prune_toi,
-                    ccd_domain kids[2], int* nk, int* checked)
-{
-    *nk = 0;
-    *checked = 0;
-    const double min_t = dom->lo[0];
-    if (min_t >= prune_toi) return 0;                      /* :295-300 */
-    if (max_iter >= 0 && checks_before > max_iter) return 0; /* :303 */
-    double true_tol = 0;
-    int box_in;
-    *checked = 1;
-    if (!origin_in_inclusion(d->v, dom->lo, dom->hi, d->err, d->ms, is_vf, arith, &true_tol, &box_in))
-        return 0;
-    const double w[3] = { dom->hi[0] - dom->lo[0], dom->hi[1] - dom->lo[1], dom->hi[2] - dom->lo[2] };
-    if (w[0] <= d->tol[0] && w[1] <= d->tol[1] && w[2] <= d->tol[2]) return 1;  /* C1 :322 */
-    if (box_in && (allow_zero_toi || min_t > 0)) return 1;                      /* C2 :331 */
-    if (true_tol <= tol && (allow_zero_toi || min_t > 0)) return 1;             /* C3 :340 */
-    const int split = split_dimension(d->tol, w);                               /* :350 */
-    /* bisect: :213-254, SplitInterval interval.cuh:18-28 */
-    const double mid = (dom->lo[split] + dom->hi[split]) / 2;
-    if (dom->lo[split] >= mid || mid >= dom->hi[split]) return 1; /* C4 :222-225,:362 */
-    kids[0] = *dom;
-    kids[0].hi[split] = mid;
-    *nk = 1;
-    int second = 0;
-    if (split == 0) {
-        second = (mid <= prune_toi); /* :229-232 */
-    } else if (is_vf) {
-        if (split == 1) second = sum_less_than_one(mid, dom->lo[2]); /* :235-240 */
-        else second = sum_less_than_one(mid, dom->lo[1]);            /* :241-246 */
-    } else {
-        second = 1; /* :248-250 */
-    }
-    if (second) {
-        kids[1] = *dom;
-        kids[1].lo[split] = mid;
-        *nk = 2;
-    }
-    return 0;
-}
-
+/* Narrow phase and ccd(): np_core.inc, once per scalar type                                   */
 static int64_t g_level_budget = ORC_MAX_LEVEL_DOMAINS;
 void orc_set_level_budget(int64_t domains) { g_level_budget = domains > 0 ? domains : ORC_MAX_LEVEL_DOMAINS; }
 
-int orc_narrow_phase(const double* V0, const double* V1, int nV, const int32_t* E, int nE,
-                     const int32_t* F, int nF, const int32_t* pairs, int64_t n, int is_vf, double ms,
-                     int max_iter, double tol, int allow_zero_toi, int arith, double* toi_io,
-                     double* per_query_toi, orc_np_stats* stats)
-{
-    orc_np_stats st;
-    memset(&st, 0, sizeof st);
-    st.n_queries = n;
-    double toi = *toi_io;
-    const int use_ms = ms > 0; /* narrow_phase.cu:128 */
-    const int per_query = per_query_toi != NULL;
-    /* narrow_phase.cu:136: loop guard toi > 0 (not in TOI_PER_QUERY builds) */
-    if (n > 0 && (toi > 0 || per_query)) {
-        ccd_data* data = (ccd_data*)malloc(sizeof(ccd_data) * (size_t)n);
-        /* two growable level buffers instead of the reference's fixed ring (ccd_buffer.cuh:7-83) */
-        int64_t cap_cur = n + 16, cap_nxt = 2 * n + 16, n_cur = 0, n_nxt = 0;
-        ccd_domain* cur = (ccd_domain*)malloc(sizeof(ccd_domain) * (size_t)cap_cur);
-        ccd_domain* nxt = (ccd_domain*)malloc(sizeof(ccd_domain) * (size_t)cap_nxt);
-        for (int64_t i = 0; i < n; i++) {
-            gather_query(V0, V1, nV, E, nE, F, nF, pairs[2 * i], pairs[2 * i + 1], is_vf, data[i].v);
-            data[i].ms = ms;
-            data[i].toi = INFINITY; /* narrow_phase.cu:70 */
-            data[i].nbr_checks = 0;
-            orc_query_constants(&data[i].v[0][0], is_vf, use_ms, tol, data[i].tol, data[i].err); /* compute_tolerance :260-275 */
-            ccd_domain d0 = { { 0, 0, 0 }, { 1, 1, 1 }, (int)i }; /* initialize_buffer ccd_buffer.cuh:70-77 */
-            cur[n_cur++] = d0;
-        }
-        /* level loop root_finder.cu:431-447 */
-        int level = 0;
-        while (n_cur > 0) {
-            if (n_cur > st.max_queue) st.max_queue = n_cur;
-            n_nxt = 0;
-            for (int64_t h = 0; h < n_cur; h++) {
-                const ccd_domain dom = cur[h];
-                ccd_data* d = &data[dom.query_id];
-                const int before = d->nbr_checks; /* data_in copy :288 */
-                d->nbr_checks++;                  /* atomicAdd :289 */
-                st.n_domains++;
-                ccd_domain kids[2];
-                int nk, checked;
-                const double prune = per_query ? d->toi : toi;
-                const int acc = ccd_step(d, &dom, is_vf, arith, tol, allow_zero_toi, max_iter, before,
-                                         prune, kids, &nk, &checked);
-                st.n_checks += checked;
-                if (acc) {
-                    if (dom.lo[0] < toi) toi = dom.lo[0]; /* atomicMin(toi, min_t) */
-                    if (dom.lo[0] < d->toi) d->toi = dom.lo[0];
-                }
-                if (nk && level == 0) st.n_root_survive++;
-                if (n_nxt + 2 > cap_nxt) {
-                    /* Level order keeps every live domain of a level: a contact-rich query set grows like
-                     * (1/tolerance)^2 (per-query mode has no global bound to prune by).  Give up at a fixed
-                     * budget instead of taking the host's memory (that took two test machines down). */
-                    if (cap_nxt >= g_level_budget) {
-                        free(cur);
-                        free(nxt);
-                        free(data);
-                        *toi_io = NAN;
-                        if (stats) *stats = st;
-                        return ORC_E_BUDGET;
-                    }
-                    cap_nxt *= 2;
-                    nxt = (ccd_domain*)realloc(nxt, sizeof(ccd_domain) * (size_t)cap_nxt);
-                }
-                for (int k = 0; k < nk; k++) nxt[n_nxt++] = kids[k];
-            }
-            /* shift_queue_start ccd_buffer.cuh:41-52: the children become the next level */
-            ccd_domain* tp = cur; cur = nxt; nxt = tp;
-            int64_t tc = cap_cur; cap_cur = cap_nxt; cap_nxt = tc;
-            n_cur = n_nxt;
-            level++;
-        }
-        for (int64_t i = 0; i < n; i++) {
-            if (data[i].nbr_checks > st.max_checks_per_query) st.max_checks_per_query = data[i].nbr_checks;
-            if (per_query_toi) per_query_toi[i] = data[i].toi;
-        }
-        free(cur);
-        free(nxt);
-        free(data);
-    }
-    *toi_io = toi;
-    if (stats) *stats = st;
-    return 0;
-}
+#define REAL double
+#define NM(x) x
+#define R_MAX DBL_MAX
+#define R_EPS DBL_EPSILON
+#define R_ABS(x) fabs(x)
+#define R_FMA(a, b, c) fma(a, b, c)
+#define R_BITS int64_t
+#define R_FILTERS { 6.661338147750939e-15, 6.217248937900877e-15, 7.549516567451064e-15, 7.105427357601002e-15 }
+#include "np_core.inc"
+#undef REAL
+#undef NM
+#undef R_MAX
+#undef R_EPS
+#undef R_ABS
+#undef R_FMA
+#undef R_BITS
+#undef R_FILTERS
 
-/* shared non-negative double min via the IEEE bit pattern (atomic_min_float.cuh:17-29) */
-static inline void atomic_min_double(double* addr, double val)
+/* SCALABLE_CCD_USE_DOUBLE off: Scalar = float.  Vertices are cast to float FIRST (aabb.cpp:43-47, ccd.cu:103-106),
+ * then everything -- boxes, tolerances, error bounds, the inclusion function, mid-points, the TOI -- is float
+ * arithmetic; the float filter constants are root_finder.cu:103-119, the bound of sum_less_than_one uses
+ * FLT_EPSILON (:21-29).  The *_f32 entry points take float arrays. */
+static inline float nextafter_down_f32(float x) { return nextafterf(x, -FLT_MAX); }
+static inline float nextafter_up_f32(float x) { return nextafterf(x, FLT_MAX); }
+void orc_build_vertex_boxes_f32(const float* V0, const float* V1, int nV, float r, orc_aabb* out)
 {
-    int64_t v, old;
-    memcpy(&v, &val, 8);
-    old = __atomic_load_n((int64_t*)addr, __ATOMIC_RELAXED);
-    while (v < old && !__atomic_compare_exchange_n((int64_t*)addr, &old, v, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
-}
-
-int orc_narrow_phase_mt(const double* V0, const double* V1, int nV, const int32_t* E, int nE,
-                        const int32_t* F, int nF, const int32_t* pairs, int64_t n, int is_vf, double ms,
-                        int max_iter, double tol, int allow_zero_toi, int arith, double* toi_io,
-                        int32_t* checks_per_query, int nthreads)
-{
-    double toi = *toi_io;
-    const int use_ms = ms > 0;
-    if (n <= 0 || !(toi > 0)) return 0;
-    int nt = nthreads > 0 ? nthreads : 1;
-#pragma omp parallel num_threads(nt)
-    {
-        int cap = 256;
-        ccd_domain* stack = (ccd_domain*)malloc(sizeof(ccd_domain) * (size_t)cap);
-#pragma omp for schedule(dynamic, 512)
-        for (int64_t i = 0; i < n; i++) {
-            ccd_data d;
-            gather_query(V0, V1, nV, E, nE, F, nF, pairs[2 * i], pairs[2 * i + 1], is_vf, d.v);
-            d.ms = ms;
-            orc_query_constants(&d.v[0][0], is_vf, use_ms, tol, d.tol, d.err);
-            int sp = 0, checks = 0;
-            ccd_domain d0 = { { 0, 0, 0 }, { 1, 1, 1 }, (int)i };
-            stack[sp++] = d0;
-            while (sp > 0) {
-                const ccd_domain dom = stack[--sp];
-                ccd_domain kids[2];
-                int nk, checked;
-                double cur;
-                {
-                    const int64_t bits = __atomic_load_n((int64_t*)&toi, __ATOMIC_RELAXED);
-                    memcpy(&cur, &bits, 8);
-                }
-                const int acc = ccd_step(&d, &dom, is_vf, arith, tol, allow_zero_toi, max_iter, checks, cur,
-                                         kids, &nk, &checked);
-                checks++;
-                if (acc) atomic_min_double(&toi, dom.lo[0]);
-                if (sp + 2 > cap) {
-                    cap *= 2;
-                    stack = (ccd_domain*)realloc(stack, sizeof(ccd_domain) * (size_t)cap);
-                }
-                /* push the later half first so the earlier half is explored first */
-                if (nk == 2) stack[sp++] = kids[1];
-                if (nk >= 1) stack[sp++] = kids[0];
-            }
-            if (checks_per_query) checks_per_query[i] = checks;
+    const float ru = nextafter_up_f32(r);
+    for (int i = 0; i < nV; i++) {
+        for (int k = 0; k < 3; k++) {
+            const float p0 = V0[i + (size_t)k * nV], p1 = V1[i + (size_t)k * nV];
+            const float l0 = nextafter_down_f32(p0) - ru, l1 = nextafter_down_f32(p1) - ru;
+            const float h0 = nextafter_up_f32(p0) + ru, h1 = nextafter_up_f32(p1) + ru;
+            out[i].min[k] = (l1 < l0) ? l1 : l0; /* float values in the double fields: every compare downstream is exact */
+            out[i].max[k] = (h0 < h1) ? h1 : h0;
         }
-        free(stack);
+        out[i].vertex_ids[0] = i;
+        out[i].vertex_ids[1] = -i - 1;
+        out[i].vertex_ids[2] = -i - 1;
+        out[i].element_id = i;
     }
-    *toi_io = toi;
-    return 0;
 }
-
-/* ccd(): src/scalable_ccd/cuda/ccd.cu:80-146 */
-int orc_ccd(const double* V0, const double* V1, int nV, const int32_t* E, int nE, const int32_t* F,
-            int nF, double ms, int max_iter, double tol, int allow_zero_toi, int arith, int nthreads,
-            double* toi_out, int64_t* n_vf, int64_t* n_ee)
-{
-    orc_aabb* vb = (orc_aabb*)malloc(sizeof(orc_aabb) * (size_t)(nV ? nV : 1));
-    orc_aabb* eb = (orc_aabb*)malloc(sizeof(orc_aabb) * (size_t)(nE ? nE : 1));
-    orc_aabb* fb = (orc_aabb*)malloc(sizeof(orc_aabb) * (size_t)(nF ? nF : 1));
-    orc_build_vertex_boxes(V0, V1, nV, ms, vb); /* ccd.cu:112: inflation radius = min_distance */
-    orc_build_edge_boxes(vb, E, nE, eb);
-    orc_build_face_boxes(vb, F, nF, fb);
-    double toi = 1; /* ccd.cu:125 */
-    int axis = 0;   /* device path always sorts on x: aabb.cu:85-86 */
-    int32_t* pairs = NULL;
-    int64_t nvf = orc_sort_and_sweep_two_lists(vb, nV, fb, nF, &axis, &pairs, nthreads);
-    int rc = 0;
-    if (nthreads > 1)
-        orc_narrow_phase_mt(V0, V1, nV, E, nE, F, nF, pairs, nvf, 1, ms, max_iter, tol, allow_zero_toi, arith, &toi, NULL, nthreads);
-    else
-        rc = orc_narrow_phase(V0, V1, nV, E, nE, F, nF, pairs, nvf, 1, ms, max_iter, tol, allow_zero_toi, arith, &toi, NULL, NULL);
-    free(pairs);
-    pairs = NULL;
-    axis = 0;
-    int64_t nee = orc_sort_and_sweep(eb, nE, &axis, &pairs, nthreads);
-    if (rc == 0) { /* (a vertex-face pass that ran out of its level budget leaves nothing to seed the edge-edge pass with) */
-        if (nthreads > 1)
-            orc_narrow_phase_mt(V0, V1, nV, E, nE, F, nF, pairs, nee, 0, ms, max_iter, tol, allow_zero_toi, arith, &toi, NULL, nthreads);
-        else
-            rc = orc_narrow_phase(V0, V1, nV, E, nE, F, nF, pairs, nee, 0, ms, max_iter, tol, allow_zero_toi, arith, &toi, NULL, NULL);
-    }
-    free(pairs);
-    free(vb);
-    free(eb);
-    free(fb);
-    *toi_out = toi;
-    if (n_vf) *n_vf = nvf;
-    if (n_ee) *n_ee = nee;
-    return rc;
-}
+#define REAL float
+#define NM(x) x##_f32
+#define R_MAX FLT_MAX
+#define R_EPS FLT_EPSILON
+#define R_ABS(x) fabsf(x)
+#define R_FMA(a, b, c) fmaf(a, b, c)
+#define R_BITS int32_t
+#define R_FILTERS { 3.576279e-06, 3.337861e-06, 4.053116e-06, 3.814698e-06 }
+#include "np_core.inc"

@@ -107,6 +107,25 @@ int orc_origin_in_inclusion_function(const double* v, const double* dom, const d
 void orc_query_constants(const double* v, int is_vf, int use_ms, double co_domain_tol,
                          double* tol3, double* err3);
 
+/* ---- SCALABLE_CCD_USE_DOUBLE = OFF: the same path with Scalar = float (scalar.hpp:13-21).
+ * Vertices are cast to float first (aabb.cpp:43-47), then boxes, tolerances, error bounds (float filter
+ * constants root_finder.cu:103-119), inclusion function, mid-points and the TOI are float arithmetic.
+ * Float arrays in and out; boxes keep the 64-byte layout with the float values widened (every comparison
+ * of the broad phase is exact on them, so orc_sort_and_sweep* serve both scalar types). */
+void orc_build_vertex_boxes_f32(const float* V0, const float* V1, int nV, float inflation_radius, orc_aabb* out);
+int orc_narrow_phase_f32(const float* V0, const float* V1, int nV, const int32_t* E, int nE, const int32_t* F, int nF,
+                         const int32_t* pairs, int64_t n, int is_vf, float ms, int max_iter, float tol,
+                         int allow_zero_toi, int arith, float* toi, float* per_query_toi, orc_np_stats* stats);
+int orc_narrow_phase_mt_f32(const float* V0, const float* V1, int nV, const int32_t* E, int nE, const int32_t* F,
+                            int nF, const int32_t* pairs, int64_t n, int is_vf, float ms, int max_iter, float tol,
+                            int allow_zero_toi, int arith, float* toi, int32_t* checks_per_query, int nthreads);
+int orc_ccd_f32(const float* V0, const float* V1, int nV, const int32_t* E, int nE, const int32_t* F, int nF, float ms,
+                int max_iter, float tol, int allow_zero_toi, int arith, int nthreads, float* toi, int64_t* n_vf,
+                int64_t* n_ee);
+int orc_origin_in_inclusion_function_f32(const float* v, const float* dom, const float* err, float ms, int is_vf,
+                                         int arith, float* true_tol, int* box_in);
+void orc_query_constants_f32(const float* v, int is_vf, int use_ms, float co_domain_tol, float* tol3, float* err3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -221,3 +221,59 @@ def test_level_order_gives_up_at_its_domain_budget(orc):
         orc.lib().orc_set_level_budget(C.c_int64(0))
     toi, _, st = orc.narrow_phase(V0, V1, E, F, [[0, 0]], True, allow_zero_toi=False, per_query=True)
     assert toi == 0.0 and st["max_queue"] > 1 << 20
+
+
+# ---- SCALABLE_CCD_USE_DOUBLE = OFF twin (Scalar = float) ----------------------------------------
+def test_f32_boxes_are_float_valued_and_conservative(orc):
+    """aabb.cpp:43-47: vertices are cast to float FIRST, then inflated with nextafterf -- the float box still
+    contains the double box of the same vertex, and every coordinate is a float."""
+    V0, V1, E, F = scenes.cloth_ball(12, 1, seed=4)
+    for r in (0.0, 1e-3):
+        v64, e64, f64 = orc.build_boxes(V0, V1, E, F, r)
+        v32, e32, f32 = orc.build_boxes(V0, V1, E, F, r, scalar="f32")
+        for b64, b32 in ((v64, v32), (e64, e32), (f64, f32)):
+            assert np.array_equal(b32["min"], b32["min"].astype(np.float32).astype(np.float64))
+            assert np.array_equal(b32["max"], b32["max"].astype(np.float32).astype(np.float64))
+            assert np.all(b32["min"] <= b64["min"] + 1e-9) and np.all(b32["max"] >= b64["max"] - 1e-9)
+            assert np.array_equal(b32["vertex_ids"], b64["vertex_ids"])
+    # one vertex by hand: p = 0.1 (not a float), r = 0
+    vb, _, _ = orc.build_boxes(np.array([[0.1, 0.1, 0.1]]), np.array([[0.1, 0.1, 0.1]]), np.zeros((0, 2), np.int32),
+                               np.zeros((0, 3), np.int32), 0.0, scalar="f32")
+    p = np.float32(0.1)
+    tiny = np.nextafter(np.float32(0), np.float32(1))
+    assert vb["min"][0, 0] == float(np.float32(np.nextafter(p, np.float32(-np.inf)) - tiny))
+    assert vb["max"][0, 0] == float(np.float32(np.nextafter(p, np.float32(np.inf)) + tiny))
+
+
+@pytest.mark.parametrize("arith", [0, 1])
+def test_f32_narrow_phase_known_answers(orc, arith):
+    V0 = np.array([[0.25, 0.25, 1.0], [0, 0, 0], [1, 0, 0], [0, 1, 0]], float)
+    V1 = V0.copy()
+    V1[0, 2] = -1.0
+    E = np.array([[1, 2], [2, 3], [1, 3]], np.int32)
+    F = np.array([[1, 2, 3]], np.int32)
+    toi, _, st = orc.narrow_phase(V0, V1, E, F, [[0, 0]], True, arith=arith, scalar="f32")
+    assert 0.5 - 1e-4 <= toi <= 0.5 and toi == float(np.float32(toi))  # a float, within the float tolerance of t* = 0.5
+    assert st["n_checks"] > 10
+    assert orc.narrow_phase(V0, V1, E, F, [[0, 0]], True, toi=0.25, scalar="f32")[0] == 0.25
+    V1[0, 2] = 0.5  # never reaches the triangle
+    assert orc.narrow_phase(V0, V1, E, F, [[0, 0]], True, scalar="f32")[0] == 1.0
+    # per-query constants: err = max(1, |coords|)^3 * the FLOAT filter (root_finder.cu:103-119)
+    v = np.arange(24, dtype=np.float32).reshape(8, 3) * np.float32(0.25)
+    tol, err = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    orc.lib().orc_query_constants_f32(v.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_int(0), C.c_float(1e-6),
+                                      tol.ctypes.data_as(C.c_void_p), err.ctypes.data_as(C.c_void_p))
+    m = np.maximum(np.float32(1), np.abs(v).max(axis=0))
+    assert np.array_equal(err, (m * m * m * np.float32(3.576279e-06)).astype(np.float32))
+
+
+def test_f32_traversal_orders_agree_and_track_the_double_result(orc):
+    """Level order and depth-first with a shared minimum give the same float TOI bit for bit; the float result
+    stays within the float tolerance of the double one; float boxes can only add candidate pairs."""
+    for V0, V1, E, F in (scenes.cloth_ball(20, 1, seed=3), scenes.triangle_soup(150, seed=9, size=0.12, motion=0.3)):
+        t64, nvf64, nee64 = orc.ccd(V0, V1, E, F, nthreads=4)
+        t_a, nvf, nee = orc.ccd(V0, V1, E, F, scalar="f32", nthreads=1)
+        t_b, nvf_b, nee_b = orc.ccd(V0, V1, E, F, scalar="f32", nthreads=4)
+        assert t_a == t_b and (nvf, nee) == (nvf_b, nee_b)
+        assert nvf >= nvf64 and nee >= nee64
+        assert abs(t_a - t64) < 1e-3 and t_a == float(np.float32(t_a))
