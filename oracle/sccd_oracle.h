@@ -11,7 +11,9 @@
  * therefore checked against (a) an independent O(n^2) brute-force pair finder, (b) analytic
  * known-answer TOI cases and (c) line-by-line citation of the reference below.
  *
- * Scalar = double (reference default, CMakeLists.txt:69 SCALABLE_CCD_USE_DOUBLE=ON).
+ * Scalar = double (reference default, CMakeLists.txt:69 SCALABLE_CCD_USE_DOUBLE=ON) for every orc_* function;
+ * the orc_*_f32 twins at the end restate the SCALABLE_CCD_USE_DOUBLE=OFF build (Scalar = float).  The narrow
+ * phase and ccd() are written once in np_core.inc and compiled for both.
  */
 #ifndef SCCD_ORACLE_H
 #define SCCD_ORACLE_H
