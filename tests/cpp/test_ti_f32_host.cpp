@@ -1,0 +1,167 @@
+// Host-side check of csrc/ti_math_f32.hpp (the float arithmetic the level-synchronous kernels run with
+// SCCD_OPT_SCALAR = 1) against the CPU oracle's float twin, operation for operation: per-query constants,
+// single inclusion-function evaluations, and whole queries walked depth-first with tif_step vs orc_narrow_phase_f32.
+// Built by tests/test_ti_f32_host.py with g++ -ffp-contract=off -mfma (no GPU needed).
+#include "sccd_oracle.h"
+#include "ti_math_f32.hpp"
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+static uint64_t g_s = 0x9E3779B97F4A7C15ull;
+static double rnd()
+{ // splitmix64 -> [0,1)
+    uint64_t z = (g_s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+static int fails = 0;
+#define CHECK(c)                                                       \
+    do {                                                               \
+        if (!(c)) {                                                    \
+            if (fails < 20) std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); \
+            ++fails;                                                   \
+        }                                                              \
+    } while (0)
+static bool same(float a, float b) { return std::memcmp(&a, &b, 4) == 0 || (a == b); }
+
+template <bool VF, int ARITH> static float walk(const TIQueryF& q, float ms, float tol, bool allow_zero, long* checks)
+{
+    struct Dom {
+        float lo[3], hi[3];
+    };
+    std::vector<Dom> st;
+    st.push_back(Dom { { 0, 0, 0 }, { 1, 1, 1 } });
+    float toi = 1;
+    while (!st.empty()) {
+        const Dom d = st.back();
+        st.pop_back();
+        const TIStepF s = tif_step<VF, ARITH>(q, d.lo, d.hi, ms, tol, allow_zero, toi);
+        if (s.checked) ++*checks;
+        if (*checks > 4000000) return -1.0f; // runaway (see main): the caller skips the comparison
+        if (s.accept && d.lo[0] < toi) toi = d.lo[0];
+        if (s.nk == 2) {
+            Dom c = d;
+            c.lo[s.split] = s.mid;
+            st.push_back(c);
+        }
+        if (s.nk >= 1) {
+            Dom c = d;
+            c.hi[s.split] = s.mid;
+            st.push_back(c);
+        }
+    }
+    return toi;
+}
+
+template <bool VF, int ARITH>
+static void run_case(int n_queries, float scale, float ms, bool allow_zero, long* hits, long* skipped)
+{
+    const float tol = 1e-6f;
+    for (int it = 0; it < n_queries; it++) {
+        // a moving point / edge falling through a slowly moving triangle / edge
+        float V0[12], V1[12]; // column-major 4 x 3
+        auto set = [&](float* M, int i, double x, double y, double z) {
+            M[i] = (float)(x * scale);
+            M[i + 4] = (float)(y * scale);
+            M[i + 8] = (float)(z * scale);
+        };
+        if (VF) {
+            const double x = rnd(), y = rnd() * (1 - x);
+            set(V0, 0, x, y, 0.2 + 0.5 * rnd());
+            set(V1, 0, x + 0.1 * (rnd() - 0.5), y + 0.1 * (rnd() - 0.5), -0.2 - 0.5 * rnd());
+            for (int j = 1; j < 4; j++) {
+                const double px = (j == 2) ? 1.0 : 0.0, py = (j == 3) ? 1.0 : 0.0;
+                set(V0, j, px + 0.05 * rnd(), py + 0.05 * rnd(), 0.05 * (rnd() - 0.5));
+                set(V1, j, px + 0.05 * rnd(), py + 0.05 * rnd(), 0.05 * (rnd() - 0.5));
+            }
+        } else {
+            set(V0, 0, rnd(), 0.0, 0.2 + 0.5 * rnd());
+            set(V0, 1, rnd(), 1.0, 0.2 + 0.5 * rnd());
+            set(V1, 0, rnd(), 0.0, -0.2 - 0.5 * rnd());
+            set(V1, 1, rnd(), 1.0, -0.2 - 0.5 * rnd());
+            set(V0, 2, 0.0, rnd(), 0.05 * (rnd() - 0.5));
+            set(V0, 3, 1.0, rnd(), 0.05 * (rnd() - 0.5));
+            set(V1, 2, 0.0, rnd(), 0.05 * (rnd() - 0.5));
+            set(V1, 3, 1.0, rnd(), 0.05 * (rnd() - 0.5));
+        }
+        TIQueryF q;
+        for (int j = 0; j < 4; j++)
+            for (int k = 0; k < 3; k++) {
+                q.v[j][k] = V0[j + 4 * k];
+                q.v[j + 4][k] = V1[j + 4 * k];
+            }
+        tif_tolerance<VF>(q.v, tol, q.tol);
+        tif_error<VF>(q.v, ms > 0, q.err);
+        float otol[3], oerr[3];
+        orc_query_constants_f32(&q.v[0][0], VF ? 1 : 0, ms > 0, tol, otol, oerr);
+        for (int k = 0; k < 3; k++) {
+            CHECK(same(q.tol[k], otol[k]));
+            CHECK(same(q.err[k], oerr[k]));
+        }
+        // single evaluations on random dyadic sub-domains
+        for (int r = 0; r < 4; r++) {
+            float lo[3], hi[3], dom[6];
+            for (int k = 0; k < 3; k++) {
+                const int d = (int)(rnd() * 6);
+                const int kk = (int)(rnd() * (1 << d));
+                lo[k] = (float)kk / (float)(1 << d);
+                hi[k] = (float)(kk + 1) / (float)(1 << d);
+                dom[2 * k] = lo[k];
+                dom[2 * k + 1] = hi[k];
+            }
+            float tt = 0, ott = 0;
+            bool bi = false;
+            int obi = 0;
+            const bool a = tif_inclusion<VF, ARITH>(q.v, lo, hi, q.err, ms, tt, bi);
+            const int b = orc_origin_in_inclusion_function_f32(&q.v[0][0], dom, q.err, ms, VF ? 1 : 0, ARITH, &ott, &obi);
+            CHECK(a == (b != 0));
+            if (a && b) {
+                CHECK(same(tt, ott));
+                CHECK(bi == (obi != 0));
+            }
+        }
+        // the whole query
+        long checks = 0;
+        const float got = walk<VF, ARITH>(q, ms, tol, allow_zero, &checks);
+        if (got < 0) { // not compared: the oracle's level order would need the same astronomical number of domains
+            ++*skipped;
+            continue;
+        }
+        const int32_t E[4] = { 0, 2, 1, 3 }; // column-major 2 x 2: edges (0,1) and (2,3)
+        const int32_t F[3] = { 1, 2, 3 };
+        const int32_t pair_vf[2] = { 0, 0 }, pair_ee[2] = { 0, 1 };
+        float want = 1;
+        orc_np_stats st;
+        orc_narrow_phase_f32(V0, V1, 4, E, 2, F, 1, VF ? pair_vf : pair_ee, 1, VF ? 1 : 0, ms, -1, tol, allow_zero ? 1 : 0,
+                             ARITH, &want, nullptr, &st);
+        CHECK(same(got, want));
+        if (want < 1) ++*hits;
+    }
+}
+
+int main()
+{
+    // Coordinates of order one and below only.  The float build's error bound is max(1, |x|)^3 * 3.6e-6
+    // (root_finder.cu:103-119): at |x| ~ 40 it is 0.2, the set of domains whose image merely TOUCHES that fat
+    // box around the origin has to be resolved down to float resolution, and a single query needs > 1e8 checks
+    // -- in the reference's float build just the same.  Queries that still run away are skipped and counted.
+    long hits = 0, skipped = 0;
+    const int n = 25;
+    for (float scale : { 1.0f, 0.3f, 0.01f })
+        for (float ms : { 0.0f, 1e-3f })
+            for (bool az : { true, false }) {
+                run_case<true, 0>(n, scale, ms * scale, az, &hits, &skipped);
+                run_case<true, 1>(n, scale, ms * scale, az, &hits, &skipped);
+                run_case<false, 0>(n, scale, ms * scale, az, &hits, &skipped);
+                run_case<false, 1>(n, scale, ms * scale, az, &hits, &skipped);
+            }
+    const int total = 3 * 2 * 2 * 4 * n;
+    std::printf("test_ti_f32_host: %d failure(s), %ld colliding queries of %d, %ld skipped (runaway)\n", fails, hits, total,
+                skipped);
+    return (fails == 0 && hits > total / 4 && skipped < total / 10) ? 0 : 1;
+}
