@@ -77,6 +77,10 @@ int sccd_synchronize(sccd_ctx* ctx);
 #define SCCD_OPT_PROFILE 8          /* hipEvents around kernel classes (sccd_get_profile): 1 = all, (class mask) << 1 = some  */
 #define SCCD_OPT_MAX_OVERLAP_CUTOFF 9 /* boxes swept per detect_overlaps_partial call (0 = all; memory_handler.hpp:9)      */
 #define SCCD_OPT_MEMORY_LIMIT_MB 10 /* memory budget of the overlap list in MiB (0 = none; MemoryHandler::memory_limit_GB)  */
+#define SCCD_OPT_SCALAR 11          /* 0 double (default, SCALABLE_CCD_USE_DOUBLE=ON); 1 float (=OFF, scalar.hpp:13-21): vertices are
+                                       cast to float first, boxes / tolerances / inclusion function / TOI are float arithmetic
+                                       (values travel widened in the same double-typed interfaces); narrow phase on the
+                                       level-synchronous kernels.  NOT YET RUN ON A GPU (arithmetic checked on the host).        */
 int sccd_set_option(sccd_ctx* ctx, int option, int64_t value);
 int64_t sccd_get_option(const sccd_ctx* ctx, int option);
 

@@ -229,6 +229,7 @@ int sccd_set_option(sccd_ctx* c, int opt, int64_t v)
     case SCCD_OPT_PROFILE: c->profile = (int)v; break; // 0 off, 1 every class, else (mask of classes) << 1
     case SCCD_OPT_MAX_OVERLAP_CUTOFF: c->max_overlap_cutoff = v; break;
     case SCCD_OPT_MEMORY_LIMIT_MB: c->memory_limit_mb = v; break;
+    case SCCD_OPT_SCALAR: c->scalar_f32 = v ? 1 : 0; break;
     default: c->err = "unknown option"; return SCCD_E_INVALID;
     }
     return SCCD_OK;
@@ -248,6 +249,7 @@ int64_t sccd_get_option(const sccd_ctx* c, int opt)
     case SCCD_OPT_PROFILE: return c->profile;
     case SCCD_OPT_MAX_OVERLAP_CUTOFF: return c->max_overlap_cutoff;
     case SCCD_OPT_MEMORY_LIMIT_MB: return c->memory_limit_mb;
+    case SCCD_OPT_SCALAR: return c->scalar_f32;
     default: return 0;
     }
 }
@@ -1084,6 +1086,10 @@ struct NarrowResult {
 static NarrowParams narrow_params(sccd_ctx* c, const sccd_mesh* m, const int2* d_pairs, int64_t n, int is_vf, int max_iter,
                                   double tol, double ms, int allow_zero_toi)
 {
+    if (c->scalar_f32) { // the float build takes Scalar (= float) arguments (narrow_phase.cuh:30-46)
+        tol = (double)(float)tol;
+        ms = (double)(float)ms;
+    }
     NarrowParams p;
     p.V = m->V.as<double>();
     p.E = m->E.as<int2>();
@@ -1108,6 +1114,7 @@ static NarrowResult run_narrow(sccd_ctx* c, const sccd_mesh* m, const int2* d_pa
                                double tol, double ms, int allow_zero_toi, double* toi, double* d_per_query)
 {
     const NarrowParams p = narrow_params(c, m, d_pairs, n, is_vf, max_iter, tol, ms, allow_zero_toi);
+    if (c->scalar_f32) *toi = (double)(float)*toi;
     narrow_phase_run(c, p, narrow_counters(c), toi, d_per_query);
     return narrow_result(c);
 }

@@ -125,11 +125,14 @@ struct StatsAcc {
 //   lo = min(nextafter_down(p0) - nextafter_up(r), nextafter_down(p1) - nextafter_up(r))
 //   hi = max(nextafter_up(p0)   + nextafter_up(r), nextafter_up(p1)   + nextafter_up(r))
 // (aabb.cu:19-37, aabb.cuh:55-63; ids aabb.cu:180-181)
+// f32: the reference's float build -- vertices and radius cast to float FIRST (aabb.cpp:43-47, aabb.cu:124-128),
+// nextafterf and float sums; the float results are stored widened (every later comparison is exact on them)
 __global__ void vertex_boxes_k(const double* __restrict__ V, int nV, double r, sccd_aabb* __restrict__ out,
-                               GridStats* __restrict__ st, double* __restrict__ part)
+                               GridStats* __restrict__ st, double* __restrict__ part, int f32)
 {
     StatsAcc acc;
     const double ru = nextafter_up(r);
+    const float ru_f = nextafter_up_f((float)r);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nV; i += gridDim.x * blockDim.x) {
         const double2* v = reinterpret_cast<const double2*>(V) + 3 * (size_t)i;
         const double2 a = v[0], b = v[1], c2 = v[2];
@@ -137,6 +140,14 @@ __global__ void vertex_boxes_k(const double* __restrict__ V, int nV, double r, s
         double lo[3], hi[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
+            if (f32) {
+                const float q0 = (float)p0[k], q1 = (float)p1[k];
+                const float l0 = nextafter_down_f(q0) - ru_f, l1 = nextafter_down_f(q1) - ru_f;
+                const float h0 = nextafter_up_f(q0) + ru_f, h1 = nextafter_up_f(q1) + ru_f;
+                lo[k] = (l1 < l0) ? l1 : l0;
+                hi[k] = (h0 < h1) ? h1 : h0;
+                continue;
+            }
             const double l0 = nextafter_down(p0[k]) - ru, l1 = nextafter_down(p1[k]) - ru;
             const double h0 = nextafter_up(p0[k]) + ru, h1 = nextafter_up(p1[k]) + ru;
             lo[k] = (l1 < l0) ? l1 : l0;
@@ -557,7 +568,7 @@ int launch_vertex_boxes(sccd_ctx* c, const double* dV, int nV, double inflation,
 {
     if (nV == 0) return 0;
     const int grid = std::min(grid_for(nV), SCCD_STATS_BLOCKS);
-    hipLaunchKernelGGL(vertex_boxes_k, dim3(grid), dim3(TPB), 0, c->stream, dV, nV, inflation, out, st, part);
+    hipLaunchKernelGGL(vertex_boxes_k, dim3(grid), dim3(TPB), 0, c->stream, dV, nV, inflation, out, st, part, c->scalar_f32);
     SCCD_HIP(hipGetLastError());
     return grid;
 }

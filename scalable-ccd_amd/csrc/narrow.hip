@@ -16,6 +16,7 @@
 //           (root_finder.cu:431-447).  Kept as the in-library cross-check.
 #include "internal.hpp"
 #include "ti_math.hpp"
+#include "ti_math_f32.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -52,7 +53,9 @@ struct LvlDomain { // CCDDomain (interval.cuh:30-44)
     int pad;
 };
 
-template <bool VF>
+// F32 (SCCD_OPT_SCALAR = 1, the reference's float build): the vertices are cast to float first (ccd.cu:103-106) and
+// every quantity is float arithmetic (ti_math_f32.hpp); the float values are stored widened in the same records.
+template <bool VF, bool F32>
 __global__ void np_level_init_k(const double* __restrict__ V, const int2* __restrict__ E, const int4* __restrict__ F,
                                 const int2* __restrict__ pairs, long long first, long long n, double tol, bool use_ms,
                                 LvlData* __restrict__ data, LvlDomain* __restrict__ dom)
@@ -63,8 +66,27 @@ __global__ void np_level_init_k(const double* __restrict__ V, const int2* __rest
     const long long i = first + j;
     TIQuery q;
     ti_gather<VF>(V, E, F, pairs[i], q.v);
-    ti_tolerance<VF>(q.v, tol, q.tol);
-    ti_error<VF>(q.v, use_ms, q.err);
+    if (F32) {
+        TIQueryF qf;
+#pragma unroll
+        for (int a = 0; a < 8; a++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) qf.v[a][k] = (float)q.v[a][k];
+        tif_tolerance<VF>(qf.v, (float)tol, qf.tol);
+        tif_error<VF>(qf.v, use_ms, qf.err);
+#pragma unroll
+        for (int a = 0; a < 8; a++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) q.v[a][k] = qf.v[a][k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            q.tol[k] = qf.tol[k];
+            q.err[k] = qf.err[k];
+        }
+    } else {
+        ti_tolerance<VF>(q.v, tol, q.tol);
+        ti_error<VF>(q.v, use_ms, q.err);
+    }
     LvlData d;
 #pragma unroll
     for (int a = 0; a < 8; a++)
@@ -90,7 +112,7 @@ __global__ void np_level_init_k(const double* __restrict__ V, const int2* __rest
     dom[j] = r;
 }
 
-template <bool VF, int ARITH>
+template <bool VF, int ARITH, bool F32>
 __global__ void np_level_k(const LvlDomain* __restrict__ cur, long long n_cur, LvlDomain* __restrict__ nxt,
                            unsigned long long* __restrict__ n_nxt, LvlData* __restrict__ data, double ms,
                            double tol, int max_iter, bool allow_zero_toi, bool per_query,
@@ -115,7 +137,30 @@ __global__ void np_level_k(const LvlDomain* __restrict__ cur, long long n_cur, L
     const double prune = per_query ? toi_load(&dp->toi_bits) : toi_load(&cnt->toi_bits);
     if (dom.lo[0] >= prune) return;                       // :295
     if (max_iter >= 0 && before > max_iter) return;       // :303
-    const TIStep s = ti_step<VF, ARITH>(q, dom.lo, dom.hi, ms, tol, allow_zero_toi, prune);
+    TIStep s;
+    if (F32) { // (every stored value is a float: the casts are exact)
+        TIQueryF qf;
+#pragma unroll
+        for (int a = 0; a < 8; a++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) qf.v[a][k] = (float)q.v[a][k];
+        float lo[3], hi[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            qf.err[k] = (float)q.err[k];
+            qf.tol[k] = (float)q.tol[k];
+            lo[k] = (float)dom.lo[k];
+            hi[k] = (float)dom.hi[k];
+        }
+        const TIStepF sf = tif_step<VF, ARITH>(qf, lo, hi, (float)ms, (float)tol, allow_zero_toi, (float)prune);
+        s.accept = sf.accept;
+        s.nk = sf.nk;
+        s.split = sf.split;
+        s.mid = sf.mid;
+        s.checked = sf.checked;
+    } else {
+        s = ti_step<VF, ARITH>(q, dom.lo, dom.hi, ms, tol, allow_zero_toi, prune);
+    }
     if (s.checked) atomicAdd(&cnt->n_checks, 1ull);
     if (s.accept) {
         toi_min(&cnt->toi_bits, dom.lo[0]);
@@ -169,8 +214,12 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
     for (long long q0 = 0; q0 < n;) {
         const long long len = std::min(slice, n - q0);
         c->np_scratch1.ensure(sizeof(LvlDomain) * (size_t)len);
-        hipLaunchKernelGGL((np_level_init_k<VF>), dim3((unsigned)((len + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, p.V,
-                           p.E, p.F, p.pairs, q0, len, p.tol, use_ms, data, c->np_scratch1.as<LvlDomain>());
+        if (c->scalar_f32)
+            hipLaunchKernelGGL((np_level_init_k<VF, true>), dim3((unsigned)((len + TPB - 1) / TPB)), dim3(TPB), 0, c->stream,
+                               p.V, p.E, p.F, p.pairs, q0, len, p.tol, use_ms, data, c->np_scratch1.as<LvlDomain>());
+        else
+            hipLaunchKernelGGL((np_level_init_k<VF, false>), dim3((unsigned)((len + TPB - 1) / TPB)), dim3(TPB), 0, c->stream,
+                               p.V, p.E, p.F, p.pairs, q0, len, p.tol, use_ms, data, c->np_scratch1.as<LvlDomain>());
         long long n_cur = len;
         DevBuf* cur = &c->np_scratch1;
         DevBuf* nxt = &c->np_scratch2;
@@ -187,14 +236,18 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
             nxt->ensure(sizeof(LvlDomain) * (size_t)(2 * n_cur));
             SCCD_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream));
             const dim3 grid((unsigned)((n_cur + TPB - 1) / TPB));
-            if (p.arith == 1)
-                hipLaunchKernelGGL((np_level_k<VF, 1>), grid, dim3(TPB), 0, c->stream, cur->as<LvlDomain>(), n_cur,
-                                   nxt->as<LvlDomain>(), d_n, data, p.ms, p.tol, p.max_iter, (bool)p.allow_zero_toi,
-                                   d_per_query_toi != nullptr, d_cnt);
-            else
-                hipLaunchKernelGGL((np_level_k<VF, 0>), grid, dim3(TPB), 0, c->stream, cur->as<LvlDomain>(), n_cur,
-                                   nxt->as<LvlDomain>(), d_n, data, p.ms, p.tol, p.max_iter, (bool)p.allow_zero_toi,
-                                   d_per_query_toi != nullptr, d_cnt);
+#define SCCD_LAUNCH_LEVEL(AR_, F32_)                                                                                   \
+    hipLaunchKernelGGL((np_level_k<VF, AR_, F32_>), grid, dim3(TPB), 0, c->stream, cur->as<LvlDomain>(), n_cur,          \
+                       nxt->as<LvlDomain>(), d_n, data, p.ms, p.tol, p.max_iter, (bool)p.allow_zero_toi,                 \
+                       d_per_query_toi != nullptr, d_cnt)
+            if (c->scalar_f32) {
+                if (p.arith == 1) SCCD_LAUNCH_LEVEL(1, true);
+                else SCCD_LAUNCH_LEVEL(0, true);
+            } else {
+                if (p.arith == 1) SCCD_LAUNCH_LEVEL(1, false);
+                else SCCD_LAUNCH_LEVEL(0, false);
+            }
+#undef SCCD_LAUNCH_LEVEL
             SCCD_HIP(hipGetLastError());
             unsigned long long h_n = 0;
             SCCD_HIP(hipMemcpyAsync(&h_n, d_n, sizeof h_n, hipMemcpyDeviceToHost, c->stream));
@@ -250,7 +303,8 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
         // A check limit is exact only in the reference's level order.  Limits that no query comes near
         // (the IPC Toolkit passes 1e7) run on the work-queue kernel, which counts per query and hands the
         // whole call to the level-synchronous kernel if any query does get there; small limits go there directly.
-        const bool level_sync = c->narrow_algo == 1 || (p.max_iter >= 0 && p.max_iter < SCCD_QUEUE_MIN_MAX_ITER);
+        const bool level_sync = c->narrow_algo == 1 || (p.max_iter >= 0 && p.max_iter < SCCD_QUEUE_MIN_MAX_ITER)
+            || c->scalar_f32; // (the work-queue kernel is double only)
         if (level_sync) {
             if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi);
             else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi);

@@ -35,6 +35,7 @@ assert AABB_DTYPE.itemsize == 64 and COLLISION_DTYPE.itemsize == 16
 OPT_ARITH, OPT_NARROW_ALGO, OPT_SWEEP_ALGO, OPT_SORT_AXIS = 1, 2, 3, 4
 OPT_SHARD_RANK, OPT_SHARD_COUNT, OPT_OVERLAP_CAPACITY, OPT_PROFILE, OPT_MAX_OVERLAP_CUTOFF = 5, 6, 7, 8, 9
 OPT_MEMORY_LIMIT_MB = 10
+OPT_SCALAR = 11  # 1: the reference's float build (SCALABLE_CCD_USE_DOUBLE=OFF)
 PROF_NAMES = ["boxes", "sort", "ranges", "sweep", "narrow_vf", "narrow_ee"]
 
 # every symbol include/sccd.h declares (tests check that the library exports all of them)
