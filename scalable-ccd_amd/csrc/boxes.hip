@@ -7,6 +7,7 @@
 // The reference builds boxes on the host and copies 64 B/box to the device; here the mesh is
 // already resident and the boxes never leave HBM.
 #include "internal.hpp"
+#include "ti_math_f32.hpp" // nextafter_up_f / nextafter_down_f of the float build
 #include "grid.hpp"
 
 #include <algorithm>

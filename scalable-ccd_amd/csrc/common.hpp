@@ -301,28 +301,4 @@ __device__ __forceinline__ double nextafter_down(double x)
     return __longlong_as_double(b);
 }
 
-// the float twins (nextafterf(x, -+FLT_MAX), scalar.hpp:31-49 with Scalar = float)
-__device__ __forceinline__ float nextafter_up_f(float x)
-{
-    if (x != x) return x;
-    const float fmax_ = 3.402823466e+38f;
-    if (x == fmax_) return x;
-    if (x > fmax_) return fmax_;
-    if (x == 0.0f) return __int_as_float(1);
-    int b = __float_as_int(x);
-    b += (x > 0.0f) ? 1 : -1;
-    return __int_as_float(b);
-}
-__device__ __forceinline__ float nextafter_down_f(float x)
-{
-    if (x != x) return x;
-    const float fmax_ = 3.402823466e+38f;
-    if (x == -fmax_) return x;
-    if (x < -fmax_) return -fmax_;
-    if (x == 0.0f) return __int_as_float((int)0x80000001u);
-    int b = __float_as_int(x);
-    b += (x > 0.0f) ? -1 : 1;
-    return __int_as_float(b);
-}
-
 #endif // __HIPCC__

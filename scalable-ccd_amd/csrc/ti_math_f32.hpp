@@ -17,6 +17,36 @@
 #define TIF_FLT_MAX 3.402823466e+38f
 #define TIF_FLT_EPS 1.192092896e-07f
 
+// nextafterf(x, +-FLT_MAX) of the float build (scalar.hpp:31-49) by bit arithmetic, like the double twins of common.hpp
+__device__ __forceinline__ float tif_from_bits(int b)
+{
+    float f;
+    __builtin_memcpy(&f, &b, 4);
+    return f;
+}
+__device__ __forceinline__ int tif_bits(float f)
+{
+    int b;
+    __builtin_memcpy(&b, &f, 4);
+    return b;
+}
+__device__ __forceinline__ float nextafter_up_f(float x)
+{
+    if (x != x) return x;
+    if (x == TIF_FLT_MAX) return x;         // x == y
+    if (x > TIF_FLT_MAX) return TIF_FLT_MAX; // +inf steps down towards y
+    if (x == 0.0f) return tif_from_bits(1);  // smallest positive subnormal
+    return tif_from_bits(tif_bits(x) + ((x > 0.0f) ? 1 : -1));
+}
+__device__ __forceinline__ float nextafter_down_f(float x)
+{
+    if (x != x) return x;
+    if (x == -TIF_FLT_MAX) return x;
+    if (x < -TIF_FLT_MAX) return -TIF_FLT_MAX;
+    if (x == 0.0f) return tif_from_bits((int)0x80000001u);
+    return tif_from_bits(tif_bits(x) + ((x > 0.0f) ? -1 : 1));
+}
+
 struct TIQueryF {
     float v[8][3]; // v0s..v3s (t = 0), v0e..v3e (t = 1): the vertices CAST TO FLOAT FIRST (ccd.cu:103-106)
     float err[3];

@@ -144,8 +144,29 @@ static void run_case(int n_queries, float scale, float ms, bool allow_zero, long
     }
 }
 
+static void check_nextafter()
+{
+    const float specials[] = { 0.0f, -0.0f, 1.0f, -1.0f, 1e-45f, -1e-45f, 1.17549435e-38f, -1.17549435e-38f, 3.402823466e+38f,
+                               -3.402823466e+38f, __builtin_inff(), -__builtin_inff(), 0.1f, -0.1f, 16777216.0f };
+    for (float x : specials) {
+        CHECK(same(nextafter_up_f(x), __builtin_nextafterf(x, 3.402823466e+38f)));
+        CHECK(same(nextafter_down_f(x), __builtin_nextafterf(x, -3.402823466e+38f)));
+    }
+    const float nan = __builtin_nanf("");
+    CHECK(nextafter_up_f(nan) != nextafter_up_f(nan) && nextafter_down_f(nan) != nextafter_down_f(nan));
+    for (int i = 0; i < 200000; i++) {
+        const int bits = (int)(rnd() * 4294967296.0);
+        float x;
+        std::memcpy(&x, &bits, 4);
+        if (x != x) continue;
+        CHECK(same(nextafter_up_f(x), __builtin_nextafterf(x, 3.402823466e+38f)));
+        CHECK(same(nextafter_down_f(x), __builtin_nextafterf(x, -3.402823466e+38f)));
+    }
+}
+
 int main()
 {
+    check_nextafter();
     // Coordinates of order one and below only.  The float build's error bound is max(1, |x|)^3 * 3.6e-6
     // (root_finder.cu:103-119): at |x| ~ 40 it is 0.2, the set of domains whose image merely TOUCHES that fat
     // box around the origin has to be resolved down to float resolution, and a single query needs > 1e8 checks
