@@ -4,8 +4,31 @@
 // and narrow_phase.cu:24-74 of the reference.  Compiled with -ffp-contract=off: the only fused
 // multiply-adds are the explicit __builtin_fma calls of ARITH == 1 (DESIGN.md "Arithmetic
 // contract"); ARITH == 0 rounds every product and sum separately in source order.
+//
+// Host-compilable: tests/cpp/test_ti_host.cpp builds this header with g++ and checks ti_step / nq_step operation
+// for operation against the CPU oracle (the arithmetic is plain C++; only the gathers need HIP vector types).
 #pragma once
+#if defined(__HIPCC__)
 #include "common.hpp"
+#else
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#if !defined(TIF_HOST_DEFS)
+#define TIF_HOST_DEFS
+#define __device__
+#define __forceinline__ inline
+#endif
+static inline long long __double_as_longlong(double x)
+{
+    long long b;
+    std::memcpy(&b, &x, 8);
+    return b;
+}
+using std::fabs;
+using std::ldexp;
+using std::min;
+#endif
 
 #define TI_DBL_MAX 1.7976931348623157e308
 #define TI_DBL_EPS 2.220446049250313e-16
@@ -54,6 +77,7 @@ __device__ __forceinline__ void ti_prepare_inv_tol(TIQuery& q)
 __device__ __forceinline__ double ti_min(double a, double b) { return __builtin_fmin(a, b); }
 __device__ __forceinline__ double ti_max(double a, double b) { return __builtin_fmax(a, b); }
 
+#if defined(__HIPCC__)
 // add_data<is_vf> (narrow_phase.cu:24-74) on the packed mesh, in two steps so that the narrow-phase
 // kernel can software-pipeline them: the four vertex ids of a query ...
 template <bool VF>
@@ -89,6 +113,8 @@ __device__ __forceinline__ void ti_gather(const double* __restrict__ V, const in
 {
     ti_gather_ids(V, ti_indices<VF>(E, F, pr), v);
 }
+
+#endif // __HIPCC__
 
 __device__ __forceinline__ double ti_linf(const double a[3], const double b[3])
 {
@@ -383,3 +409,91 @@ __device__ __forceinline__ TIStep ti_step(const TIQuery& q, const double lo[3], 
     if (second) r.nk = 2;
     return r;
 }
+
+// ---- np_queue_k's domain entries and step (used by narrow_queue.inc) ---------------------------------------------
+// A DOMAIN ENTRY.  Every interval the bisection produces is [k 2^-d, (k + 1) 2^-d] (root [0, 1]: k = 0,
+// d = 0; halves of (k, d): (2k, d + 1) and (2k + 1, d + 1)), and all of those numbers -- like the
+// reference's mid = (lo + hi) / 2 (interval.cuh:21) -- are exact in double.  The kernel therefore keeps
+// a domain as three u32 numerators + three 8-bit levels (16 bytes: registers, LDS stack, HBM spill and
+// hand-over all hold the same thing), bisects in integers, and only the inclusion check sees doubles:
+// the same bits as carrying (lo, hi) pairs around, a quarter of the registers, no conversions on push / pop.
+// Levels stop at NQ_MAX_LEVEL (2^-31 is four orders of magnitude below any tolerance in use; deeper => NQ_OVF_INTERVAL
+// and the caller falls back to the level-synchronous kernels).
+struct NQDom {
+    unsigned k0, k1, k2, d; // d = d_t | d_u << 8 | d_v << 16
+};
+__device__ __forceinline__ void nq_bounds(unsigned k, unsigned d, double& lo, double& hi, double& w)
+{
+    const int e = -(int)d;
+    lo = ldexp((double)k, e);
+    hi = ldexp((double)(k + 1u), e);
+    w = ldexp(1.0, e);
+}
+
+// One ccd_kernel invocation (root_finder.cu:277-370) on a domain entry: ti_step of ti_math.hpp with the
+// interval arithmetic done in integers.  nk = 0, 1, 2 children: first half always, second half per
+// bisect() (root_finder.cu:213-254).  Condition 4 (:222-225, an empty half) cannot occur above 2^-53.
+struct NQStep {
+    bool accept, checked;
+    int nk, split;
+    double min_t;
+};
+template <bool VF, int ARITH>
+__device__ __forceinline__ NQStep nq_step(const TIQuery& q, const NQDom& dm, double ms, double co_domain_tol,
+                                          bool allow_zero_toi, double prune_toi)
+{
+    NQStep r;
+    r.accept = false;
+    r.checked = false;
+    r.nk = 0;
+    r.split = 0;
+    double lo[3], hi[3], w[3];
+    nq_bounds(dm.k0, dm.d & 255u, lo[0], hi[0], w[0]);
+    nq_bounds(dm.k1, (dm.d >> 8) & 255u, lo[1], hi[1], w[1]);
+    nq_bounds(dm.k2, (dm.d >> 16) & 255u, lo[2], hi[2], w[2]);
+    const double min_t = lo[0];
+    r.min_t = min_t;
+    if (min_t >= prune_toi) return r; // :295
+    double true_tol;
+    bool box_in;
+    r.checked = true;
+    if (!ti_inclusion<VF, ARITH, true>(q.v, lo, hi, q.err, ms, true_tol, box_in)) return r;
+    const bool zero_ok = allow_zero_toi || min_t > 0;
+    if ((w[0] <= q.tol[0] && w[1] <= q.tol[1] && w[2] <= q.tol[2]) // Condition 1 :322
+        || (box_in && zero_ok)                                     // Condition 2 :331
+        || (true_tol <= co_domain_tol && zero_ok)) {               // Condition 3 :340
+        r.accept = true;
+        return r;
+    }
+    // split_dimension :200-211 (widths are powers of two: ti_math.hpp on the reciprocal shortcut)
+    double r0, r1, r2;
+    if (q.inv_ok) {
+        r0 = w[0] * q.inv_tol[0];
+        r1 = w[1] * q.inv_tol[1];
+        r2 = w[2] * q.inv_tol[2];
+    } else {
+        r0 = w[0] / q.tol[0];
+        r1 = w[1] / q.tol[1];
+        r2 = w[2] / q.tol[2];
+    }
+    int split;
+    if (r0 >= r1 && r0 >= r2) split = 0;
+    else if (r1 >= r0 && r1 >= r2) split = 1;
+    else split = 2;
+    r.split = split;
+    r.nk = 1;
+    // mid = (lo + hi) / 2 = lo + w / 2, exact
+    const double slo = split == 0 ? lo[0] : (split == 1 ? lo[1] : lo[2]);
+    const double sw = split == 0 ? w[0] : (split == 1 ? w[1] : w[2]);
+    const double mid = slo + 0.5 * sw;
+    bool second;
+    if (split == 0) second = mid <= prune_toi; // :229-232
+    else if (VF) {
+        // sum_less_than_one (:21-29): u + v <= 1 / (1 - DBL_EPSILON)
+        const double other = (split == 1) ? lo[2] : lo[1];
+        second = (mid + other) <= 1 / (1 - TI_DBL_EPS);
+    } else second = true; // :248-250
+    if (second) r.nk = 2;
+    return r;
+}
+

@@ -1,0 +1,23 @@
+"""The arithmetic of the narrow-phase kernels (csrc/ti_math.hpp: ti_step of np_level_k; nq_step on integer domain
+entries, per-query displacements, reciprocal tolerances and per-coordinate constants of np_queue_k) is plain C++:
+compile it with the HOST compiler and compare it with the CPU oracle -- constants, single inclusion-function
+evaluations and whole queries walked depth-first, bit for bit, with identical check counts.  No GPU needed; the
+kernels AROUND this arithmetic (queues, stacks, gathers) are what the -m gpu tests cover."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_kernel_arithmetic_matches_the_oracle_on_the_host(orc, tmp_path):
+    orc.lib()  # builds oracle/libsccd_oracle.so if needed
+    exe = str(tmp_path / "test_ti_host")
+    subprocess.check_call([
+        "g++", "-std=c++17", "-O1", "-ffp-contract=off", "-mfma", "-Wall", "-Wextra", "-Wno-unknown-pragmas",
+        "-I" + os.path.join(ROOT, "scalable-ccd_amd", "csrc"), "-I" + os.path.join(ROOT, "oracle"),
+        os.path.join(ROOT, "tests", "cpp", "test_ti_host.cpp"), "-o", exe,
+        "-L" + os.path.join(ROOT, "oracle"), "-lsccd_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+    ])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert "0 failure(s)" in out.stdout
