@@ -128,8 +128,9 @@ struct StatsAcc {
 // (aabb.cu:19-37, aabb.cuh:55-63; ids aabb.cu:180-181)
 // f32: the reference's float build -- vertices and radius cast to float FIRST (aabb.cpp:43-47, aabb.cu:124-128),
 // nextafterf and float sums; the float results are stored widened (every later comparison is exact on them)
+template <bool F32>
 __global__ void vertex_boxes_k(const double* __restrict__ V, int nV, double r, sccd_aabb* __restrict__ out,
-                               GridStats* __restrict__ st, double* __restrict__ part, int f32)
+                               GridStats* __restrict__ st, double* __restrict__ part)
 {
     StatsAcc acc;
     const double ru = nextafter_up(r);
@@ -141,7 +142,7 @@ __global__ void vertex_boxes_k(const double* __restrict__ V, int nV, double r, s
         double lo[3], hi[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            if (f32) {
+            if (F32) {
                 const float q0 = (float)p0[k], q1 = (float)p1[k];
                 const float l0 = nextafter_down_f(q0) - ru_f, l1 = nextafter_down_f(q1) - ru_f;
                 const float h0 = nextafter_up_f(q0) + ru_f, h1 = nextafter_up_f(q1) + ru_f;
@@ -569,7 +570,8 @@ int launch_vertex_boxes(sccd_ctx* c, const double* dV, int nV, double inflation,
 {
     if (nV == 0) return 0;
     const int grid = std::min(grid_for(nV), SCCD_STATS_BLOCKS);
-    hipLaunchKernelGGL(vertex_boxes_k, dim3(grid), dim3(TPB), 0, c->stream, dV, nV, inflation, out, st, part, c->scalar_f32);
+    if (c->scalar_f32) hipLaunchKernelGGL(vertex_boxes_k<true>, dim3(grid), dim3(TPB), 0, c->stream, dV, nV, inflation, out, st, part);
+    else hipLaunchKernelGGL(vertex_boxes_k<false>, dim3(grid), dim3(TPB), 0, c->stream, dV, nV, inflation, out, st, part);
     SCCD_HIP(hipGetLastError());
     return grid;
 }
