@@ -187,6 +187,26 @@ def ccd(V0, V1, E, F, ms=0.0, max_iter=-1, tol=1e-6, allow_zero_toi=True, arith=
     return t.value, nvf.value, nee.value
 
 
+def ipc_ccd_strategy(V0, V1, E, F, ms=0.0, max_iter=-1, tol=1e-6, arith=ARITH_STRICT, want_branches=False):
+    """Restatement of scalable_ccd::cuda::ipc_ccd_strategy (ipc_ccd_strategy.cu:12-152), one chunk per pass
+    (the reference's `while (!broad_phase.is_complete())` runs once when the overlaps fit its buffer).
+    Returns earliest_toi (and, on request, which passes took the conservative re-run branch :72-91)."""
+    vb, eb, fb = build_boxes(V0, V1, E, F, ms)  # :123-125: inflation radius = min_distance
+    earliest = 1.0  # :136
+    reran = []
+    for run_vf in (True, False):  # :138-148
+        pairs = sort_and_sweep(vb, fb)[0] if run_vf else sort_and_sweep(eb)[0]
+        before = earliest  # :52
+        earliest = narrow_phase(V0, V1, E, F, pairs, run_vf, ms, max_iter, tol, True, arith, toi=earliest)[0]  # :61-69
+        if earliest < 1e-6:  # :72
+            earliest = before  # :76
+            # :79-87: max_iterations = -1, ms = 0, allow_zero_toi = false
+            earliest = narrow_phase(V0, V1, E, F, pairs, run_vf, 0.0, -1, tol, False, arith, toi=earliest)[0]
+            earliest *= 0.8  # :88
+            reran.append(run_vf)
+    return (earliest, reran) if want_branches else earliest
+
+
 def query_constants(v24, is_vf, use_ms, tol):
     L = lib()
     v = np.ascontiguousarray(v24, dtype=np.float64).reshape(24)

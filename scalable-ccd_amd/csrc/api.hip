@@ -1090,6 +1090,10 @@ static NarrowParams narrow_params(sccd_ctx* c, const sccd_mesh* m, const int2* d
         tol = (double)(float)tol;
         ms = (double)(float)ms;
     }
+    // Condition 1 (root_finder.cu:322) can only end a bisection for a positive finite tolerance; the reference
+    // asserts nothing and would bisect down to empty intervals (Condition 4) -- refused here instead
+    SCCD_REQUIRE(tol > 0 && std::isfinite(tol), "narrow_phase: tolerance must be positive and finite");
+    SCCD_REQUIRE(ms >= 0 && std::isfinite(ms), "narrow_phase: minimum separation must be >= 0 and finite");
     NarrowParams p;
     p.V = m->V.as<double>();
     p.E = m->E.as<int2>();

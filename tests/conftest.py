@@ -9,8 +9,44 @@ for p in (os.path.join(ROOT, "scalable-ccd_amd"), os.path.join(ROOT, "oracle"), 
         sys.path.insert(0, p)
 
 
+# ---- safety net ---------------------------------------------------------------------------------
+# A checker that takes the host's memory, or a kernel that never returns, costs a GPU box (round 1 lost
+# two that way).  (RLIMIT_AS is not usable: the HIP runtime reserves terabytes of address space.)
+#  * a watchdog thread ends the process (exit code 86) when its resident set passes SCCD_TEST_RSS_GB
+#    (default 24 GB; the largest legitimate test needs about 6);
+#  * every test has a wall-clock limit (pytest-timeout, thread method: it can end a process whose main
+#    thread is stuck inside a C call), SCCD_TEST_TIMEOUT seconds, default 900.
+def _start_rss_watchdog():
+    import threading
+    import time
+
+    limit = float(os.environ.get("SCCD_TEST_RSS_GB", "24")) * (1 << 30)
+
+    def rss():
+        with open("/proc/self/statm") as f:
+            return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
+
+    def watch():
+        while True:
+            try:
+                if rss() > limit:
+                    sys.stderr.write("\n[conftest] resident set above %.0f GB: aborting the test run\n" % (limit / (1 << 30)))
+                    sys.stderr.flush()
+                    os._exit(86)
+            except OSError:
+                pass
+            time.sleep(0.25)
+
+    threading.Thread(target=watch, name="rss-watchdog", daemon=True).start()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _start_rss_watchdog()
+    if config.pluginmanager.hasplugin("timeout"):
+        if not getattr(config.option, "timeout", None):
+            config.option.timeout = float(os.environ.get("SCCD_TEST_TIMEOUT", "900"))
+        config.option.timeout_method = "thread"
 
 
 @pytest.fixture(scope="session")

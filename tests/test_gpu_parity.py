@@ -591,6 +591,39 @@ def test_ipc_ccd_strategy(sccd, ctx, orc):
     F = np.array([[1, 2, 3]], np.int32)
     t = sccd.ipc_ccd_strategy(V0, V1, E, F, 0.0, -1, 1e-6, ctx=ctx)
     assert 0.0 <= t <= 1e-5
+    want, reran = orc.ipc_ccd_strategy(V0, V1, E, F, 0.0, -1, 1e-6, want_branches=True)
+    assert reran and t == want  # the oracle twin took the re-run branch too: same value, bit for bit
+
+
+@pytest.mark.parametrize("case", ["resting_mesh", "ms_contact", "late_hit"])
+def test_ipc_ccd_strategy_matches_the_oracle_twin(sccd, ctx, orc, case):
+    """ipc_ccd_strategy.cu:43-91 against orc.ipc_ccd_strategy, bit for bit, on scenes that take the conservative
+    re-run in the vertex-face pass, in the edge-edge pass, in both, or in neither."""
+    if case == "resting_mesh":  # a small cloth lying ON a static one, pushed through it: toi = 0 in both passes
+        V0a, Fa = scenes.cloth_grid(6)
+        Ea = scenes.edges_from_faces(Fa)
+        nA = len(V0a)  # second copy of the whole sheet, shifted in x/y by a fraction of a cell
+        V0 = np.vstack([V0a, V0a + np.array([0.013, 0.007, 0.0])])
+        V1 = V0.copy()
+        V1[nA:, 2] -= 0.05
+        E = np.vstack([Ea, Ea + nA]).astype(np.int32)
+        F = np.vstack([Fa, Fa + nA]).astype(np.int32)
+        ms, mi = 0.0, -1
+    elif case == "ms_contact":  # closer than the minimum separation at t = 0: re-run WITHOUT ms finds the real hit
+        V0 = np.array([[0.3, 0.3, 1e-4], [0, 0, 0], [1, 0, 0], [0, 1, 0]], float)
+        V1 = V0.copy()
+        V1[0, 2] = -0.5
+        E = np.array([[1, 2], [2, 3], [1, 3]], np.int32)
+        F = np.array([[1, 2, 3]], np.int32)
+        ms, mi = 1e-3, 10_000_000
+    else:
+        V0, V1, E, F = scenes.triangle_soup(300, seed=21)
+        ms, mi = 0.0, 10_000_000
+    want, reran = orc.ipc_ccd_strategy(V0, V1, E, F, ms, mi, 1e-6, want_branches=True)
+    got = sccd.ipc_ccd_strategy(V0, V1, E, F, ms, mi, 1e-6, ctx=ctx)
+    assert got == want, (case, got, want, reran)
+    if case != "late_hit":
+        assert reran, "the scene is meant to take the conservative re-run branch"
 
 
 def test_check_limit_that_no_query_reaches_runs_on_the_fast_kernel(sccd, ctx, orc):
