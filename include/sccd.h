@@ -65,6 +65,11 @@ const char* sccd_version(void);
 /* hipStream_t to launch on (e.g. torch's current stream); NULL = the context's own stream. */
 int sccd_set_stream(sccd_ctx* ctx, void* hip_stream);
 int sccd_synchronize(sccd_ctx* ctx);
+/* Self-test of the hand-written memory idioms of the narrow-phase kernel (no reference counterpart): n_waves
+ * wavefronts each gather n_active (0..64) 48-byte vertex records into LDS by LDS-direct loads with a deliberately
+ * late wait while other LDS traffic runs, and read a spill-stack entry back through the kernel's inline-assembly
+ * load.  *n_bad = number of LDS / memory words that differ from the expected layout (0 = pass). */
+int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* n_bad);
 
 /* options (sccd_set_option) */
 #define SCCD_OPT_ARITH 1            /* 0 strict (default): *, +/- rounded separately; 1: a*b+c fused (nvcc -fmad form) */
@@ -80,7 +85,11 @@ int sccd_synchronize(sccd_ctx* ctx);
 #define SCCD_OPT_SCALAR 11          /* 0 double (default, SCALABLE_CCD_USE_DOUBLE=ON); 1 float (=OFF, scalar.hpp:13-21): vertices are
                                        cast to float first, boxes / tolerances / inclusion function / TOI are float arithmetic
                                        (values travel widened in the same double-typed interfaces); narrow phase on the
-                                       level-synchronous kernels.  NOT YET RUN ON A GPU (arithmetic checked on the host).        */
+                                       level-synchronous kernels (bit-equal to the oracle's float twin on the GPU, tests/test_gpu_parity.py) */
+#define SCCD_OPT_MAX_ITER_FAST 12   /* check limits (max_iter >= 0): 0 (default) level-synchronous kernels -- the reference's
+                                       own order, in which alone its per-query check count (root_finder.cu:287-305) is
+                                       defined; 1: limits >= 4096 on the depth-first work-queue kernel, equal whenever no
+                                       query comes near the limit, otherwise conservative (TOI <= the reference's)          */
 int sccd_set_option(sccd_ctx* ctx, int option, int64_t value);
 int64_t sccd_get_option(const sccd_ctx* ctx, int option);
 

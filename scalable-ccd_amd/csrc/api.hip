@@ -230,6 +230,7 @@ int sccd_set_option(sccd_ctx* c, int opt, int64_t v)
     case SCCD_OPT_MAX_OVERLAP_CUTOFF: c->max_overlap_cutoff = v; break;
     case SCCD_OPT_MEMORY_LIMIT_MB: c->memory_limit_mb = v; break;
     case SCCD_OPT_SCALAR: c->scalar_f32 = v ? 1 : 0; break;
+    case SCCD_OPT_MAX_ITER_FAST: c->max_iter_fast = v ? 1 : 0; break;
     default: c->err = "unknown option"; return SCCD_E_INVALID;
     }
     return SCCD_OK;
@@ -250,6 +251,7 @@ int64_t sccd_get_option(const sccd_ctx* c, int opt)
     case SCCD_OPT_MAX_OVERLAP_CUTOFF: return c->max_overlap_cutoff;
     case SCCD_OPT_MEMORY_LIMIT_MB: return c->memory_limit_mb;
     case SCCD_OPT_SCALAR: return c->scalar_f32;
+    case SCCD_OPT_MAX_ITER_FAST: return c->max_iter_fast;
     default: return 0;
     }
 }
@@ -1394,6 +1396,51 @@ extern "C" int sccd_ipc_ccd_strategy(sccd_ctx* c, const double* V0, const double
     });
     sccd_mesh_destroy(m);
     return rc;
+}
+
+extern "C" int sccd_selftest_lds_gather(sccd_ctx* c, int n_waves, int n_active, int64_t* n_bad)
+{
+    if (!c || !n_bad) return SCCD_E_INVALID;
+    *n_bad = -1;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(n_waves >= 1 && n_waves <= 4096 && n_active >= 0 && n_active <= 64, "selftest: bad arguments");
+        const int nrec = 5000, per_wave = 2 * 3 * 64 * 2 + 64 * 2;
+        n_waves = (n_waves + 1) / 2 * 2; // whole blocks
+        std::vector<double> hV((size_t)nrec * 6);
+        for (size_t i = 0; i < hV.size(); i++) hV[i] = (double)i + 0.5;
+        std::vector<int> perm((size_t)n_waves * 64);
+        for (size_t i = 0; i < perm.size(); i++) perm[i] = (int)((i * 2654435761ull + 11) % nrec);
+        DevBuf dV, dP, dO;
+        dV.ensure(hV.size() * 8);
+        dP.ensure(perm.size() * 4);
+        dO.ensure((size_t)n_waves * per_wave * 8);
+        copy_in(c, dV.p, hV.data(), hV.size() * 8, 0);
+        copy_in(c, dP.p, perm.data(), perm.size() * 4, 0);
+        narrow_selftest_lds_gather(c, dV.as<double>(), dP.as<int>(), n_waves, n_active, dO.as<double>());
+        std::vector<double> o((size_t)n_waves * per_wave);
+        SCCD_HIP(hipMemcpy(o.data(), dO.p, o.size() * 8, hipMemcpyDeviceToHost));
+        int64_t bad = 0;
+        for (int w = 0; w < n_waves; w++) {
+            const double* ow = o.data() + (size_t)w * per_wave;
+            for (int p = 0; p < 3; p++)
+                for (int l = 0; l < 64; l++) {
+                    const double base = (double)perm[(size_t)w * 64 + l] * 6 + p * 2 + 0.5;
+                    const double w0 = l < n_active ? base : -1.0, w1 = l < n_active ? base + 1 : -1.0;
+                    bad += ow[2 * (p * 64 + l)] != w0;     // B1: the gathered pieces
+                    bad += ow[2 * (p * 64 + l) + 1] != w1;
+                    const int i = p * 64 + l;              // B0: what the plain LDS traffic left
+                    bad += ow[2 * 3 * 64 + 2 * i] != (i < 64 ? 8.0 : 0.0);
+                    bad += ow[2 * 3 * 64 + 2 * i + 1] != (double)i;
+                }
+            for (int l = 0; l < 64; l++) {
+                double acc = 0;
+                for (int r = 0; r < 8; r++) acc += (double)((l + 7 * r) % (3 * 64));
+                bad += ow[4 * 3 * 64 + 2 * l] != (double)(l + 1000 * w);
+                bad += ow[4 * 3 * 64 + 2 * l + 1] != acc;
+            }
+        }
+        *n_bad = bad;
+    });
 }
 
 extern "C" int sccd_sort_pairs_u32(sccd_ctx* c, uint32_t* d_keys, uint32_t* d_vals, int64_t n)

@@ -102,6 +102,7 @@ struct sccd_ctx {
     int64_t overlap_capacity = 0;
     int profile = 0;
     int scalar_f32 = 0; // SCCD_OPT_SCALAR: 1 = the reference's float build
+    int max_iter_fast = 0; // SCCD_OPT_MAX_ITER_FAST: 1 = check limits >= 4096 on the depth-first kernel (conservative)
     // narrow_counters_upload() already put {zeros, this TOI} into the narrow phase's counters (it rides ahead of
     // the sweep in ccd(), so that the narrow kernel can start right behind the sweep's read-back)
     bool np_uploaded = false;
@@ -123,7 +124,7 @@ struct sccd_ctx {
     DevBuf sort_tmp_keys, sort_tmp_vals, sort_hist, sort_status;
     DevBuf scalars;      // small device-side counters block
     PinnedBuf h_scalars; // pinned mirror for async read-back
-    DevBuf np_scratch0, np_scratch1, np_scratch2, np_scratch3;
+    DevBuf np_scratch0, np_scratch1, np_scratch2, np_scratch3, np_scratch4;
     DevBuf tmp0, tmp1, tmp2;
     void* pipeline = nullptr; // cached pipeline objects (api.hip)
     hipEvent_t rb_event = nullptr; // ReadBack: polled, not waited for

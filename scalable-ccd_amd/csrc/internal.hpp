@@ -149,7 +149,8 @@ struct NarrowCounters {
     unsigned long long n_checks; // inclusion-function evaluations (one atomicAdd per wave)
     unsigned int overflow;
     unsigned int pad2;
-    unsigned long long pad3[14];
+    unsigned long long toi_level; // level-synchronous kernels with a check limit: the TOI as of the start of the level
+    unsigned long long pad3[13];
     // occupancy diagnostics of np_queue_k (SCCD_NP_DIAG=1 prints them)
     unsigned long long wave_steps;   // check steps executed by waves
     unsigned long long lane_steps;   // live lanes summed over those steps
@@ -175,3 +176,4 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
                       double* d_per_query_toi);
 void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
                       double* d_per_query_toi);
+void narrow_selftest_lds_gather(sccd_ctx* c, const double* d_V, const int* d_perm, int n_waves, int n_active, double* d_out);

@@ -112,11 +112,37 @@ __global__ void np_level_init_k(const double* __restrict__ V, const int2* __rest
     dom[j] = r;
 }
 
+// What a thread of one level launch READS of the state the same launch WRITES (root_finder.cu:287-289, :295, :229:
+// the query's check counter and TOI, the global TOI).  In the reference those reads race with the other threads'
+// atomicAdd / atomicMin -- any interleaving is a legal outcome.  With a check limit (max_iter >= 0) the interleaving
+// decides which domains are dropped, so the kernels then follow the ONE serialisation that does not depend on thread
+// order: every thread of a launch reads before any thread of that launch writes.  np_level_snap_k copies that state
+// in front of each level; the oracle restates the same order.  Without a limit the live values are read (earlier
+// pruning, same result: Appendix A.20).
+struct LvlSnap {
+    unsigned long long toi_bits;
+    int nbr_checks;
+    int pad;
+};
+__global__ void np_level_snap_k(const LvlDomain* __restrict__ cur, long long n_cur, const LvlData* __restrict__ data,
+                                LvlSnap* __restrict__ snap, NarrowCounters* __restrict__ cnt)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) cnt->toi_level = cnt->toi_bits;
+    if (i >= n_cur) return;
+    const int q = cur[i].query_id; // (several domains of one query store the same values)
+    LvlSnap s;
+    s.toi_bits = data[q].toi_bits;
+    s.nbr_checks = data[q].nbr_checks;
+    s.pad = 0;
+    snap[q] = s;
+}
+
 template <bool VF, int ARITH, bool F32>
 __global__ void np_level_k(const LvlDomain* __restrict__ cur, long long n_cur, LvlDomain* __restrict__ nxt,
                            unsigned long long* __restrict__ n_nxt, LvlData* __restrict__ data, double ms,
                            double tol, int max_iter, bool allow_zero_toi, bool per_query,
-                           NarrowCounters* __restrict__ cnt)
+                           NarrowCounters* __restrict__ cnt, const LvlSnap* __restrict__ snap)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_cur) return;
@@ -132,9 +158,11 @@ __global__ void np_level_k(const LvlDomain* __restrict__ cur, long long n_cur, L
         q.err[k] = dp->err[k];
         q.tol[k] = dp->tol[k];
     }
-    const int before = dp->nbr_checks;  // data_in copy, root_finder.cu:288
-    atomicAdd(&dp->nbr_checks, 1);      // :289
-    const double prune = per_query ? toi_load(&dp->toi_bits) : toi_load(&cnt->toi_bits);
+    const int before = snap ? snap[dom.query_id].nbr_checks : dp->nbr_checks; // data_in copy, root_finder.cu:287-288
+    atomicAdd(&dp->nbr_checks, 1);                                            // :289
+    const double prune = snap
+        ? __longlong_as_double((long long)(per_query ? snap[dom.query_id].toi_bits : cnt->toi_level))
+        : (per_query ? toi_load(&dp->toi_bits) : toi_load(&cnt->toi_bits));
     if (dom.lo[0] >= prune) return;                       // :295
     if (max_iter >= 0 && before > max_iter) return;       // :303
     TIStep s;
@@ -210,6 +238,11 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
     // more are hopeless in level order, and failing early beats filling 288 GB first)
     const size_t budget = std::min<size_t>((size_t)8 << 30,
                                            std::max<size_t>((free_b + c->np_scratch1.cap + c->np_scratch2.cap) / 3, (size_t)64 << 20));
+    LvlSnap* snap = nullptr; // (a check limit: level-snapshot serialisation, see LvlSnap)
+    if (p.max_iter >= 0) {
+        c->np_scratch4.ensure(sizeof(LvlSnap) * (size_t)n);
+        snap = c->np_scratch4.as<LvlSnap>();
+    }
     long long slice = n;
     for (long long q0 = 0; q0 < n;) {
         const long long len = std::min(slice, n - q0);
@@ -236,10 +269,11 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
             nxt->ensure(sizeof(LvlDomain) * (size_t)(2 * n_cur));
             SCCD_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream));
             const dim3 grid((unsigned)((n_cur + TPB - 1) / TPB));
+            if (snap) hipLaunchKernelGGL(np_level_snap_k, grid, dim3(TPB), 0, c->stream, cur->as<LvlDomain>(), n_cur, data, snap, d_cnt);
 #define SCCD_LAUNCH_LEVEL(AR_, F32_)                                                                                   \
     hipLaunchKernelGGL((np_level_k<VF, AR_, F32_>), grid, dim3(TPB), 0, c->stream, cur->as<LvlDomain>(), n_cur,          \
                        nxt->as<LvlDomain>(), d_n, data, p.ms, p.tol, p.max_iter, (bool)p.allow_zero_toi,                 \
-                       d_per_query_toi != nullptr, d_cnt)
+                       d_per_query_toi != nullptr, d_cnt, snap)
             if (c->scalar_f32) {
                 if (p.arith == 1) SCCD_LAUNCH_LEVEL(1, true);
                 else SCCD_LAUNCH_LEVEL(0, true);
@@ -300,11 +334,14 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
     const long long n = p.n_pairs;
     if (run && n > 0) {
         ProfScope ps(c, p.is_vf ? SCCD_PROF_NARROW_VF : SCCD_PROF_NARROW_EE);
-        // A check limit is exact only in the reference's level order.  Limits that no query comes near
-        // (the IPC Toolkit passes 1e7) run on the work-queue kernel, which counts per query and hands the
-        // whole call to the level-synchronous kernel if any query does get there; small limits go there directly.
-        const bool level_sync = c->narrow_algo == 1 || (p.max_iter >= 0 && p.max_iter < SCCD_QUEUE_MIN_MAX_ITER)
-            || c->scalar_f32; // (the work-queue kernel is double only)
+        // A check limit (max_iter >= 0) is exact only in the reference's level order: it counts the domains of a
+        // query as the breadth-first launches pop them (root_finder.cu:287-305), several times what a depth-first
+        // walk with pruning checks.  Such calls therefore run on the level-synchronous kernels.  SCCD_OPT_MAX_ITER_FAST
+        // = 1 (opt-in) serves limits >= 4096 with the work-queue kernel instead: it counts depth-first checks per
+        // lane and falls back to level order if a count passes the limit -- equal to the reference whenever no
+        // query comes near the limit (the IPC Toolkit passes 1e7), otherwise conservative (TOI <= the reference's).
+        const bool level_sync = c->narrow_algo == 1 || c->scalar_f32 // (the work-queue kernel is double only)
+            || (p.max_iter >= 0 && (p.max_iter < SCCD_QUEUE_MIN_MAX_ITER || !c->max_iter_fast));
         if (level_sync) {
             if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi);
             else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi);

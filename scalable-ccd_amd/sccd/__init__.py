@@ -21,7 +21,8 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libsccd_hip.so")
+# (SCCD_LIB: another build of the same library -- kernel variants under measurement, tools/variants.sh)
+_LIB_PATH = os.environ.get("SCCD_LIB") or os.path.join(_HERE, "libsccd_hip.so")
 _lib = None
 
 AABB_DTYPE = np.dtype(
@@ -36,6 +37,7 @@ OPT_ARITH, OPT_NARROW_ALGO, OPT_SWEEP_ALGO, OPT_SORT_AXIS = 1, 2, 3, 4
 OPT_SHARD_RANK, OPT_SHARD_COUNT, OPT_OVERLAP_CAPACITY, OPT_PROFILE, OPT_MAX_OVERLAP_CUTOFF = 5, 6, 7, 8, 9
 OPT_MEMORY_LIMIT_MB = 10
 OPT_SCALAR = 11  # 1: the reference's float build (SCALABLE_CCD_USE_DOUBLE=OFF)
+OPT_MAX_ITER_FAST = 12  # 1: check limits >= 4096 on the depth-first kernel (conservative); default: level order (exact)
 PROF_NAMES = ["boxes", "sort", "ranges", "sweep", "narrow_vf", "narrow_ee"]
 
 # every symbol include/sccd.h declares (tests check that the library exports all of them)
@@ -48,7 +50,7 @@ ABI_SYMBOLS = [
     "sccd_broad_phase_detect_overlaps_partial", "sccd_broad_phase_detect_overlaps", "sccd_broad_phase_is_complete",
     "sccd_broad_phase_num_boxes", "sccd_broad_phase_candidates", "sccd_free", "sccd_narrow_phase", "sccd_ccd",
     "sccd_ccd_mesh", "sccd_ccd_mesh_prepare", "sccd_ccd_mesh_pass", "sccd_ipc_ccd_strategy", "sccd_get_profile", "sccd_reset_profile", "sccd_sort_pairs_u32",
-    "sccd_shard_bounds", "sccd_boxes_variance_axis",
+    "sccd_shard_bounds", "sccd_boxes_variance_axis", "sccd_selftest_lds_gather",
 ]
 
 
@@ -162,6 +164,12 @@ class Context:
 
     def reset_profile(self):
         self._check(lib().sccd_reset_profile(self._h))
+
+    def selftest_lds_gather(self, n_waves=64, n_active=64):
+        """number of words that differ from the expected layout (0 = pass); sccd.h sccd_selftest_lds_gather"""
+        bad = C.c_int64(-1)
+        self._check(lib().sccd_selftest_lds_gather(self._h, C.c_int(n_waves), C.c_int(n_active), C.byref(bad)))
+        return bad.value
 
     def sort_pairs_u32(self, d_keys, d_vals, n):
         """in-place radix sort of device arrays (raw device pointers)"""

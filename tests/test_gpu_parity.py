@@ -627,24 +627,61 @@ def test_ipc_ccd_strategy_matches_the_oracle_twin(sccd, ctx, orc, case):
 
 
 def test_check_limit_that_no_query_reaches_runs_on_the_fast_kernel(sccd, ctx, orc):
-    """max_iter >= 0 (the IPC Toolkit passes 1e7): a limit no query comes near changes nothing, and
-    is served by the work-queue kernel (same check count as max_iter = -1, far fewer than the
-    level-order scheme needs); a small limit follows the reference's level order (oracle)."""
+    """SCCD_OPT_MAX_ITER_FAST = 1 (opt-in): a limit no query comes near (the IPC Toolkit passes 1e7) changes
+    nothing and is served by the work-queue kernel (same check count as max_iter = -1, far fewer than the
+    level-order scheme needs).  Default: every limit follows the reference's level order (oracle)."""
     V0, V1, E, F = _scene("cloth_ball_10k")
     mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
     t_free, st_free = sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True, want_stats=True)
-    for limit in (4096, 10_000_000):
-        t, st = sccd.ccd_mesh(mesh, 0.0, limit, 1e-6, True, want_stats=True)
-        assert t == t_free
-        # depth-first with pruning: the count depends a little on timing, never by a factor
-        assert st["n_vf_checks"] + st["n_ee_checks"] < 1.5 * (st_free["n_vf_checks"] + st_free["n_ee_checks"])
-    t_ipc = sccd.ipc_ccd_strategy(V0, V1, E, F, 0.0, 10_000_000, 1e-6, ctx=ctx)
-    assert t_ipc == sccd.ipc_ccd_strategy(V0, V1, E, F, 0.0, -1, 1e-6, ctx=ctx)
-    # a limit below SCCD_QUEUE_MIN_MAX_ITER: level-synchronous kernel, one legal order of the reference's scheme
+    try:
+        ctx.set_option(sccd.OPT_MAX_ITER_FAST, 1)
+        for limit in (4096, 10_000_000):
+            t, st = sccd.ccd_mesh(mesh, 0.0, limit, 1e-6, True, want_stats=True)
+            assert t == t_free
+            # depth-first with pruning: the count depends a little on timing, never by a factor
+            assert st["n_vf_checks"] + st["n_ee_checks"] < 1.5 * (st_free["n_vf_checks"] + st_free["n_ee_checks"])
+        t_ipc = sccd.ipc_ccd_strategy(V0, V1, E, F, 0.0, 10_000_000, 1e-6, ctx=ctx)
+        assert t_ipc == sccd.ipc_ccd_strategy(V0, V1, E, F, 0.0, -1, 1e-6, ctx=ctx)
+    finally:
+        ctx.set_option(sccd.OPT_MAX_ITER_FAST, 0)
+    # default: level-synchronous kernels, the reference's own order
+    t, st = sccd.ccd_mesh(mesh, 0.0, 10_000_000, 1e-6, True, want_stats=True)
+    assert t == t_free and st["n_vf_checks"] + st["n_ee_checks"] > st_free["n_vf_checks"] + st_free["n_ee_checks"]
     want, _, _ = orc.ccd(V0, V1, E, F, 0.0, 3, 1e-6, True)
     got = sccd.ccd_mesh(mesh, 0.0, 3, 1e-6, True)
     assert got >= t_free  # truncation can only lose collisions
     assert got == want
+
+
+@pytest.mark.parametrize("arith", [0, 1])
+def test_check_limits_follow_the_reference_level_order(sccd, ctx, orc, arith):
+    """max_iter >= 0 (root_finder.cu:287-305): the reference counts the domains of a query as its breadth-first
+    launches pop them and drops the query's domains once the count has passed the limit.  On this contact-rich soup a
+    vertex-face query is popped 11,701 times in level order but needs only 3,384 depth-first checks: limits of 50,
+    500 and 5,000 all truncate queries in the reference, and only the level order reproduces WHICH domains are lost.
+    Bit-equal to the oracle (level-snapshot serialisation on both sides) for the TOI and for every per-query TOI."""
+    V0, V1, E, F = _scene("soup_dense")
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F, 0.0)
+    pv = orc.sort_and_sweep(vb, fb)[0]
+    stats = orc.narrow_phase(V0, V1, E, F, pv, True, arith=arith)[2]
+    assert stats["max_checks_per_query"] > 5000  # the limits below do bite
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    try:
+        ctx.set_option(sccd.OPT_ARITH, arith)
+        seen = set()
+        for k in (50, 500, 5000):
+            want = orc.ccd(V0, V1, E, F, 0.0, k, 1e-6, True, arith=arith)[0]
+            assert sccd.ccd_mesh(mesh, 0.0, k, 1e-6, True) == want, k
+            seen.add(want)
+            want_t, want_pq, _ = orc.narrow_phase(V0, V1, E, F, pv, True, 0.0, k, 1e-6, True, arith=arith, per_query=True)
+            got_t, col = sccd.narrow_phase(mesh, pv, True, k, 1e-6, 0.0, True, want_collisions=True)
+            assert got_t == want_t, k
+            hit = want_pq < 1
+            assert len(col) == int(hit.sum()), k
+            assert np.array_equal(col["toi"], want_pq[hit]), k
+        assert len(seen) >= 2  # different limits, different answers: the test can tell them apart
+    finally:
+        ctx.set_option(sccd.OPT_ARITH, 0)
 
 
 def test_sort_is_a_stable_permutation(sccd, ctx):
@@ -841,3 +878,12 @@ def test_float_build_matches_the_oracle_twin(sccd, ctx, orc, arith):
         finally:
             ctx.set_option(sccd.OPT_SCALAR, 0)
             ctx.set_option(sccd.OPT_ARITH, 0)
+
+
+@pytest.mark.parametrize("n_active", [64, 24, 1, 0])
+def test_lds_direct_gather_idiom(sccd, ctx, n_active):
+    """The narrow-phase kernel issues its LDS-direct gathers and its spill-stack loads as inline assembly that the
+    compiler's wait-count bookkeeping does not see (narrow_queue.inc: nq_glds16, hbm_read).  This pins the idiom
+    against a compiler update: landed layout (piece p of lane l at base + (p * 64 + l) * 16), inactive lanes
+    untouched, a late hand-placed wait behind other LDS traffic, per-wave M0 bases with two waves per block."""
+    assert ctx.selftest_lds_gather(n_waves=512, n_active=n_active) == 0
