@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <string>
 
 namespace {
 
@@ -305,6 +306,7 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
 } // namespace
 
 #include "narrow_queue.inc"
+#include "narrow_walk.inc"
 
 // counters = {zeros, toi}: from the pinned mirror [12 KB, 16 KB)
 void narrow_counters_upload(sccd_ctx* c, NarrowCounters* d_cnt, double toi)
@@ -351,7 +353,10 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
                                    reinterpret_cast<unsigned long long*>(d_per_query_toi), n, 0x7FF0000000000000ull);
                 SCCD_HIP(hipGetLastError());
             }
-            run_queue(c, p, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi));
+            // (SCCD_NP_KERNEL=queue: the explicit-stack kernel, kept for comparison)
+            static const bool old_kernel = std::getenv("SCCD_NP_KERNEL") && std::string(std::getenv("SCCD_NP_KERNEL")) == "queue";
+            if (old_kernel) run_queue(c, p, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi));
+            else run_walk(c, p, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi));
         }
     }
 }

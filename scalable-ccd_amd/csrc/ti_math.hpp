@@ -497,3 +497,275 @@ __device__ __forceinline__ NQStep nq_step(const TIQuery& q, const NQDom& dm, dou
     return r;
 }
 
+
+// ---- stackless depth-first walk (np_queue_k) ---------------------------------------------------------------------
+// WHICH dimension a domain is split in (split_dimension, root_finder.cu:200-211) depends on its three widths and
+// the query's tolerances only -- not on the inclusion check.  By induction the level triple (d_t, d_u, d_v) of a
+// node depends on its DEPTH n = d_t + d_u + d_v alone: the bisection tree of a query is a complete binary tree in
+// which every node of depth n is split in the same dimension s_n.  A depth-first walk of such a tree needs no
+// stack of deferred halves:
+//   S0, S1   bit n set <=> s_n = 0 / 1 (neither: 2).  Written on the way down (idempotent), valid for every path.
+//   pend     bit n set <=> on the CURRENT root-to-node path the split at depth n was left towards the first half
+//            and its second half is still to be visited.
+// Going from the current node (depth n) to the deepest pending second half (split depth j = top bit of pend):
+// undo the splits of depths j+1 .. n-1 -- their number per dimension is a population count of S0 / S1 over those
+// bits, and undoing c splits of a dimension is `numerator >>= c` -- then set the low bit of the numerator of
+// dimension s_j.  Handing work to another lane gives away the SHALLOWEST pending half (low bit of pend: the largest
+// subtree), computed the same way without moving.  Levels stop at 31 per dimension (NQ_MAX_LEVEL): depth <= 93 < 96.
+// The second half of a split is registered when the reference would push it (bisect(), root_finder.cu:229-250).
+struct NQBits { // 96 bits
+    unsigned long long lo;
+    unsigned hi;
+};
+__device__ __forceinline__ bool nqb_any(const NQBits& b) { return (b.lo | b.hi) != 0; }
+__device__ __forceinline__ void nqb_set(NQBits& b, unsigned n)
+{
+    b.lo |= n < 64u ? 1ull << (n & 63u) : 0ull;
+    b.hi |= n < 64u ? 0u : 1u << (n & 31u);
+}
+__device__ __forceinline__ void nqb_clear(NQBits& b, unsigned n)
+{
+    b.lo &= ~(n < 64u ? 1ull << (n & 63u) : 0ull);
+    b.hi &= ~(n < 64u ? 0u : 1u << (n & 31u));
+}
+__device__ __forceinline__ bool nqb_test(const NQBits& b, unsigned n)
+{
+    return n < 64u ? ((b.lo >> (n & 63u)) & 1ull) != 0 : ((b.hi >> (n & 31u)) & 1u) != 0;
+}
+__device__ __forceinline__ unsigned nqb_top(const NQBits& b) // highest set bit (b != 0)
+{
+    return b.hi ? 95u - (unsigned)__builtin_clz(b.hi) : 63u - (unsigned)__builtin_clzll(b.lo | 1ull);
+}
+__device__ __forceinline__ unsigned nqb_low(const NQBits& b) // lowest set bit (b != 0)
+{
+    return b.lo ? (unsigned)__builtin_ctzll(b.lo) : 64u + (unsigned)__builtin_ctz(b.hi | 0x80000000u);
+}
+// number of set bits of b at positions j+1 .. n-1
+__device__ __forceinline__ unsigned nqb_count_between(const NQBits& b, unsigned j, unsigned n)
+{
+    // below(x) = bits [0, x)
+    const unsigned a = j + 1u;
+    const unsigned long long lo_n = n >= 64u ? ~0ull : (1ull << (n & 63u)) - 1ull;
+    const unsigned long long lo_a = a >= 64u ? ~0ull : (1ull << (a & 63u)) - 1ull;
+    const unsigned hn = n <= 64u ? 0u : n - 64u, ha = a <= 64u ? 0u : a - 64u; // < 32 each (depth <= 95)
+    const unsigned hi_n = (1u << (hn & 31u)) - 1u, hi_a = (1u << (ha & 31u)) - 1u;
+    return (unsigned)__builtin_popcountll(b.lo & lo_n & ~lo_a) + (unsigned)__builtin_popcount(b.hi & hi_n & ~hi_a);
+}
+struct NQWalk {
+    NQBits pend, s0, s1;
+};
+__device__ __forceinline__ unsigned nq_depth(const NQDom& d) { return (d.d & 255u) + ((d.d >> 8) & 255u) + ((d.d >> 16) & 255u); }
+// the second half of the split at depth j of the path that ends in `cur` (depth n > j)
+__device__ __forceinline__ NQDom nq_second_half_at(const NQWalk& w, const NQDom& cur, unsigned j)
+{
+    const unsigned n = nq_depth(cur);
+    const unsigned c0 = nqb_count_between(w.s0, j, n), c1 = nqb_count_between(w.s1, j, n);
+    const unsigned c2 = (n - 1u - j) - c0 - c1;
+    NQDom r;
+    r.k0 = cur.k0 >> c0;
+    r.k1 = cur.k1 >> c1;
+    r.k2 = cur.k2 >> c2;
+    r.d = cur.d - (c0 | (c1 << 8) | (c2 << 16));
+    // now the FIRST half of the split at depth j (its numerator in dimension s_j is even): step to the sibling
+    const bool is0 = nqb_test(w.s0, j), is1 = nqb_test(w.s1, j);
+    r.k0 |= is0 ? 1u : 0u;
+    r.k1 |= (!is0 && is1) ? 1u : 0u;
+    r.k2 |= (!is0 && !is1) ? 1u : 0u;
+    return r;
+}
+// descend: the node `cur` (depth n) was split in dimension `split`; `second` = its later half is to be visited too
+__device__ __forceinline__ NQDom nq_descend(NQWalk& w, const NQDom& cur, int split, bool second)
+{
+    const unsigned n = nq_depth(cur);
+    if (split == 0) nqb_set(w.s0, n);
+    if (split == 1) nqb_set(w.s1, n);
+    if (second) nqb_set(w.pend, n);
+    NQDom r;
+    r.k0 = split == 0 ? 2u * cur.k0 : cur.k0;
+    r.k1 = split == 1 ? 2u * cur.k1 : cur.k1;
+    r.k2 = split == 2 ? 2u * cur.k2 : cur.k2;
+    r.d = cur.d + (1u << (8 * split));
+    return r;
+}
+// backtrack to the deepest pending second half (w.pend != 0)
+__device__ __forceinline__ NQDom nq_backtrack(NQWalk& w, const NQDom& cur)
+{
+    const unsigned j = nqb_top(w.pend);
+    nqb_clear(w.pend, j);
+    return nq_second_half_at(w, cur, j);
+}
+// give away the shallowest pending second half (w.pend != 0)
+__device__ __forceinline__ NQDom nq_donate(NQWalk& w, const NQDom& cur)
+{
+    const unsigned j = nqb_low(w.pend);
+    nqb_clear(w.pend, j);
+    return nq_second_half_at(w, cur, j);
+}
+
+// origin_in_inclusion_function for np_walk_k: the same bounding box of the eight corner images as ti_inclusion, from
+// FEWER operations.  Rounding is monotone -- fl(x - y) never decreases when x grows or y shrinks, and the same holds
+// for one fused fl(x - d * w) -- so the extreme values over the corners are the images of the extreme operands:
+//   edge-edge      c_ij = fl(x_i - y_j)                  min c = fl(min x - max y),    max c = fl(max x - min y)
+//   vertex-face    c_ij = fl(fl(r1_i - p_j) - a1)        min c = fl(fl(min r1 - max p) - a1), ...   (p_j = fl(d2 w_j))
+//   (fused form    r2_ij = fl(r1_i - d2 w_j): both w are tried for the extreme r1, 4 fma + 2 min/max)
+// Identical cmin / cmax up to the sign of a zero (which no later comparison or subtraction can see), 8 instead of
+// 12-14 operations per (coordinate, time).  v[4..7] hold displacements.  (tests/cpp/test_ti_host.cpp walks whole
+// queries with it against the oracle, bit for bit with equal check counts.)
+template <bool VF, int ARITH>
+__device__ __forceinline__ bool ti_inclusion_mm(const double v[8][3], const double lo[3], const double hi[3],
+                                                const double err[3], double ms, double& true_tol, bool& box_in)
+{
+    double cmin[3], cmax[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double mn = TI_DBL_MAX, mx = -TI_DBL_MAX;
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const double t = it ? hi[0] : lo[0];
+            double a0, a1, a2, a3; // the four vertices at time t
+            if (ARITH == 1) {
+                a0 = __builtin_fma(v[4][k], t, v[0][k]);
+                a1 = __builtin_fma(v[5][k], t, v[1][k]);
+                a2 = __builtin_fma(v[6][k], t, v[2][k]);
+                a3 = __builtin_fma(v[7][k], t, v[3][k]);
+            } else {
+                a0 = v[4][k] * t + v[0][k];
+                a1 = v[5][k] * t + v[1][k];
+                a2 = v[6][k] * t + v[2][k];
+                a3 = v[7][k] * t + v[3][k];
+            }
+            double c_lo, c_hi;
+            if (VF) { // v - (t1 - t0)*u - (t2 - t0)*v - t0   with v=a0, t0=a1, t1=a2, t2=a3
+                const double d1 = a2 - a1, d2 = a3 - a1;
+                double r1a, r1b;
+                if (ARITH == 1) {
+                    r1a = __builtin_fma(-d1, lo[1], a0);
+                    r1b = __builtin_fma(-d1, hi[1], a0);
+                } else {
+                    r1a = a0 - d1 * lo[1];
+                    r1b = a0 - d1 * hi[1];
+                }
+                const double r1min = ti_min(r1a, r1b), r1max = ti_max(r1a, r1b);
+                double r2min, r2max;
+                if (ARITH == 1) {
+                    r2min = ti_min(__builtin_fma(-d2, lo[2], r1min), __builtin_fma(-d2, hi[2], r1min));
+                    r2max = ti_max(__builtin_fma(-d2, lo[2], r1max), __builtin_fma(-d2, hi[2], r1max));
+                } else {
+                    const double pa = d2 * lo[2], pb = d2 * hi[2];
+                    r2min = r1min - ti_max(pa, pb);
+                    r2max = r1max - ti_min(pa, pb);
+                }
+                c_lo = r2min - a1;
+                c_hi = r2max - a1;
+            } else { // ((ea1 - ea0)*u + ea0) - ((eb1 - eb0)*v + eb0)
+                const double da = a1 - a0, db = a3 - a2;
+                double xa, xb, ya, yb;
+                if (ARITH == 1) {
+                    xa = __builtin_fma(da, lo[1], a0);
+                    xb = __builtin_fma(da, hi[1], a0);
+                    ya = __builtin_fma(db, lo[2], a2);
+                    yb = __builtin_fma(db, hi[2], a2);
+                } else {
+                    xa = da * lo[1] + a0;
+                    xb = da * hi[1] + a0;
+                    ya = db * lo[2] + a2;
+                    yb = db * hi[2] + a2;
+                }
+                c_lo = ti_min(xa, xb) - ti_max(ya, yb);
+                c_hi = ti_max(xa, xb) - ti_min(ya, yb);
+            }
+            mn = ti_min(mn, c_lo);
+            mx = ti_max(mx, c_hi);
+        }
+        cmin[k] = mn;
+        cmax[k] = mx;
+    }
+    double wdt = cmax[0] - cmin[0];
+    wdt = ti_max(wdt, cmax[1] - cmin[1]);
+    wdt = ti_max(wdt, cmax[2] - cmin[2]);
+    true_tol = ti_max(0.0, wdt); // :183
+    box_in = true;
+    bool out = false, notin = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        out = out || (cmin[k] - ms > err[k]) || (cmax[k] + ms < -err[k]);   // :187-190
+        notin = notin || (cmin[k] + ms < -err[k]) || (cmax[k] - ms > err[k]); // :192-195
+    }
+    if (out) return false;
+    box_in = !notin;
+    return true;
+}
+
+// ---- np_walk_k's query and step ---------------------------------------------------------------------------------
+// Condition 1 (root_finder.cu:322) compares the three widths with the three tolerances.  A width is 2^-d, so
+// 2^-d <= tol  <=>  d >= D with D = max(0, -floor(log2 tol)) (the largest power of two <= tol is 2^floor(log2 tol));
+// tol = +inf (a static query) gives D = 0, a NaN tolerance D = 255 (never).  The walk kernel therefore keeps three
+// 8-bit levels instead of three doubles; bit 24 marks tolerances whose reciprocal shortcut (ti_inv_tol_ok) is not
+// exact -- astronomically large or small displacements -- which the kernel hands to the level-synchronous path.
+struct NWQuery {
+    double v[8][3]; // v[0..3] start positions, v[4..7] displacements
+    double err[3];
+    double inv_tol[3];
+    unsigned dlev; // D_t | D_u << 8 | D_v << 16 | (inexact reciprocal) << 24
+};
+__device__ __forceinline__ unsigned nw_tol_levels(const double tol[3], bool inv_ok)
+{
+    unsigned r = inv_ok ? 0u : 1u << 24;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int be = (int)(((unsigned long long)__double_as_longlong(tol[k]) >> 52) & 0x7FFull); // (tolerances are >= 0)
+        int D = 1023 - be; // -floor(log2 tol) for a normal number; subnormal or zero: 1023 (never reached)
+        D = D < 0 ? 0 : (D > 255 ? 255 : D);
+        if (tol[k] != tol[k]) D = 255;
+        r |= (unsigned)D << (8 * k);
+    }
+    return r;
+}
+template <bool VF, int ARITH>
+__device__ __forceinline__ NQStep nw_step(const NWQuery& q, const NQDom& dm, double ms, double co_domain_tol,
+                                          bool allow_zero_toi, double prune_toi)
+{
+    NQStep r;
+    r.accept = false;
+    r.checked = false;
+    r.nk = 0;
+    r.split = 0;
+    double lo[3], hi[3], w[3];
+    const unsigned d0 = dm.d & 255u, d1 = (dm.d >> 8) & 255u, d2 = (dm.d >> 16) & 255u;
+    nq_bounds(dm.k0, d0, lo[0], hi[0], w[0]);
+    nq_bounds(dm.k1, d1, lo[1], hi[1], w[1]);
+    nq_bounds(dm.k2, d2, lo[2], hi[2], w[2]);
+    const double min_t = lo[0];
+    r.min_t = min_t;
+    if (min_t >= prune_toi) return r; // :295
+    double true_tol;
+    bool box_in;
+    r.checked = true;
+    if (!ti_inclusion_mm<VF, ARITH>(q.v, lo, hi, q.err, ms, true_tol, box_in)) return r;
+    const bool zero_ok = allow_zero_toi || min_t > 0;
+    const bool c1 = d0 >= (q.dlev & 255u) && d1 >= ((q.dlev >> 8) & 255u) && d2 >= ((q.dlev >> 16) & 255u); // Condition 1 :322
+    if (c1 || (box_in && zero_ok)                        // Condition 2 :331
+        || (true_tol <= co_domain_tol && zero_ok)) {     // Condition 3 :340
+        r.accept = true;
+        return r;
+    }
+    // split_dimension :200-211 by the reciprocal shortcut (exact: see ti_inv_tol_ok; inexact ones never get here)
+    const double r0 = w[0] * q.inv_tol[0], r1 = w[1] * q.inv_tol[1], r2 = w[2] * q.inv_tol[2];
+    int split;
+    if (r0 >= r1 && r0 >= r2) split = 0;
+    else if (r1 >= r0 && r1 >= r2) split = 1;
+    else split = 2;
+    r.split = split;
+    r.nk = 1;
+    const double slo = split == 0 ? lo[0] : (split == 1 ? lo[1] : lo[2]);
+    const double sw = split == 0 ? w[0] : (split == 1 ? w[1] : w[2]);
+    const double mid = slo + 0.5 * sw; // = (lo + hi) / 2, exact
+    bool second;
+    if (split == 0) second = mid <= prune_toi; // :229-232
+    else if (VF) {
+        const double other = (split == 1) ? lo[2] : lo[1];
+        second = (mid + other) <= 1 / (1 - TI_DBL_EPS); // sum_less_than_one :21-29
+    } else second = true; // :248-250
+    if (second) r.nk = 2;
+    return r;
+}

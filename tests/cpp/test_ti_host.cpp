@@ -81,6 +81,50 @@ template <bool VF, int ARITH> static double walk_nq(const TIQuery& qd, double ms
     return toi;
 }
 
+// work-queue kernel as it walks now: no stack -- pending halves are bits of the path (NQWalk); `donate_every` > 0 also
+// gives the shallowest pending half away every so many checks and walks it afterwards as a sub-query of its own
+// (what work sharing between lanes does)
+template <bool VF, int ARITH>
+static double walk_stackless(const TIQuery& qd, double ms, double tol, bool allow_zero, long* checks, int donate_every)
+{
+    NWQuery nq; // the walk kernel's query: tolerance LEVELS instead of tolerances
+    std::memcpy(nq.v, qd.v, sizeof nq.v);
+    for (int k = 0; k < 3; k++) {
+        nq.err[k] = qd.err[k];
+        nq.inv_tol[k] = qd.inv_tol[k];
+    }
+    nq.dlev = nw_tol_levels(qd.tol, qd.inv_ok);
+    if (nq.dlev >> 24) return -3.0; // inexact reciprocals: level-synchronous path
+    std::vector<NQDom> roots;
+    roots.push_back(NQDom { 0u, 0u, 0u, 0u });
+    double toi = 1;
+    long since = 0;
+    while (!roots.empty()) {
+        NQDom d = roots.back();
+        roots.pop_back();
+        NQWalk w = { { 0, 0 }, { 0, 0 }, { 0, 0 } };
+        bool live = true;
+        while (live) {
+            const NQStep s = nw_step<VF, ARITH>(nq, d, ms, tol, allow_zero, toi);
+            if (s.checked && ++*checks > 1000000) return -1.0;
+            if (s.accept && s.min_t < toi) toi = s.min_t;
+            if (s.nk >= 1) {
+                if ((((d.d + (1u << (8 * s.split))) >> (8 * s.split)) & 255u) > 31u) return -2.0;
+                d = nq_descend(w, d, s.split, s.nk == 2);
+            } else if (nqb_any(w.pend)) {
+                d = nq_backtrack(w, d);
+            } else {
+                live = false;
+            }
+            if (live && donate_every > 0 && ++since >= donate_every && nqb_any(w.pend)) {
+                since = 0;
+                roots.push_back(nq_donate(w, d));
+            }
+        }
+    }
+    return toi;
+}
+
 template <bool VF, int ARITH>
 static void run_case(int n_queries, double scale, double ms, bool allow_zero, long* hits, long* skipped, long* handed_over)
 {
@@ -138,7 +182,7 @@ static void run_case(int n_queries, double scale, double ms, bool allow_zero, lo
         TIQuery qd = q; // the queue kernel's query: displacements instead of end positions
         for (int j = 0; j < 4; j++)
             for (int k = 0; k < 3; k++) qd.v[j + 4][k] = q.v[j + 4][k] - q.v[j][k];
-        for (int r = 0; r < 4; r++) { // single evaluations on random dyadic sub-domains
+        for (int r = 0; r < 24; r++) { // single evaluations on random dyadic sub-domains
             double lo[3], hi[3], dom[6];
             for (int k = 0; k < 3; k++) {
                 const int d = (int)(rnd() * 8);
@@ -159,6 +203,12 @@ static void run_case(int n_queries, double scale, double ms, bool allow_zero, lo
                 CHECK(same(tt, ott) && same(td, ott));
                 CHECK(bi == (obi != 0) && bd == bi);
             }
+            // the walk kernel's evaluation from the extreme operands (monotone rounding): same verdict, same width
+            double tm = 0;
+            bool bm = false;
+            const bool am = ti_inclusion_mm<VF, ARITH>(qd.v, lo, hi, q.err, ms, tm, bm);
+            CHECK(am == a);
+            if (am && a) CHECK(same(tm, ott) && bm == bi);
         }
         const int32_t E[4] = { 0, 2, 1, 3 }; // column-major 2 x 2: edges (0,1) and (2,3)
         const int32_t F[3] = { 1, 2, 3 };
@@ -183,6 +233,13 @@ static void run_case(int n_queries, double scale, double ms, bool allow_zero, lo
         CHECK(same(got2, want) && c2 == c1);
         if (got3 == -2.0) ++*handed_over; // deeper than 2^-31: np_queue_k hands the call to the level-synchronous kernel
         else CHECK(same(got3, want) && c3 == c1); // same traversal, same number of checks
+        // the stackless walk visits the same domains in the same order as the explicit stack ...
+        long c4 = 0, c5 = 0;
+        const double got4 = walk_stackless<VF, ARITH>(qd, ms, tol, allow_zero, &c4, 0);
+        if (got4 != -3.0) CHECK(same(got4, got3) && c4 == c3);
+        // ... and with sub-trees given away every few checks (work sharing) still finds the same time of impact
+        const double got5 = walk_stackless<VF, ARITH>(qd, ms, tol, allow_zero, &c5, 3 + it % 5);
+        if (got3 != -2.0 && got5 >= 0) CHECK(same(got5, want));
         if (want < 1) ++*hits;
     }
 }

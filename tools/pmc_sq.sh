@@ -12,7 +12,13 @@ for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
          "SQ_IFETCH SQ_IFETCH_LEVEL" \
          "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY" \
          "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_SALU" \
-         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_VMEM"; do
+         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_VMEM" \
+         "SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU" \
+         "SQ_INSTS_CBRANCH SQ_INSTS_CBRANCH_TAKEN SQ_INSTS_CBRANCH_NOT_TAKEN" \
+         "SQ_LEVEL_WAVES SQ_WAVES SQ_BUSY_CYCLES" \
+         "SQ_INST_CYCLES_VALU SQ_VALU_MFMA_BUSY_CYCLES" \
+         "SQ_WAIT_INST_VALU SQ_WAIT_INST_SCA SQ_WAIT_INST_BRANCH SQ_WAIT_INST_MISC" \
+         "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
   rm -rf gpurun_out/pmcsq_$i
   rocprofv3 --pmc $G -d gpurun_out/pmcsq_$i --output-format csv -- python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmcsq_$i.log 2>&1 || tail -3 gpurun_out/pmcsq_$i.log
@@ -26,7 +32,7 @@ for d in sorted(glob.glob("gpurun_out/pmcsq_*/")):
     agg=collections.defaultdict(lambda:[0.0,0])
     for r in csv.DictReader(open(fs[-1])):
         nm=r["Kernel_Name"]
-        if "np_queue_k" not in nm and "sweep_stq_k" not in nm and "os_pass_k" not in nm: continue
+        if "np_queue_k" not in nm and "np_walk_k" not in nm and "sweep_stq_k" not in nm and "os_pass_k" not in nm: continue
         nm=nm.replace("(anonymous namespace)::","").split("(")[0].replace("void ","")
         agg[(nm,r["Counter_Name"])][0]+=float(r["Counter_Value"]); agg[(nm,r["Counter_Name"])][1]+=1
     for (k,c),(v,n) in agg.items(): out[k][c]=v/n
