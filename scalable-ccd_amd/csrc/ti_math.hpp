@@ -587,6 +587,47 @@ __device__ __forceinline__ NQDom nq_descend(NQWalk& w, const NQDom& cur, int spl
     r.d = cur.d + (1u << (8 * split));
     return r;
 }
+// descend from a node of depth < 32: the low words only
+__device__ __forceinline__ NQDom nq_descend32(NQWalk& w, const NQDom& cur, int split, bool second)
+{
+    const unsigned bit = 1u << (nq_depth(cur) & 31u);
+    w.s0.lo |= split == 0 ? bit : 0u;
+    w.s1.lo |= split == 1 ? bit : 0u;
+    w.pend.lo |= second ? bit : 0u;
+    NQDom r;
+    r.k0 = split == 0 ? 2u * cur.k0 : cur.k0;
+    r.k1 = split == 1 ? 2u * cur.k1 : cur.k1;
+    r.k2 = split == 2 ? 2u * cur.k2 : cur.k2;
+    r.d = cur.d + (1u << (8 * split));
+    return r;
+}
+// the same for depths below 32 (every bit involved sits in the low words: a third of the instructions)
+__device__ __forceinline__ NQDom nq_second_half_at32(const NQWalk& w, const NQDom& cur, unsigned j)
+{
+    const unsigned n = nq_depth(cur); // j < n <= 32
+    const unsigned below_n = n >= 32u ? ~0u : (1u << (n & 31u)) - 1u;
+    const unsigned m = below_n & ~((2u << j) - 1u); // bits j+1 .. n-1
+    const unsigned s0 = (unsigned)w.s0.lo, s1 = (unsigned)w.s1.lo;
+    const unsigned c0 = (unsigned)__builtin_popcount(s0 & m), c1 = (unsigned)__builtin_popcount(s1 & m);
+    const unsigned c2 = (n - 1u - j) - c0 - c1;
+    NQDom r;
+    r.k0 = cur.k0 >> c0;
+    r.k1 = cur.k1 >> c1;
+    r.k2 = cur.k2 >> c2;
+    r.d = cur.d - (c0 | (c1 << 8) | (c2 << 16));
+    const bool is0 = ((s0 >> j) & 1u) != 0, is1 = ((s1 >> j) & 1u) != 0;
+    r.k0 |= is0 ? 1u : 0u;
+    r.k1 |= (!is0 && is1) ? 1u : 0u;
+    r.k2 |= (!is0 && !is1) ? 1u : 0u;
+    return r;
+}
+__device__ __forceinline__ NQDom nq_backtrack32(NQWalk& w, const NQDom& cur) // depth(cur) <= 32, w.pend != 0
+{
+    const unsigned p = (unsigned)w.pend.lo;
+    const unsigned j = 31u - (unsigned)__builtin_clz(p | 1u);
+    w.pend.lo = (unsigned long long)(p & ~(1u << j)) | (w.pend.lo & 0xFFFFFFFF00000000ull);
+    return nq_second_half_at32(w, cur, j);
+}
 // backtrack to the deepest pending second half (w.pend != 0)
 __device__ __forceinline__ NQDom nq_backtrack(NQWalk& w, const NQDom& cur)
 {

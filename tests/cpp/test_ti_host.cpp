@@ -110,8 +110,20 @@ static double walk_stackless(const TIQuery& qd, double ms, double tol, bool allo
             if (s.accept && s.min_t < toi) toi = s.min_t;
             if (s.nk >= 1) {
                 if ((((d.d + (1u << (8 * s.split))) >> (8 * s.split)) & 255u) > 31u) return -2.0;
+                if (nq_depth(d) < 32u) {
+                    NQWalk w2 = w, w3 = w;
+                    const NQDom a = nq_descend32(w2, d, s.split, s.nk == 2), b = nq_descend(w3, d, s.split, s.nk == 2);
+                    CHECK(std::memcmp(&a, &b, sizeof a) == 0 && std::memcmp(&w2, &w3, sizeof w2) == 0);
+                }
                 d = nq_descend(w, d, s.split, s.nk == 2);
             } else if (nqb_any(w.pend)) {
+                if (nq_depth(d) <= 32u) { // the kernel's shallow form must agree with the general one
+                    NQWalk w2 = w;
+                    const NQDom a = nq_backtrack32(w2, d);
+                    NQWalk w3 = w;
+                    const NQDom b = nq_backtrack(w3, d);
+                    CHECK(std::memcmp(&a, &b, sizeof a) == 0 && std::memcmp(&w2, &w3, sizeof w2) == 0);
+                }
                 d = nq_backtrack(w, d);
             } else {
                 live = false;
