@@ -8,8 +8,10 @@
 //   build_vertex/edge/face_boxes broad_phase/aabb.cuh:156-188      same signatures (Matrix views)
 //   DeviceAABBs                  broad_phase/aabb.cuh:122-150      DeviceAABBs
 //   BroadPhase                   broad_phase/broad_phase.cuh:15-92 BroadPhase
-//   DeviceMatrix<T> x 4          utils/device_matrix.cuh:10-66     DeviceMesh (V0, V1, E, F together)
-//   narrow_phase<is_vf>          narrow_phase/narrow_phase.cuh:30  narrow_phase<is_vf>
+//   DeviceMatrix<T>              utils/device_matrix.cuh:10-66     DeviceMatrix<T>
+//   thrust::device_vector<int2>  (overlap list)                    DeviceVector<int2> (size(), data())
+//   MemoryHandler                memory_handler.hpp:7-44           MemoryHandler (same fields)
+//   narrow_phase<is_vf>          narrow_phase/narrow_phase.cuh:30  narrow_phase<is_vf>, same argument list
 //   ccd                          ccd.cuh:26-38                     ccd
 //   ipc_ccd_strategy             ipc_ccd_strategy.hpp:17-24        ipc_ccd_strategy
 //
@@ -83,6 +85,137 @@ private:
     sccd_ctx* m_ctx = nullptr;
 };
 
+/// Two packed ints, the element type of the overlap list (CUDA's int2 in the reference).
+struct int2 {
+    int x, y;
+};
+
+/// Device memory with the interface the reference uses of thrust::device_vector<T>: size(), data(), resize(), clear().
+/// Owning (allocated through the C ABI) or, for BroadPhase::overlaps(), a view of library-owned memory.
+template <class T> class DeviceVector {
+public:
+    DeviceVector() = default;
+    explicit DeviceVector(size_t n, Context& ctx = Context::default_context()) : m_ctx(&ctx) { resize(n); }
+    DeviceVector(const std::vector<T>& host, Context& ctx = Context::default_context()) : m_ctx(&ctx) { assign(host.data(), host.size()); }
+    ~DeviceVector() { release(); }
+    DeviceVector(const DeviceVector&) = delete;
+    DeviceVector& operator=(const DeviceVector&) = delete;
+    DeviceVector(DeviceVector&& o) noexcept { swap(o); }
+    DeviceVector& operator=(DeviceVector&& o) noexcept
+    {
+        swap(o);
+        return *this;
+    }
+    size_t size() const { return m_size; }
+    bool empty() const { return m_size == 0; }
+    T* data() { return m_data; }
+    const T* data() const { return m_data; }
+    void clear() { m_size = 0; }
+    void resize(size_t n)
+    {
+        if (n > m_cap) {
+            release();
+            ctx().check(sccd_dev_alloc(ctx().get(), n * sizeof(T), reinterpret_cast<void**>(&m_data)));
+            m_cap = n;
+            m_owned = true;
+        }
+        m_size = n;
+    }
+    void assign(const T* host, size_t n)
+    {
+        resize(n);
+        if (n) ctx().check(sccd_dev_upload(ctx().get(), m_data, host, n * sizeof(T)));
+    }
+    std::vector<T> to_host() const
+    {
+        std::vector<T> h(m_size);
+        if (m_size) ctx().check(sccd_dev_download(ctx().get(), h.data(), m_data, m_size * sizeof(T)));
+        return h;
+    }
+    /// (BroadPhase) point at library-owned memory
+    void view(const T* d, size_t n, Context& c)
+    {
+        release();
+        m_ctx = &c;
+        m_data = const_cast<T*>(d);
+        m_size = n;
+        m_cap = 0;
+        m_owned = false;
+    }
+    Context& ctx() const { return m_ctx ? *m_ctx : Context::default_context(); }
+
+private:
+    void release()
+    {
+        if (m_owned && m_data) sccd_dev_free(ctx().get(), m_data);
+        m_data = nullptr;
+        m_size = m_cap = 0;
+        m_owned = false;
+    }
+    void swap(DeviceVector& o)
+    {
+        std::swap(m_ctx, o.m_ctx);
+        std::swap(m_data, o.m_data);
+        std::swap(m_size, o.m_size);
+        std::swap(m_cap, o.m_cap);
+        std::swap(m_owned, o.m_owned);
+    }
+    Context* m_ctx = nullptr;
+    T* m_data = nullptr;
+    size_t m_size = 0, m_cap = 0;
+    bool m_owned = false;
+};
+
+/// A column-major matrix stored on the device (utils/device_matrix.cuh:10-66).
+template <typename T> class DeviceMatrix {
+public:
+    DeviceMatrix() = default;
+    DeviceMatrix(const size_t rows, const size_t cols, Context& ctx = Context::default_context())
+        : m_rows(rows), m_cols(cols), m_data(rows * cols, ctx) { }
+    DeviceMatrix(const ConstMatrixView<T>& mat, Context& ctx = Context::default_context())
+        : m_rows((size_t)mat.rows), m_cols((size_t)mat.cols), m_data(0, ctx)
+    {
+        m_data.assign(mat.data, m_rows * m_cols);
+    }
+    void operator=(const ConstMatrixView<T>& mat)
+    {
+        m_rows = (size_t)mat.rows;
+        m_cols = (size_t)mat.cols;
+        m_data.assign(mat.data, m_rows * m_cols);
+    }
+#ifdef SCCD_HIP_HAVE_EIGEN
+    DeviceMatrix(const Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic>& mat, Context& ctx = Context::default_context())
+        : DeviceMatrix(ConstMatrixView<T>(mat), ctx) { }
+#endif
+    T* data() { return m_data.data(); }
+    const T* data() const { return m_data.data(); }
+    size_t size() const { return m_data.size(); }
+    size_t rows() const { return m_rows; }
+    size_t cols() const { return m_cols; }
+    Context& ctx() const { return m_data.ctx(); }
+
+private:
+    size_t m_rows = 0, m_cols = 0;
+    DeviceVector<T> m_data;
+};
+
+/// MemoryHandler (memory_handler.hpp:7-44): the knobs of the reference's memory policy.  Here the library sizes its
+/// buffers itself (counted overflow -> exact-size rerun); what a caller can set keeps its meaning:
+///   memory_limit_GB      budget of the overlap list   (SCCD_OPT_MEMORY_LIMIT_MB)
+///   MAX_OVERLAP_CUTOFF   boxes swept per detect_overlaps_partial() call, 0 = all (SCCD_OPT_MAX_OVERLAP_CUTOFF)
+///   MAX_OVERLAP_SIZE     initial capacity of the overlap list in pairs, 0 = automatic (SCCD_OPT_OVERLAP_CAPACITY)
+/// real_count is written back after every detect_overlaps_partial(); the other fields are kept for source
+/// compatibility and have no effect.
+struct MemoryHandler {
+    size_t MAX_OVERLAP_CUTOFF = 0;
+    size_t MAX_OVERLAP_SIZE = 0;
+    size_t MAX_UNIT_SIZE = 0;
+    size_t MAX_QUERIES = 0;
+    size_t per_overlap_memory_size = 256 + 3 * sizeof(int2); // sizeof(CCDData) + 3 * sizeof(int2), memory_handler.hpp:18
+    int real_count = 0;
+    int memory_limit_GB = 0;
+};
+
 // --- boxes (aabb.cuh:156-188) -------------------------------------------------------------------
 
 inline void build_vertex_boxes(const MatrixXdView& vertices_t0, const MatrixXdView& vertices_t1,
@@ -138,19 +271,34 @@ private:
 /// class BroadPhase (broad_phase.cuh:15-92).
 class BroadPhase {
 public:
-    explicit BroadPhase(Context& ctx = Context::default_context()) : m_ctx(&ctx)
+    BroadPhase() : BroadPhase(std::make_shared<MemoryHandler>()) { }
+    explicit BroadPhase(std::shared_ptr<MemoryHandler> _memory_handler, Context& ctx = Context::default_context())
+        : memory_handler(std::move(_memory_handler)), m_ctx(&ctx)
     {
         ctx.check(sccd_broad_phase_create(ctx.get(), &m_bp));
     }
+    explicit BroadPhase(Context& ctx) : BroadPhase(std::make_shared<MemoryHandler>(), ctx) { }
     ~BroadPhase() { sccd_broad_phase_destroy(m_bp); }
     BroadPhase(const BroadPhase&) = delete;
     BroadPhase& operator=(const BroadPhase&) = delete;
 
+    /// Forget the boxes and the overlaps (broad_phase.cu:103-119; the reference also resets the caller's memory
+    /// handler and clears the CALLER's boxes here -- two quirks that are not reproduced).
+    void clear()
+    {
+        m_a.reset();
+        m_b.reset();
+        d_overlaps.view(nullptr, 0, *m_ctx);
+        sccd_broad_phase_destroy(m_bp);
+        m_bp = nullptr;
+        m_ctx->check(sccd_broad_phase_create(m_ctx->get(), &m_bp));
+    }
     void build(const std::shared_ptr<DeviceAABBs> boxes)
     {
         if (!boxes) throw std::runtime_error("BroadPhase::build: boxes are null");
         m_a = boxes;
         m_b.reset();
+        apply_memory_handler();
         m_ctx->check(sccd_broad_phase_build(m_bp, boxes->get(), nullptr));
     }
     void build(const std::shared_ptr<DeviceAABBs> boxesA, const std::shared_ptr<DeviceAABBs> boxesB)
@@ -158,20 +306,25 @@ public:
         if (!boxesA || !boxesB) throw std::runtime_error("BroadPhase::build: boxes are null");
         m_a = boxesA;
         m_b = boxesB;
+        apply_memory_handler();
         m_ctx->check(sccd_broad_phase_build(m_bp, boxesA->get(), boxesB->get()));
     }
-    /// Device pointer to int32[n][2] + n; valid until the next call (broad_phase.cuh:41-44).
-    std::pair<const int32_t*, int64_t> detect_overlaps_partial()
+    /// One sweep step; the overlaps stay on the device, valid until the next call (broad_phase.cuh:41-44).
+    const DeviceVector<int2>& detect_overlaps_partial()
     {
         const int32_t* p = nullptr;
         int64_t n = 0;
+        apply_memory_handler();
         m_ctx->check(sccd_broad_phase_detect_overlaps_partial(m_bp, &p, &n));
-        return { p, n };
+        d_overlaps.view(reinterpret_cast<const int2*>(p), (size_t)n, *m_ctx);
+        if (memory_handler) memory_handler->real_count = (int)n;
+        return d_overlaps;
     }
     std::vector<std::pair<int, int>> detect_overlaps()
     {
         int32_t* p = nullptr;
         int64_t n = 0;
+        apply_memory_handler();
         m_ctx->check(sccd_broad_phase_detect_overlaps(m_bp, &p, &n));
         std::vector<std::pair<int, int>> out((size_t)n);
         for (int64_t i = 0; i < n; i++) out[(size_t)i] = { p[2 * i], p[2 * i + 1] };
@@ -179,12 +332,27 @@ public:
         return out;
     }
     bool is_complete() const { return sccd_broad_phase_is_complete(m_bp) != 0; }
+    /// The boxes handed to build() (list A; unsorted, as given) -- broad_phase.cuh:60.
+    std::shared_ptr<DeviceAABBs> boxes() { return m_a; }
     size_t num_boxes() const { return (size_t)sccd_broad_phase_num_boxes(m_bp); }
+    /// The overlaps of the last detect_overlaps_partial(), on the device (broad_phase.cuh:66-68).
+    const DeviceVector<int2>& overlaps() { return d_overlaps; }
+
+    int threads_per_block = 32; // accepted for source compatibility; the sweep kernel picks its own launch shape
 
 private:
+    void apply_memory_handler()
+    {
+        if (!memory_handler) return;
+        if (memory_handler->memory_limit_GB > 0) m_ctx->set_option(SCCD_OPT_MEMORY_LIMIT_MB, (int64_t)memory_handler->memory_limit_GB * 1024);
+        if (memory_handler->MAX_OVERLAP_CUTOFF > 0) m_ctx->set_option(SCCD_OPT_MAX_OVERLAP_CUTOFF, (int64_t)memory_handler->MAX_OVERLAP_CUTOFF);
+        if (memory_handler->MAX_OVERLAP_SIZE > 0) m_ctx->set_option(SCCD_OPT_OVERLAP_CAPACITY, (int64_t)memory_handler->MAX_OVERLAP_SIZE);
+    }
+    std::shared_ptr<MemoryHandler> memory_handler;
     Context* m_ctx;
     sccd_broad_phase* m_bp = nullptr;
     std::shared_ptr<DeviceAABBs> m_a, m_b; // shared ownership as in the reference
+    DeviceVector<int2> d_overlaps;          // view of the library's overlap buffer
 };
 
 /// sort_and_sweep() of the reference's CPU API (broad_phase/sort_and_sweep.hpp:28-42,
@@ -252,23 +420,77 @@ private:
     sccd_mesh* m_mesh = nullptr;
 };
 
-/// narrow_phase<is_vf>() (narrow_phase.cuh:30-46).  `overlaps` are host pairs; toi is in/out.
+namespace detail {
+    template <bool is_vf>
+    void narrow_phase_on_mesh(Context& ctx, const sccd_mesh* mesh, const int32_t* pairs, int64_t n, int pairs_on_device,
+                              const int max_iter, const Scalar tol, const Scalar ms, const bool allow_zero_toi,
+                              std::vector<std::tuple<int, int, Scalar>>* collisions, Scalar& toi)
+    {
+        sccd_collision* col = nullptr;
+        int64_t ncol = 0;
+        ctx.check(sccd_narrow_phase(ctx.get(), mesh, pairs, n, pairs_on_device, is_vf ? 1 : 0, max_iter, tol, ms,
+                                    allow_zero_toi ? 1 : 0, &toi, collisions ? &col : nullptr, collisions ? &ncol : nullptr));
+        if (collisions) {
+            for (int64_t i = 0; i < ncol; i++) collisions->emplace_back(col[i].aid, col[i].bid, col[i].toi);
+            sccd_free(col);
+        }
+    }
+    struct MeshOfMatrices { // the library's packed mesh (sccd_mesh) of four device matrices, for one call
+        sccd_mesh* m = nullptr;
+        MeshOfMatrices(Context& ctx, const DeviceMatrix<Scalar>& V0, const DeviceMatrix<Scalar>& V1,
+                       const DeviceMatrix<int>& E, const DeviceMatrix<int>& F)
+        {
+            if (V0.rows() != V1.rows() || (V0.rows() && (V0.cols() != 3 || V1.cols() != 3)) || (E.rows() && E.cols() != 2)
+                || (F.rows() && F.cols() != 3))
+                throw std::runtime_error("narrow_phase: V must be n x 3, E m x 2, F k x 3");
+            ctx.check(sccd_mesh_create(ctx.get(), V0.data(), V1.data(), (int)V0.rows(), E.data(), (int)E.rows(), F.data(),
+                                       (int)F.rows(), /*src_on_device=*/1, &m));
+        }
+        ~MeshOfMatrices() { sccd_mesh_destroy(m); }
+    };
+} // namespace detail
+
+/// narrow_phase<is_vf>() with the reference's argument list (narrow_phase.cuh:30-46): four device matrices, the
+/// overlaps ON THE DEVICE (BroadPhase::overlaps()), `threads` and `memory_handler` accepted and unused (the kernel
+/// picks its own launch shape and needs no CCDData pool), toi in/out (>= 0, narrow_phase.cu:126).
+template <bool is_vf>
+void narrow_phase(const DeviceMatrix<Scalar>& d_vertices_t0, const DeviceMatrix<Scalar>& d_vertices_t1,
+                  const DeviceMatrix<int>& d_edges, const DeviceMatrix<int>& d_faces, const DeviceVector<int2>& d_overlaps,
+                  const int threads, const int max_iter, const Scalar tol, const Scalar ms, const bool allow_zero_toi,
+                  std::shared_ptr<MemoryHandler> memory_handler, Scalar& toi)
+{
+    (void)threads;
+    (void)memory_handler;
+    Context& ctx = d_vertices_t0.ctx();
+    detail::MeshOfMatrices mesh(ctx, d_vertices_t0, d_vertices_t1, d_edges, d_faces);
+    detail::narrow_phase_on_mesh<is_vf>(ctx, mesh.m, reinterpret_cast<const int32_t*>(d_overlaps.data()),
+                                        (int64_t)d_overlaps.size(), 1, max_iter, tol, ms, allow_zero_toi, nullptr, toi);
+}
+/// The SCALABLE_CCD_TOI_PER_QUERY overload (narrow_phase.cuh:42-44): also appends (aid, bid, toi) of the queries with toi < 1.
+template <bool is_vf>
+void narrow_phase(const DeviceMatrix<Scalar>& d_vertices_t0, const DeviceMatrix<Scalar>& d_vertices_t1,
+                  const DeviceMatrix<int>& d_edges, const DeviceMatrix<int>& d_faces, const DeviceVector<int2>& d_overlaps,
+                  const int threads, const int max_iter, const Scalar tol, const Scalar ms, const bool allow_zero_toi,
+                  std::shared_ptr<MemoryHandler> memory_handler, std::vector<std::tuple<int, int, Scalar>>& collisions,
+                  Scalar& toi)
+{
+    (void)threads;
+    (void)memory_handler;
+    Context& ctx = d_vertices_t0.ctx();
+    detail::MeshOfMatrices mesh(ctx, d_vertices_t0, d_vertices_t1, d_edges, d_faces);
+    detail::narrow_phase_on_mesh<is_vf>(ctx, mesh.m, reinterpret_cast<const int32_t*>(d_overlaps.data()),
+                                        (int64_t)d_overlaps.size(), 1, max_iter, tol, ms, allow_zero_toi, &collisions, toi);
+}
+/// Convenience forms on a packed DeviceMesh with HOST pairs (not in the reference).
 template <bool is_vf>
 void narrow_phase(const DeviceMesh& mesh, const std::vector<std::pair<int, int>>& overlaps, const int max_iter,
                   const Scalar tol, const Scalar minimum_separation_distance, const bool allow_zero_toi, Scalar& toi,
                   std::vector<std::tuple<int, int, Scalar>>* collisions = nullptr)
 {
     static_assert(sizeof(std::pair<int, int>) == 2 * sizeof(int32_t), "pair<int,int> must be two packed ints");
-    sccd_collision* col = nullptr;
-    int64_t ncol = 0;
-    mesh.context().check(sccd_narrow_phase(
-        mesh.context().get(), mesh.get(), reinterpret_cast<const int32_t*>(overlaps.data()), (int64_t)overlaps.size(),
-        0, is_vf ? 1 : 0, max_iter, tol, minimum_separation_distance, allow_zero_toi ? 1 : 0, &toi,
-        collisions ? &col : nullptr, collisions ? &ncol : nullptr));
-    if (collisions) {
-        for (int64_t i = 0; i < ncol; i++) collisions->emplace_back(col[i].aid, col[i].bid, col[i].toi);
-        sccd_free(col);
-    }
+    detail::narrow_phase_on_mesh<is_vf>(mesh.context(), mesh.get(), reinterpret_cast<const int32_t*>(overlaps.data()),
+                                        (int64_t)overlaps.size(), 0, max_iter, tol, minimum_separation_distance,
+                                        allow_zero_toi, collisions, toi);
 }
 
 /// ccd() (ccd.cuh:26-38): earliest time of impact in [0, 1], 1 = none.
@@ -288,35 +510,25 @@ inline Scalar ccd(const MatrixXdView& vertices_t0, const MatrixXdView& vertices_
 }
 
 /// ccd() of a SCALABLE_CCD_TOI_PER_QUERY build (ccd.cuh:26-38 with the `collisions` argument, ccd.cu:14-78):
-/// also returns (aid, bid, toi) of every query with toi < 1 -- vertex-face pairs first, then edge-edge.
+/// also returns (aid, bid, toi) of every query with toi < 1 -- vertex-face pairs first, then edge-edge.  One call
+/// into the library (sccd_ccd_collisions): the overlap pairs stay on the device between the phases.
 inline Scalar ccd(const MatrixXdView& vertices_t0, const MatrixXdView& vertices_t1, const MatrixXiView& edges,
                   const MatrixXiView& faces, const Scalar minimum_separation_distance, const int max_iterations,
                   const Scalar tolerance, const bool allow_zero_toi,
                   std::vector<std::tuple<int, int, Scalar>>& collisions, const int memory_limit_GB = 0,
                   Context& ctx = Context::default_context())
 {
-    collisions.clear();
-    DeviceMesh mesh(vertices_t0, vertices_t1, edges, faces, ctx);
-    std::vector<AABB> vertex_boxes, edge_boxes, face_boxes;
-    build_vertex_boxes(vertices_t0, vertices_t1, vertex_boxes, minimum_separation_distance, ctx); // ccd.cu:112
-    build_edge_boxes(vertex_boxes, edges, edge_boxes, ctx);
-    build_face_boxes(vertex_boxes, faces, face_boxes, ctx);
-    const int64_t saved = sccd_get_option(ctx.get(), SCCD_OPT_MEMORY_LIMIT_MB);
-    if (memory_limit_GB > 0) ctx.set_option(SCCD_OPT_MEMORY_LIMIT_MB, (int64_t)memory_limit_GB * 1024);
-    Scalar toi = 1; // ccd.cu:125
-    try {
-        BroadPhase broad_phase(ctx);
-        broad_phase.build(std::make_shared<DeviceAABBs>(vertex_boxes, ctx), std::make_shared<DeviceAABBs>(face_boxes, ctx));
-        narrow_phase<true>(mesh, broad_phase.detect_overlaps(), max_iterations, tolerance, minimum_separation_distance,
-                           allow_zero_toi, toi, &collisions);
-        broad_phase.build(std::make_shared<DeviceAABBs>(edge_boxes, ctx));
-        narrow_phase<false>(mesh, broad_phase.detect_overlaps(), max_iterations, tolerance, minimum_separation_distance,
-                            allow_zero_toi, toi, &collisions);
-    } catch (...) {
-        ctx.set_option(SCCD_OPT_MEMORY_LIMIT_MB, saved);
-        throw;
-    }
-    ctx.set_option(SCCD_OPT_MEMORY_LIMIT_MB, saved);
+    if (vertices_t0.rows != vertices_t1.rows || vertices_t0.cols != 3 || vertices_t1.cols != 3
+        || (edges.rows > 0 && edges.cols != 2) || (faces.rows > 0 && faces.cols != 3))
+        throw std::runtime_error("ccd: V must be n x 3, E m x 2, F k x 3"); // ccd.cu:94-98
+    Scalar toi = 1;
+    sccd_collision* col = nullptr;
+    int64_t ncol = 0;
+    ctx.check(sccd_ccd_collisions(ctx.get(), vertices_t0.data, vertices_t1.data, vertices_t0.rows, edges.data, edges.rows,
+                                  faces.data, faces.rows, minimum_separation_distance, max_iterations, tolerance,
+                                  allow_zero_toi ? 1 : 0, memory_limit_GB, &toi, &col, &ncol));
+    for (int64_t i = 0; i < ncol; i++) collisions.emplace_back(col[i].aid, col[i].bid, col[i].toi);
+    sccd_free(col);
     return toi;
 }
 

@@ -20,6 +20,7 @@
 #ifndef SCCD_H
 #define SCCD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -92,6 +93,15 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        query comes near the limit, otherwise conservative (TOI <= the reference's)          */
 int sccd_set_option(sccd_ctx* ctx, int option, int64_t value);
 int64_t sccd_get_option(const sccd_ctx* ctx, int option);
+
+/* ------------------------------------------------------------------------------------------ */
+/* device memory == thrust::device_vector<T> storage of DeviceMatrix<T> (utils/device_matrix.cuh:10-66)  */
+
+/* bytes of device memory on the context's device (0 bytes gives a NULL pointer); blocking copies */
+int sccd_dev_alloc(sccd_ctx* ctx, size_t bytes, void** d_ptr);
+int sccd_dev_free(sccd_ctx* ctx, void* d_ptr);
+int sccd_dev_upload(sccd_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int sccd_dev_download(sccd_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 
 /* ------------------------------------------------------------------------------------------ */
 /* mesh  == the four DeviceMatrix objects of ccd() (src/scalable_ccd/cuda/ccd.cu:103-106)     */
@@ -180,6 +190,13 @@ typedef struct sccd_stats {
 int sccd_ccd(sccd_ctx* ctx, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
              const int32_t* F, int nF, double min_distance, int max_iterations, double tolerance,
              int allow_zero_toi, int memory_limit_GB, double* toi);
+/* ccd() of a SCALABLE_CCD_TOI_PER_QUERY build (ccd.cuh:26-38 with `collisions`, ccd.cu:14-78): additionally hands
+ * back the (aid, bid, toi) records of every query with toi < 1 -- the vertex-face pass's, then the edge-edge pass's
+ * (a malloc'ed list, sccd_free).  The overlap pairs never leave the device between the two phases. */
+int sccd_ccd_collisions(sccd_ctx* ctx, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
+                        const int32_t* F, int nF, double min_distance, int max_iterations, double tolerance,
+                        int allow_zero_toi, int memory_limit_GB, double* toi, sccd_collision** collisions,
+                        int64_t* n_collisions);
 /* Same on a device-resident mesh; stats may be NULL.  This is what bench.py times. */
 int sccd_ccd_mesh(sccd_ctx* ctx, const sccd_mesh* mesh, double min_distance, int max_iterations,
                   double tolerance, int allow_zero_toi, double* toi, sccd_stats* stats);

@@ -330,6 +330,15 @@ static void mesh_set_vertices(sccd_mesh* m, const double* V0, const double* V1, 
     SCCD_HIP(hipStreamSynchronize(c->stream)); // borrowed inputs may go away after return
 }
 
+static void check_mesh_host(const double* V0, const double* V1, int nV, const int32_t* E, int nE, const int32_t* F, int nF);
+// Device-resident index matrices are validated on the device: an out-of-range vertex index would turn into wild
+// gathers in the box builders and the narrow phase (the reference asserts nothing and would fault).
+__global__ void mesh_index_check_k(const int32_t* __restrict__ idx, long long n, int nV, unsigned* __restrict__ bad)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (idx[i] < 0 || idx[i] >= nV)) atomicOr(bad, 1u);
+}
+
 extern "C" int sccd_mesh_create(sccd_ctx* c, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
                                 const int32_t* F, int nF, int src_on_device, sccd_mesh** out)
 {
@@ -338,6 +347,22 @@ extern "C" int sccd_mesh_create(sccd_ctx* c, const double* V0, const double* V1,
     return guarded(c, [&] {
         SCCD_REQUIRE(nV >= 0 && nE >= 0 && nF >= 0, "mesh: negative size");
         SCCD_REQUIRE((nV == 0 || (V0 && V1)) && (nE == 0 || E) && (nF == 0 || F), "mesh: null matrix");
+        if (!src_on_device) check_mesh_host(V0, V1, nV, E, nE, F, nF);
+        else if (nE + nF > 0) {
+            c->tmp2.ensure(sizeof(unsigned));
+            SCCD_HIP(hipMemsetAsync(c->tmp2.p, 0, sizeof(unsigned), c->stream));
+            if (nE > 0)
+                hipLaunchKernelGGL(mesh_index_check_k, dim3((unsigned)((2ll * nE + 255) / 256)), dim3(256), 0, c->stream, E,
+                                   2ll * nE, nV, c->tmp2.as<unsigned>());
+            if (nF > 0)
+                hipLaunchKernelGGL(mesh_index_check_k, dim3((unsigned)((3ll * nF + 255) / 256)), dim3(256), 0, c->stream, F,
+                                   3ll * nF, nV, c->tmp2.as<unsigned>());
+            SCCD_HIP(hipGetLastError());
+            unsigned bad = 0;
+            SCCD_HIP(hipMemcpyAsync(&bad, c->tmp2.p, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+            SCCD_HIP(hipStreamSynchronize(c->stream));
+            SCCD_REQUIRE(bad == 0, "mesh: edge or face index out of range");
+        }
         std::unique_ptr<sccd_mesh> m(new sccd_mesh());
         m->ctx = c;
         m->nV = nV;
@@ -1125,6 +1150,63 @@ static NarrowResult run_narrow(sccd_ctx* c, const sccd_mesh* m, const int2* d_pa
     return narrow_result(c);
 }
 
+// copy_out_collisions (narrow_phase.cu:84-103): the queries with toi < 1, appended as (aid, bid, toi).  The filter runs on
+// the device (ballot + one atomic per wave); only the records that survive cross the bus.
+__global__ void collisions_compact_k(const int2* __restrict__ pairs, const double* __restrict__ per_query, long long n,
+                                     sccd_collision* __restrict__ out, long long* __restrict__ out_idx,
+                                     unsigned long long* __restrict__ n_out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const double t = i < n ? per_query[i] : 2.0;
+    const bool hit = t < 1;
+    const unsigned long long mask = __ballot(hit);
+    if (mask == 0) return;
+    const int leader = (int)__builtin_ctzll(mask);
+    unsigned long long base = 0;
+    if (lane_id() == leader) base = atomicAdd(n_out, (unsigned long long)popc64(mask));
+    base = __shfl(base, leader, 64);
+    if (hit) {
+        const int2 p = pairs[i];
+        const unsigned long long at = base + (unsigned long long)mbcnt64(mask);
+        out[at] = sccd_collision { p.x, p.y, t };
+        out_idx[at] = i;
+    }
+}
+static void copy_out_collisions(sccd_ctx* c, const int2* d_pairs, const double* d_pq, int64_t n, std::vector<sccd_collision>& acc)
+{
+    if (n <= 0) return;
+    DevBuf out, idx, cnt;
+    out.ensure(sizeof(sccd_collision) * (size_t)n);
+    idx.ensure(sizeof(long long) * (size_t)n);
+    cnt.ensure(sizeof(unsigned long long));
+    SCCD_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(collisions_compact_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_pairs, d_pq,
+                       (long long)n, out.as<sccd_collision>(), idx.as<long long>(), cnt.as<unsigned long long>());
+    SCCD_HIP(hipGetLastError());
+    unsigned long long k = 0;
+    SCCD_HIP(hipMemcpyAsync(&k, cnt.p, sizeof k, hipMemcpyDeviceToHost, c->stream));
+    SCCD_HIP(hipStreamSynchronize(c->stream));
+    if (k == 0) return;
+    std::vector<sccd_collision> rec((size_t)k);
+    std::vector<long long> at((size_t)k);
+    SCCD_HIP(hipMemcpy(rec.data(), out.p, sizeof(sccd_collision) * (size_t)k, hipMemcpyDeviceToHost));
+    SCCD_HIP(hipMemcpy(at.data(), idx.p, sizeof(long long) * (size_t)k, hipMemcpyDeviceToHost));
+    // waves reserve their slots in order of arrival: put the records back into query order (what a serial
+    // copy_out_collisions gives; the reference's own order comes from atomics and is unspecified)
+    std::vector<size_t> order((size_t)k);
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return at[a] < at[b]; });
+    acc.reserve(acc.size() + (size_t)k);
+    for (size_t i = 0; i < order.size(); i++) acc.push_back(rec[order[i]]);
+}
+static sccd_collision* collisions_to_c(const std::vector<sccd_collision>& acc)
+{
+    sccd_collision* o = (sccd_collision*)std::malloc(std::max<size_t>(16, sizeof(sccd_collision) * acc.size()));
+    if (!o) throw SccdError { SCCD_E_NOMEM, "host allocation failed" };
+    if (!acc.empty()) std::memcpy(o, acc.data(), sizeof(sccd_collision) * acc.size());
+    return o;
+}
+
 extern "C" int sccd_narrow_phase(sccd_ctx* c, const sccd_mesh* m, const int32_t* pairs, int64_t n, int pairs_on_device,
                                  int is_vf, int max_iter, double tol, double ms, int allow_zero_toi, double* toi,
                                  sccd_collision** collisions, int64_t* n_collisions)
@@ -1156,26 +1238,11 @@ extern "C" int sccd_narrow_phase(sccd_ctx* c, const sccd_mesh* m, const int32_t*
             d_pq = pq.as<double>();
         }
         run_narrow(c, m, d_pairs, n, is_vf, max_iter, tol, ms, allow_zero_toi, toi, d_pq);
-        if (collisions && n > 0) { // copy_out_collisions (narrow_phase.cu:84-103)
-            std::vector<double> hq((size_t)n);
-            std::vector<int32_t> hp;
-            SCCD_HIP(hipMemcpyAsync(hq.data(), d_pq, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-            const int32_t* src = pairs;
-            if (pairs_on_device) {
-                hp.resize(2 * (size_t)n);
-                SCCD_HIP(hipMemcpyAsync(hp.data(), d_pairs, sizeof(int2) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-                src = hp.data();
-            }
-            SCCD_HIP(hipStreamSynchronize(c->stream));
-            int64_t k = 0;
-            for (int64_t i = 0; i < n; i++) k += hq[(size_t)i] < 1;
-            sccd_collision* o = (sccd_collision*)std::malloc(std::max<size_t>(16, sizeof(sccd_collision) * (size_t)k));
-            if (!o) throw SccdError { SCCD_E_NOMEM, "host allocation failed" };
-            k = 0;
-            for (int64_t i = 0; i < n; i++)
-                if (hq[(size_t)i] < 1) o[k++] = sccd_collision { src[2 * i], src[2 * i + 1], hq[(size_t)i] };
-            *collisions = o;
-            if (n_collisions) *n_collisions = k;
+        if (collisions && n > 0) {
+            std::vector<sccd_collision> acc;
+            copy_out_collisions(c, d_pairs, d_pq, n, acc);
+            *collisions = collisions_to_c(acc);
+            if (n_collisions) *n_collisions = (int64_t)acc.size();
         }
     });
 }
@@ -1326,8 +1393,7 @@ extern "C" int sccd_ccd_mesh_pass(sccd_ctx* c, const sccd_mesh* m, int is_vf, do
     });
 }
 
-static void check_mesh_host(const double* V0, const double* V1, int nV, const int32_t* E, int nE, const int32_t* F,
-                            int nF)
+static void check_mesh_host(const double* V0, const double* V1, int nV, const int32_t* E, int nE, const int32_t* F, int nF)
 {
     SCCD_REQUIRE(nV >= 0 && nE >= 0 && nF >= 0, "ccd: negative size");
     SCCD_REQUIRE((nV == 0 || (V0 && V1)) && (nE == 0 || E) && (nF == 0 || F), "ccd: null matrix");
@@ -1355,6 +1421,97 @@ extern "C" int sccd_ccd(sccd_ctx* c, const double* V0, const double* V1, int nV,
     rc = sccd_ccd_mesh(c, m, ms, max_iter, tol, allow_zero_toi, toi, nullptr);
     sccd_mesh_destroy(m);
     return rc;
+}
+
+// ccd() with the per-query collision list (ccd.cu:14-78 in a SCALABLE_CCD_TOI_PER_QUERY build): build, then alternate
+// detect_overlaps_partial / narrow_phase with per-query output; the pairs stay on the device throughout
+static void ccd_pass_collisions(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, bool vf, double ms, int max_iter, double tol,
+                                int allow_zero_toi, double* toi, std::vector<sccd_collision>& acc)
+{
+    if (vf) bp_build(&pl->bp, &pl->vb, &pl->fb);
+    else bp_build(&pl->bp, &pl->eb, nullptr);
+    DevBuf pq;
+    while (pl->bp.cursor < pl->bp.total_rows) {
+        bp_detect_partial(&pl->bp);
+        const int64_t n = pl->bp.n_overlaps;
+        if (n > 0) pq.ensure(sizeof(double) * (size_t)n);
+        run_narrow(c, m, pl->bp.overlaps.as<int2>(), n, vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi, toi,
+                   n > 0 ? pq.as<double>() : nullptr);
+        copy_out_collisions(c, pl->bp.overlaps.as<int2>(), pq.as<double>(), n, acc);
+    }
+}
+
+extern "C" int sccd_ccd_collisions(sccd_ctx* c, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
+                                   const int32_t* F, int nF, double ms, int max_iter, double tol, int allow_zero_toi,
+                                   int memory_limit_GB, double* toi, sccd_collision** collisions, int64_t* n_collisions)
+{
+    if (!c || !toi || !collisions || !n_collisions) return SCCD_E_INVALID;
+    *collisions = nullptr;
+    *n_collisions = 0;
+    const int64_t saved_limit = c->memory_limit_mb; // memory_limit_GB applies to this call (ccd.cu:40-43)
+    if (memory_limit_GB > 0) c->memory_limit_mb = (int64_t)memory_limit_GB << 10;
+    struct Restore {
+        sccd_ctx* c;
+        int64_t v;
+        ~Restore() { c->memory_limit_mb = v; }
+    } restore { c, saved_limit };
+    sccd_mesh* m = nullptr;
+    int rc = guarded(c, [&] { check_mesh_host(V0, V1, nV, E, nE, F, nF); });
+    if (rc != SCCD_OK) return rc;
+    rc = sccd_mesh_create(c, V0, V1, nV, E, nE, F, nF, 0, &m);
+    if (rc != SCCD_OK) return rc;
+    rc = guarded(c, [&] {
+        Pipeline* pl = pipeline_of(c);
+        boxes_from_mesh(c, m, ms, pl, true, true, true); // inflation radius = min_distance (ccd.cu:112)
+        double t = 1;                                    // ccd.cu:125
+        std::vector<sccd_collision> acc;
+        ccd_pass_collisions(c, m, pl, true, ms, max_iter, tol, allow_zero_toi, &t, acc);
+        ccd_pass_collisions(c, m, pl, false, ms, max_iter, tol, allow_zero_toi, &t, acc);
+        *collisions = collisions_to_c(acc);
+        *n_collisions = (int64_t)acc.size();
+        *toi = t;
+    });
+    sccd_mesh_destroy(m);
+    return rc;
+}
+
+extern "C" int sccd_dev_alloc(sccd_ctx* c, size_t bytes, void** d_ptr)
+{
+    if (!c || !d_ptr) return SCCD_E_INVALID;
+    *d_ptr = nullptr;
+    return guarded(c, [&] {
+        if (bytes == 0) return;
+        SCCD_HIP(hipSetDevice(c->device));
+        if (hipMalloc(d_ptr, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            throw SccdError { SCCD_E_NOMEM, "device allocation failed" };
+        }
+    });
+}
+extern "C" int sccd_dev_free(sccd_ctx* c, void* d_ptr)
+{
+    if (!c) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        if (d_ptr) SCCD_HIP(hipFree(d_ptr));
+    });
+}
+extern "C" int sccd_dev_upload(sccd_ctx* c, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!c || (bytes && (!d_dst || !h_src))) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        if (bytes == 0) return;
+        SCCD_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+extern "C" int sccd_dev_download(sccd_ctx* c, void* h_dst, const void* d_src, size_t bytes)
+{
+    if (!c || (bytes && (!h_dst || !d_src))) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        if (bytes == 0) return;
+        SCCD_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+    });
 }
 
 // partial_ipc_ccd_strategy<run_vf> (ipc_ccd_strategy.cu:12-92)

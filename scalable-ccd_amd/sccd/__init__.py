@@ -51,6 +51,7 @@ ABI_SYMBOLS = [
     "sccd_broad_phase_num_boxes", "sccd_broad_phase_candidates", "sccd_free", "sccd_narrow_phase", "sccd_ccd",
     "sccd_ccd_mesh", "sccd_ccd_mesh_prepare", "sccd_ccd_mesh_pass", "sccd_ipc_ccd_strategy", "sccd_get_profile", "sccd_reset_profile", "sccd_sort_pairs_u32",
     "sccd_shard_bounds", "sccd_boxes_variance_axis", "sccd_selftest_lds_gather",
+    "sccd_dev_alloc", "sccd_dev_free", "sccd_dev_upload", "sccd_dev_download", "sccd_ccd_collisions",
 ]
 
 
@@ -450,26 +451,28 @@ def ccd(V0, V1, E, F, min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow
 
 
 def _ccd_collisions(V0, V1, E, F, min_distance, max_iterations, tolerance, allow_zero_toi, memory_limit_GB, ctx):
-    """ccd.cu:14-78 with the per-query list: both passes through the public pieces."""
-    saved = ctx.get_option(OPT_MEMORY_LIMIT_MB)
-    if memory_limit_GB > 0:
-        ctx.set_option(OPT_MEMORY_LIMIT_MB, int(memory_limit_GB) * 1024)
-    mesh = Mesh(V0, V1, E, F, ctx=ctx)
-    bp = BroadPhase(ctx)
-    try:
-        vb, eb, fb = DeviceAABBs.from_mesh(mesh, min_distance)
-        toi, out = 1.0, []
-        for is_vf, a, b in ((True, vb, fb), (False, eb, None)):
-            bp.build(a, b)
-            ov = bp.detect_overlaps()
-            toi, col = narrow_phase(mesh, ov, is_vf, max_iterations, tolerance, min_distance, allow_zero_toi, toi,
-                                    want_collisions=True)
-            out.append(col)
-        return toi, np.concatenate(out)
-    finally:
-        bp.close()
-        mesh.close()
-        ctx.set_option(OPT_MEMORY_LIMIT_MB, saved)
+    """ccd.cu:14-78 with the per-query list: ONE call into the library (sccd_ccd_collisions); the overlap pairs stay on
+    the device between the broad and the narrow phase."""
+    V0c, V1c, Ec, Fc = _f64cm(V0), _f64cm(V1), _i32cm(E), _i32cm(F)
+    if V0c.ndim != 2 or V0c.shape[1] != 3 or V0c.shape != V1c.shape:
+        raise RuntimeError("V0, V1 must both be n x 3")
+    nE = Ec.shape[0] if Ec.size else 0
+    nF = Fc.shape[0] if Fc.size else 0
+    if (nE and Ec.shape[1] != 2) or (nF and Fc.shape[1] != 3):
+        raise RuntimeError("E must be m x 2 and F k x 3")
+    t = C.c_double(1.0)
+    cp = C.c_void_p()
+    cn = C.c_int64()
+    ctx._check(lib().sccd_ccd_collisions(
+        ctx._h, _ptr(V0c), _ptr(V1c), C.c_int(V0c.shape[0]), _ptr(Ec) if nE else None, C.c_int(nE),
+        _ptr(Fc) if nF else None, C.c_int(nF), C.c_double(min_distance), C.c_int(max_iterations), C.c_double(tolerance),
+        C.c_int(int(allow_zero_toi)), C.c_int(int(memory_limit_GB)), C.byref(t), C.byref(cp), C.byref(cn)))
+    if cn.value:
+        col = np.frombuffer(C.string_at(cp, cn.value * COLLISION_DTYPE.itemsize), dtype=COLLISION_DTYPE).copy()
+    else:
+        col = np.zeros(0, COLLISION_DTYPE)
+    lib().sccd_free(cp)
+    return t.value, col
 
 
 def ccd_mesh(mesh, min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow_zero_toi=True, want_stats=False):

@@ -88,6 +88,67 @@ static std::vector<std::pair<int, int>> sorted_pairs(const int32_t* p, int64_t n
     return v;
 }
 
+// ---- a driver written against the REFERENCE's interfaces -- the call sequence of partial_ccd<run_vf> / ccd()
+// (src/scalable_ccd/cuda/ccd.cu:14-146): MemoryHandler, BroadPhase(memory_handler), threads_per_block, build,
+// is_complete / detect_overlaps_partial, narrow_phase<run_vf>(four DeviceMatrix, broad_phase.overlaps(), threads, ...,
+// memory_handler, [collisions,] toi).  Only the namespace differs (sccd_ref below is scalable_ccd::cuda there); the
+// logger / profiler / cudaDeviceSynchronize lines of the original are infrastructure outside the path and left out.
+namespace sccd_ref = scalable_ccd::hip;
+namespace as_in_reference {
+using namespace sccd_ref;
+
+template <bool run_vf, bool per_query>
+void partial_ccd(const DeviceMatrix<Scalar>& d_vertices_t0, const DeviceMatrix<Scalar>& d_vertices_t1,
+                 const DeviceMatrix<int>& d_edges, const DeviceMatrix<int>& d_faces,
+                 const std::shared_ptr<DeviceAABBs> d_vertex_boxes, const std::shared_ptr<DeviceAABBs> d_edge_boxes,
+                 const std::shared_ptr<DeviceAABBs> d_face_boxes, const Scalar min_distance, const int max_iterations,
+                 const Scalar tolerance, const bool allow_zero_toi, std::vector<std::tuple<int, int, Scalar>>& collisions,
+                 Scalar& toi, const int memory_limit_GB)
+{
+    constexpr int bp_threads = 32;
+    constexpr int np_threads = 1024;
+    std::shared_ptr<MemoryHandler> memory_handler = std::make_shared<MemoryHandler>();
+    if (memory_limit_GB) memory_handler->memory_limit_GB = memory_limit_GB;
+    BroadPhase broad_phase(memory_handler);
+    broad_phase.threads_per_block = bp_threads;
+    if constexpr (run_vf) broad_phase.build(d_vertex_boxes, d_face_boxes);
+    else broad_phase.build(d_edge_boxes);
+    while (!broad_phase.is_complete()) {
+        broad_phase.detect_overlaps_partial();
+        if constexpr (per_query)
+            narrow_phase<run_vf>(d_vertices_t0, d_vertices_t1, d_edges, d_faces, broad_phase.overlaps(), np_threads,
+                                 max_iterations, tolerance, min_distance, allow_zero_toi, memory_handler, collisions, toi);
+        else
+            narrow_phase<run_vf>(d_vertices_t0, d_vertices_t1, d_edges, d_faces, broad_phase.overlaps(), np_threads,
+                                 max_iterations, tolerance, min_distance, allow_zero_toi, memory_handler, toi);
+    }
+}
+
+template <bool per_query>
+Scalar ccd(const MatrixXdView& vertices_t0, const MatrixXdView& vertices_t1, const MatrixXiView& edges, const MatrixXiView& faces,
+           const Scalar min_distance, const int max_iterations, const Scalar tolerance, const bool allow_zero_toi,
+           std::vector<std::tuple<int, int, Scalar>>& collisions, const int memory_limit_GB = 0)
+{
+    const DeviceMatrix<Scalar> d_vertices_t0(vertices_t0);
+    const DeviceMatrix<Scalar> d_vertices_t1(vertices_t1);
+    const DeviceMatrix<int> d_edges(edges);
+    const DeviceMatrix<int> d_faces(faces);
+    std::vector<AABB> vertex_boxes, edge_boxes, face_boxes;
+    build_vertex_boxes(vertices_t0, vertices_t1, vertex_boxes, min_distance);
+    build_edge_boxes(vertex_boxes, edges, edge_boxes);
+    build_face_boxes(vertex_boxes, faces, face_boxes);
+    const std::shared_ptr<DeviceAABBs> d_vertex_boxes = std::make_shared<DeviceAABBs>(vertex_boxes);
+    const std::shared_ptr<DeviceAABBs> d_edge_boxes = std::make_shared<DeviceAABBs>(edge_boxes);
+    const std::shared_ptr<DeviceAABBs> d_face_boxes = std::make_shared<DeviceAABBs>(face_boxes);
+    Scalar toi = 1;
+    partial_ccd<true, per_query>(d_vertices_t0, d_vertices_t1, d_edges, d_faces, d_vertex_boxes, d_edge_boxes, d_face_boxes,
+                                 min_distance, max_iterations, tolerance, allow_zero_toi, collisions, toi, memory_limit_GB);
+    partial_ccd<false, per_query>(d_vertices_t0, d_vertices_t1, d_edges, d_faces, d_vertex_boxes, d_edge_boxes, d_face_boxes,
+                                  min_distance, max_iterations, tolerance, allow_zero_toi, collisions, toi, memory_limit_GB);
+    return toi;
+}
+} // namespace as_in_reference
+
 int main()
 {
     std::vector<double> V0, V1;
@@ -202,6 +263,33 @@ int main()
         Scalar mn = 1;
         for (const auto& [i, j, _t] : all) mn = _t < mn ? _t : mn;
         CHECK(mn == toi);
+    }
+
+    {
+        // the driver written against the reference's interfaces (above): same TOI, same collision records
+        std::vector<std::tuple<int, int, Scalar>> none, mine, lib;
+        CHECK(as_in_reference::ccd<false>(vertices_t0, vertices_t1, edges, faces, min_distance, max_iterations, tolerance, allow_zero_toi, none) == toi);
+        CHECK(none.empty());
+        CHECK(as_in_reference::ccd<true>(vertices_t0, vertices_t1, edges, faces, min_distance, max_iterations, tolerance, allow_zero_toi, mine, 1) == toi);
+        CHECK(ccd(vertices_t0, vertices_t1, edges, faces, min_distance, max_iterations, tolerance, allow_zero_toi, lib) == toi);
+        std::sort(mine.begin(), mine.end());
+        std::sort(lib.begin(), lib.end());
+        CHECK(mine == lib && !mine.empty());
+        // BroadPhase surface of broad_phase.cuh:41-66: overlaps() is the device list of the last partial call
+        auto handler = std::make_shared<MemoryHandler>();
+        BroadPhase bp2(handler);
+        auto d_eb = std::make_shared<DeviceAABBs>(edge_boxes);
+        bp2.build(d_eb);
+        CHECK(bp2.boxes() == d_eb && bp2.num_boxes() == (size_t)nE);
+        const DeviceVector<int2>& ov = bp2.detect_overlaps_partial();
+        CHECK(&ov == &bp2.overlaps() && ov.size() == ee_overlaps.size() && handler->real_count == (int)ee_overlaps.size());
+        std::vector<int2> hv = ov.to_host();
+        std::vector<std::pair<int, int>> got(hv.size());
+        for (size_t i = 0; i < hv.size(); i++) got[i] = { hv[i].x, hv[i].y };
+        std::sort(got.begin(), got.end());
+        CHECK(got == ee_overlaps);
+        bp2.clear();
+        CHECK(bp2.num_boxes() == 0 && bp2.overlaps().size() == 0);
     }
 
     threw = false;
