@@ -31,6 +31,28 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 BYTES_PER_QUERY = 220.0       # narrow phase: pair 8 + element indices 12/16 + 24 coords + toi
 BYTES_SWEEP_PER_BOX = 64.0    # sweep: sorted box record, + 8 B per emitted pair
 BYTES_SORT_PER_KEY_PASS = 16  # one radix pass over (u32 key, u32 index): read 8 + write 8
+FLOP_PER_CHECK = 520.0        # one inclusion-function check = 8 corners x 57 FLOP + min/max/tests
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: FP64 vector peak
+
+
+def pmc_kernels(workload):
+    """per-kernel HBM bytes of profiles/r02_pmc_traffic_<workload>.json if that profile is of THIS build, else None"""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_%s.json" % workload)))
+        return tj["kernels"] if tj.get("lib_sha256") == lib_sha256() else None
+    except Exception:
+        return None
+
+
+def lib_sha256():
+    """hash of the libsccd_hip.so this process runs (stamps PMC profiles: bench.py only quotes a traffic figure that was
+    measured on the same build)"""
+    import hashlib
+
+    import sccd
+
+    with open(sccd._LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
 
 
 def parse():
@@ -70,6 +92,11 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
+    # --gpus N means N ranks, one GPU each (python -m torch.distributed.run --nproc-per-node N ...)
+    rccl_ranks = dist.get_world_size() if use_dist else 1
+    if args.gpus != rccl_ranks and os.environ.get("SCCD_FORCE_DIST") != "1":
+        raise SystemExit("bench.py --gpus %d needs %d ranks (launch with python -m torch.distributed.run --nproc-per-node %d), "
+                         "found %d" % (args.gpus, args.gpus, args.gpus, rccl_ranks))
     red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the scalars of the all-reduces live
 
     import sccd
@@ -154,13 +181,17 @@ def main():
         queries_per_step = float(qq[0].item()) / args.steps
         value = float(qq[0].item()) / dt
 
-        # roofline of the dominant kernel class of this rank: algorithmic bytes / device time
-        # measured live with hipEvents on the context's stream (SCCD_OPT_PROFILE)
+        # roofline of the dominant kernel class of this rank, measured live with hipEvents on the context's stream
+        # (SCCD_OPT_PROFILE).  Broad-phase classes are HBM-bound: algorithmic bytes / device time against
+        # 8 TB/s.  The narrow phase is bound by FP64 vector issue: inclusion checks x 520 FLOP
+        # (the survey's per-check figure: 8 corners x 57 + min/max/tests) / device time against the 78.6 TFLOP/s FP64
+        # vector peak; its HBM figure (220 B per query) is kept beside it as `hbm`.
         n_boxes = len(V0) + len(F) + len(E)
         q_vf, q_ee = stats["n_vf_pairs"], stats["n_ee_pairs"]  # this rank's queries per step
+        c_vf, c_ee = stats["n_vf_checks"], stats["n_ee_checks"]  # ... and inclusion checks (last step)
         units = {  # class -> (algorithmic bytes per step, kernel name, name in the rocprofv3 summaries)
-            "narrow_ee": (BYTES_PER_QUERY * q_ee, "np_queue_k<false> (edge-edge Tight-Inclusion)", "np_queue_k<false, %d, false>" % args.arith),
-            "narrow_vf": (BYTES_PER_QUERY * q_vf, "np_queue_k<true> (vertex-face Tight-Inclusion)", "np_queue_k<true, %d, false>" % args.arith),
+            "narrow_ee": (BYTES_PER_QUERY * q_ee, "np_walk_k<false> (edge-edge Tight-Inclusion)", "np_walk_k<false, %d, 0>" % args.arith),
+            "narrow_vf": (BYTES_PER_QUERY * q_vf, "np_walk_k<true> (vertex-face Tight-Inclusion)", "np_walk_k<true, %d, 0>" % args.arith),
             "sweep": (BYTES_SWEEP_PER_BOX * n_boxes + 8.0 * (q_vf + q_ee), "sweep_stq_k (3 launches per step)", "sweep_stq_k"),
             "sort": (BYTES_SORT_PER_KEY_PASS * 4 * n_boxes, "onesweep radix sort + scans", "os_pass_k"),
             "boxes": (124.0 * n_boxes, "box build, cell count/fill, gather", "entry_gather_k"),
@@ -169,33 +200,51 @@ def main():
         ms_dom, launches = prof[dom]  # live, over the timed region
         per_launch_ms = ms_dom / max(1, launches)
         launches_per_step = max(1, launches) / args.steps
-        achieved = units[dom][0] / launches_per_step / (per_launch_ms * 1e-3) / 1e9 if ms_dom > 0 else 0.0
-        traffic = None  # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.sh), same workload only
+        hbm_achieved = units[dom][0] / launches_per_step / (per_launch_ms * 1e-3) / 1e9 if ms_dom > 0 else 0.0
+        # HBM bytes per launch from the PMC passes (tools/pmc_traffic.sh, same workload) -- only if they were taken on
+        # THIS build of the library: the JSON carries the hash of the libsccd_hip.so it profiled
+        traffic, traffic_note = None, "no PMC profile of this workload"
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_cloth1m.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_cloth1m.json")))
             if args.workload == "cloth1m" and args.cloth_n == 708 and world == 1:
-                traffic = tj["kernels"][units[dom][2]]["hbm_bytes_per_launch_corrected"]
+                if tj.get("lib_sha256") == lib_sha256():
+                    traffic = tj["kernels"][units[dom][2]]["hbm_bytes_per_launch_corrected"]
+                    traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build (profiles/r02_pmc_traffic_cloth1m.json)"
+                else:
+                    traffic_note = "profiles/r02_pmc_traffic_cloth1m.json was taken on another build of the library: dropped"
         except Exception:
-            traffic = None
-        checks = float(stats["n_vf_checks"] + stats["n_ee_checks"])
-        roofline = {
-            "bound": "hbm", "kernel": units[dom][1], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "avg_launch_ms": round(per_launch_ms, 4), "launches": launches,
+            pass
+        checks = float(c_vf + c_ee)
+        narrow_ms = (prof_all["narrow_vf"][0] + prof_all["narrow_ee"][0]) / n_prof
+        if dom.startswith("narrow"):
+            dom_checks = float(c_ee if dom == "narrow_ee" else c_vf)
+            achieved = dom_checks * FLOP_PER_CHECK / launches_per_step / (per_launch_ms * 1e-3) / 1e12 if ms_dom > 0 else 0.0
+            roofline = {
+                "bound": "fp64_valu", "kernel": units[dom][1], "achieved": round(achieved, 3), "peak": FP64_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / FP64_VALU_PEAK_TFLOPS, 5), "traffic": traffic,
+                "flop_per_check": FLOP_PER_CHECK, "checks_per_launch": dom_checks / launches_per_step,
+                "hbm": {"achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(hbm_achieved / HBM_PEAK_GBS, 5), "bytes_per_query": BYTES_PER_QUERY},
+            }
+        else:
+            roofline = {"bound": "hbm", "kernel": units[dom][1], "achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 5), "traffic": traffic}
+        roofline.update({
+            "traffic_note": traffic_note, "avg_launch_ms": round(per_launch_ms, 4), "launches": launches,
             "class_ms_per_step": {k: round(v[0] / n_prof, 4) for k, v in prof_all.items()},
             "class_ms_source": "%d untimed steps after the warm-up with events on every class (the timed region times %s only)" % (n_prof, dom),
-            "note": "the narrow phase is FP64-VALU/latency bound, not HBM bound (DESIGN.md 5.5): "
-                    "%.3g inclusion checks/s = %.1f%% of the FP64 vector peak at 520 FLOP per check"
-                    % (checks / max(1e-9, (prof_all["narrow_vf"][0] + prof_all["narrow_ee"][0]) / n_prof * 1e-3),
-                       100.0 * checks * 520.0 / max(1e-9, (prof_all["narrow_vf"][0] + prof_all["narrow_ee"][0]) / n_prof * 1e-3) / 78.6e12),
-        }
+            "narrow_phase": {"checks_per_s": checks / max(1e-9, narrow_ms * 1e-3),
+                             "fp64_frac_vf_plus_ee": round(checks * FLOP_PER_CHECK / max(1e-9, narrow_ms * 1e-3) / (FP64_VALU_PEAK_TFLOPS * 1e12), 5),
+                             "ms_per_step": round(narrow_ms, 4)},
+        })
         result = {
             "metric": "CCD queries/sec (broad+narrow)", "value": value, "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": dict(wl, queries_per_step=queries_per_step, toi=toi, arith=["strict", "fma"][args.arith],
                            checks_per_step=float(qq[1].item()), candidates_per_step=float(qq[2].item()),
-                           parallelism=f"cell windows sharded over {world} GPU(s), one RCCL all-reduce(min) of the TOI per step"),
+                           parallelism=f"cell windows sharded over {world} GPU(s), one RCCL all-reduce(min) of the TOI per step",
+                           rccl_ranks=rccl_ranks, backend=(backend if use_dist else "none")),
             "min_toi_latency_ms": dt / args.steps * 1e3,
             "roofline": roofline,
         }
@@ -238,12 +287,8 @@ def bench_boxes(args, ctx, sccd, scenes, torch):
     prof = ctx.profile()
     ms_sweep, launches = prof["sweep"]
     achieved = (BYTES_SWEEP_PER_BOX * n + 8.0 * pairs) * args.steps / (ms_sweep * 1e-3) / 1e9
-    traffic = None  # HBM bytes per sweep launch from the committed PMC passes (tools/pmc_traffic.sh boxes1m)
-    try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_boxes1m.json")))["kernels"]["sweep_stq_k"][
-            "hbm_bytes_per_launch_corrected"]
-    except Exception:
-        traffic = None
+    tk = pmc_kernels("boxes1m")  # HBM bytes per sweep launch from the PMC passes of this build (tools/pmc_traffic.sh boxes1m)
+    traffic = tk["sweep_stq_k"]["hbm_bytes_per_launch_corrected"] if tk and "sweep_stq_k" in tk else None
     cls = {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[0] > 0}
     return {
         "metric": "broad-phase boxes/sec", "value": n * args.steps / dt, "unit": "boxes/s", "n_gpus": 1,
@@ -282,13 +327,12 @@ def bench_sort(args, ctx, sccd, torch):
     prof = ctx.profile()
     ms, launches = prof["sort"]
     ok = bool((keys[1:] >= keys[:-1]).all().item())
+    n_passes = 4
     achieved = BYTES_SORT_PER_KEY_PASS * 4 * n * args.steps / (ms * 1e-3) / 1e9
-    traffic = None  # HBM bytes of one sort (4 passes + histogram) from the committed PMC passes (tools/pmc_traffic.sh)
-    try:
-        tk = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_sort16m.json")))["kernels"]
-        traffic = 4 * tk["os_pass_k"]["hbm_bytes_per_launch_corrected"] + tk["os_hist_k"]["hbm_bytes_per_launch_corrected"]
-    except Exception:
-        traffic = None
+    tk = pmc_kernels("sort16m")  # HBM bytes of one sort (passes + histogram) from the PMC passes of this build
+    traffic = None
+    if tk and "os_pass_k" in tk and "os_hist_k" in tk:
+        traffic = n_passes * tk["os_pass_k"]["hbm_bytes_per_launch_corrected"] + tk["os_hist_k"]["hbm_bytes_per_launch_corrected"]
     return {
         "metric": "radix sort keys/sec", "value": n * args.steps / (ms * 1e-3), "unit": "keys/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms / args.steps, "higher_is_better": True,
