@@ -12,7 +12,9 @@ OBJS    := $(SRCS:.hip=.o)
 CPPTEST := tests/cpp/test_ccd_api
 HDRS    := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inc) include/sccd.h
 
-all: $(OUT) oracle $(CPPTEST)
+WALKPROBE := tests/gpu_probe/walk_probe
+
+all: $(OUT) oracle $(CPPTEST) $(WALKPROBE)
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -36,3 +38,9 @@ $(CPPTEST): tests/cpp/test_ccd_api.cpp include/scalable_ccd/hip/ccd.hpp include/
 	    -Wl,-rpath,'$$ORIGIN/../../scalable-ccd_amd/sccd' -Wl,-rpath,'$$ORIGIN/../../oracle' -Wl,-rpath,/opt/rocm/lib
 cpptest: $(CPPTEST)
 .PHONY: cpptest
+
+# device-vs-host check of the stackless-walk helpers of ti_math.hpp (compiles without a GPU, runs on one: tests/test_gpu_parity.py)
+$(WALKPROBE): tests/gpu_probe/walk_probe.hip tests/gpu_probe/walk_probe_host.cpp tests/gpu_probe/walk_probe_ops.h $(CSRC)/ti_math.hpp
+	g++ -O1 -std=c++17 -I$(CSRC) -Itests/gpu_probe -c tests/gpu_probe/walk_probe_host.cpp -o tests/gpu_probe/walk_probe_host.o
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -I$(CSRC) -Itests/gpu_probe -c tests/gpu_probe/walk_probe.hip -o tests/gpu_probe/walk_probe_dev.o
+	$(HIPCC) --offload-arch=$(ARCH) tests/gpu_probe/walk_probe_dev.o tests/gpu_probe/walk_probe_host.o -o $@

@@ -68,8 +68,7 @@ int sccd_set_stream(sccd_ctx* ctx, void* hip_stream);
 int sccd_synchronize(sccd_ctx* ctx);
 /* Self-test of the hand-written memory idioms of the narrow-phase kernel (no reference counterpart): n_waves
  * wavefronts each gather n_active (0..64) 48-byte vertex records into LDS by LDS-direct loads with a deliberately
- * late wait while other LDS traffic runs, and read a spill-stack entry back through the kernel's inline-assembly
- * load.  *n_bad = number of LDS / memory words that differ from the expected layout (0 = pass). */
+ * late wait while other LDS traffic runs.  *n_bad = number of LDS / memory words that differ from the expected layout (0 = pass). */
 int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* n_bad);
 
 /* options (sccd_set_option) */
@@ -221,8 +220,8 @@ int sccd_ipc_ccd_strategy(sccd_ctx* ctx, const double* V0, const double* V1, int
 #define SCCD_PROF_SORT 1
 #define SCCD_PROF_RANGES 2
 #define SCCD_PROF_SWEEP 3
-#define SCCD_PROF_NARROW_VF 4 /* np_queue_k<true> / np_level_k<true> launches  */
-#define SCCD_PROF_NARROW_EE 5 /* np_queue_k<false> / np_level_k<false> launches */
+#define SCCD_PROF_NARROW_VF 4 /* np_walk_k<true> / np_level_k<true> launches  */
+#define SCCD_PROF_NARROW_EE 5 /* np_walk_k<false> / np_level_k<false> launches */
 #define SCCD_PROF_COUNT 6
 /* accumulated device milliseconds and launch counts per kernel class since the last reset */
 int sccd_get_profile(sccd_ctx* ctx, double ms[SCCD_PROF_COUNT], int64_t launches[SCCD_PROF_COUNT]);

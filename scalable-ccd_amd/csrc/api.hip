@@ -1293,8 +1293,9 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
     // The edge-edge lists do not depend on the vertex-face pass: a helper context (own stream, scratch, pinned mirror)
     // builds them on a worker thread meanwhile.  Both builds are chains of short, latency-bound kernels with host
     // round trips in between, so two of them interleave almost for free (2.23 instead of 2.34 ms per step on the
-    // 1M-triangle cloth).  OPT-IN (SCCD_OVERLAP=1) until it has been soaked: the default keeps the passes apart.
-    static const bool overlap_env = std::getenv("SCCD_OVERLAP") && std::atoi(std::getenv("SCCD_OVERLAP")) == 1;
+    // 1M-triangle cloth; 1.99 instead of 2.11 with the round-2 kernels).  On by default since the whole GPU suite
+    // and the soak run with it; SCCD_OVERLAP=0 keeps the passes apart.
+    static const bool overlap_env = !(std::getenv("SCCD_OVERLAP") && std::atoi(std::getenv("SCCD_OVERLAP")) == 0);
     bool helper = false;
     if (overlap_env && m->nE > 0) {
         if (!c->side) {

@@ -151,7 +151,7 @@ struct NarrowCounters {
     unsigned int pad2;
     unsigned long long toi_level; // level-synchronous kernels with a check limit: the TOI as of the start of the level
     unsigned long long pad3[13];
-    // occupancy diagnostics of np_queue_k (SCCD_NP_DIAG=1 prints them)
+    // occupancy diagnostics of np_walk_k (SCCD_NP_DIAG=1 prints them)
     unsigned long long wave_steps;   // check steps executed by waves
     unsigned long long lane_steps;   // live lanes summed over those steps
     unsigned long long refill_execs; // hand-overs of a staging buffer

@@ -6,7 +6,7 @@
 //
 // Two algorithms, same results for max_iter < 0 (the final TOI is a min over accepted domains
 // and pruning by the running TOI never changes that min -- SURVEY Appendix A.20):
-//   algo 0  np_queue_k (narrow_queue.inc): ONE persistent launch.  Every lane walks its query's
+//   algo 0  np_walk_k (narrow_walk.inc): ONE persistent launch.  Every lane walks its query's
 //           [t]x[u]x[v] tree depth-first (earlier half first, so the running TOI drops early) with
 //           an on-chip stack; idle lanes pick fresh queries from a per-wave LDS staging area that
 //           LDS-direct loads refill in the background.  Divergent bisection depth is absorbed per
@@ -237,7 +237,10 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
     SCCD_HIP(hipMemGetInfo(&free_b, &total_b));
     // (8 GB per level buffer = 1.4e8 live domains: beyond that a slice is cut; 4096 queries that still need
     // more are hopeless in level order, and failing early beats filling 288 GB first)
-    const size_t budget = std::min<size_t>((size_t)8 << 30,
+    // (SCCD_LEVEL_BUDGET_MB: a smaller budget per level buffer, for soak runs on shared test machines)
+    static const size_t budget_cap = std::getenv("SCCD_LEVEL_BUDGET_MB")
+        ? std::max<size_t>(64, (size_t)std::atoll(std::getenv("SCCD_LEVEL_BUDGET_MB"))) << 20 : (size_t)8 << 30;
+    const size_t budget = std::min<size_t>(budget_cap,
                                            std::max<size_t>((free_b + c->np_scratch1.cap + c->np_scratch2.cap) / 3, (size_t)64 << 20));
     LvlSnap* snap = nullptr; // (a check limit: level-snapshot serialisation, see LvlSnap)
     if (p.max_iter >= 0) {
@@ -305,7 +308,6 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
 
 } // namespace
 
-#include "narrow_queue.inc"
 #include "narrow_walk.inc"
 
 // counters = {zeros, toi}: from the pinned mirror [12 KB, 16 KB)
@@ -353,10 +355,7 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
                                    reinterpret_cast<unsigned long long*>(d_per_query_toi), n, 0x7FF0000000000000ull);
                 SCCD_HIP(hipGetLastError());
             }
-            // (SCCD_NP_KERNEL=queue: the explicit-stack kernel, kept for comparison)
-            static const bool old_kernel = std::getenv("SCCD_NP_KERNEL") && std::string(std::getenv("SCCD_NP_KERNEL")) == "queue";
-            if (old_kernel) run_queue(c, p, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi));
-            else run_walk(c, p, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi));
+            run_walk(c, p, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi));
         }
     }
 }

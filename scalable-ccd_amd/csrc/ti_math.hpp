@@ -38,7 +38,7 @@ struct TIQuery {
     double v[8][3];
     double err[3];
     double tol[3];
-    // np_queue_k only: fl(1 / tol[k]) and whether the reciprocal shortcut below is exact for it
+    // np_walk_k only: fl(1 / tol[k]) and whether the reciprocal shortcut below is exact for it
     double inv_tol[3];
     bool inv_ok;
 };
@@ -171,7 +171,7 @@ template <bool VF> __device__ __forceinline__ void ti_tolerance(const double v[8
 }
 
 // The same tolerances and error bounds ONE COORDINATE AT A TIME, for callers that cannot afford
-// all 24 coordinates plus the eight differences in registers at once (np_queue_k's ingest reads
+// all 24 coordinates plus the eight differences in registers at once (np_walk_k's ingest reads
 // the coordinates back from LDS).  x[j] = v[j][k]; m[0..2] accumulate the three max_Linf_4 values
 // over k (max is exact, so the order of the maxima does not change a bit), start them at 0.
 template <bool VF> __device__ __forceinline__ void ti_tolerance_dim(const double x[8], double m[3])
@@ -250,7 +250,7 @@ template <bool VF> __device__ __forceinline__ void ti_error(const double v[8][3]
 // origin_in_inclusion_function (root_finder.cu:157-198) with calculate_vf / calculate_ee
 // (:137-155).  The reference evaluates all eight corners from scratch; the values that do not
 // depend on u or v are computed once per t here -- the same operations on the same operands,
-// hence the same bits.  DIFF: v[4..7] already hold the displacements v_e - v_s (np_queue_k computes
+// hence the same bits.  DIFF: v[4..7] already hold the displacements v_e - v_s (np_walk_k computes
 // them once per query instead of once per check).
 template <bool VF, int ARITH, bool DIFF = false>
 __device__ __forceinline__ bool ti_inclusion(const double v[8][3], const double lo[3], const double hi[3],
@@ -410,7 +410,7 @@ __device__ __forceinline__ TIStep ti_step(const TIQuery& q, const double lo[3], 
     return r;
 }
 
-// ---- np_queue_k's domain entries and step (used by narrow_queue.inc) ---------------------------------------------
+// ---- np_walk_k's domain entries and step (used by narrow_walk.inc) ---------------------------------------------
 // A DOMAIN ENTRY.  Every interval the bisection produces is [k 2^-d, (k + 1) 2^-d] (root [0, 1]: k = 0,
 // d = 0; halves of (k, d): (2k, d + 1) and (2k + 1, d + 1)), and all of those numbers -- like the
 // reference's mid = (lo + hi) / 2 (interval.cuh:21) -- are exact in double.  The kernel therefore keeps
@@ -498,7 +498,7 @@ __device__ __forceinline__ NQStep nq_step(const TIQuery& q, const NQDom& dm, dou
 }
 
 
-// ---- stackless depth-first walk (np_queue_k) ---------------------------------------------------------------------
+// ---- stackless depth-first walk (np_walk_k) ---------------------------------------------------------------------
 // WHICH dimension a domain is split in (split_dimension, root_finder.cu:200-211) depends on its three widths and
 // the query's tolerances only -- not on the inclusion check.  By induction the level triple (d_t, d_u, d_v) of a
 // node depends on its DEPTH n = d_t + d_u + d_v alone: the bisection tree of a query is a complete binary tree in

@@ -1,5 +1,5 @@
 // Host-side check of the PRODUCTION arithmetic (csrc/ti_math.hpp, Scalar = double): what np_level_k (ti_step) and
-// np_queue_k (nq_step on integer domain entries, per-query displacements, reciprocal tolerances, constants one
+// np_walk_k (nq_step on integer domain entries, per-query displacements, reciprocal tolerances, constants one
 // coordinate at a time) compute, against the CPU oracle -- per-query constants, single inclusion-function
 // evaluations, and whole queries walked depth-first, bit for bit.  Built by tests/test_ti_host.py with
 // g++ -ffp-contract=off -mfma (no GPU needed; the kernels around this arithmetic are covered by the -m gpu tests).
@@ -70,7 +70,7 @@ template <bool VF, int ARITH> static double walk_nq(const TIQuery& qd, double ms
         const NQStep s = nq_step<VF, ARITH>(qd, d, ms, tol, allow_zero, toi);
         if (s.checked && ++*checks > 1000000) return -1.0;
         if (s.accept && s.min_t < toi) toi = s.min_t;
-        if (s.nk >= 1) { // narrow_queue.inc, section 3
+        if (s.nk >= 1) { // narrow_walk.inc, section 3
             const unsigned nd = d.d + (1u << (8 * s.split));
             if (((nd >> (8 * s.split)) & 255u) > 31u) return -2.0; // NQ_OVF_INTERVAL: the kernel would hand over to level order
             const unsigned c0 = s.split == 0 ? 2u * d.k0 : d.k0, c1 = s.split == 1 ? 2u * d.k1 : d.k1, c2 = s.split == 2 ? 2u * d.k2 : d.k2;
@@ -178,7 +178,7 @@ static void run_case(int n_queries, double scale, double ms, bool allow_zero, lo
         ti_prepare_inv_tol(q);
         double otol[3], oerr[3];
         orc_query_constants(&q.v[0][0], VF ? 1 : 0, ms > 0, tol, otol, oerr);
-        // the work-queue kernel derives the same constants one coordinate at a time (narrow_queue.inc, constants_of)
+        // the work-queue kernel derives the same constants one coordinate at a time (narrow_walk.inc, constants_of)
         double m[3] = { 0, 0, 0 }, er[3], tl[3];
         for (int k = 0; k < 3; k++) {
             double x[8];
@@ -243,7 +243,7 @@ static void run_case(int n_queries, double scale, double ms, bool allow_zero, lo
         }
         CHECK(same(got1, want));
         CHECK(same(got2, want) && c2 == c1);
-        if (got3 == -2.0) ++*handed_over; // deeper than 2^-31: np_queue_k hands the call to the level-synchronous kernel
+        if (got3 == -2.0) ++*handed_over; // deeper than 2^-31: np_walk_k hands the call to the level-synchronous kernel
         else CHECK(same(got3, want) && c3 == c1); // same traversal, same number of checks
         // the stackless walk visits the same domains in the same order as the explicit stack ...
         long c4 = 0, c5 = 0;

@@ -882,8 +882,22 @@ def test_float_build_matches_the_oracle_twin(sccd, ctx, orc, arith):
 
 @pytest.mark.parametrize("n_active", [64, 24, 1, 0])
 def test_lds_direct_gather_idiom(sccd, ctx, n_active):
-    """The narrow-phase kernel issues its LDS-direct gathers and its spill-stack loads as inline assembly that the
-    compiler's wait-count bookkeeping does not see (narrow_queue.inc: nq_glds16, hbm_read).  This pins the idiom
+    """The narrow-phase kernel issues its LDS-direct gathers as inline assembly that the compiler's wait-count
+    bookkeeping does not see (narrow_walk.inc: nq_glds16, waited for by hand at the hand-over).  This pins the idiom
     against a compiler update: landed layout (piece p of lane l at base + (p * 64 + l) * 16), inactive lanes
     untouched, a late hand-placed wait behind other LDS traffic, per-wave M0 bases with two waves per block."""
     assert ctx.selftest_lds_gather(n_waves=512, n_active=n_active) == 0
+
+
+def test_walk_helpers_on_the_device_equal_the_host():
+    """ti_math.hpp's stackless-walk helpers (nq_descend / nq_backtrack / nq_donate: 96-bit path arithmetic) give the
+    same domains and path bits on the device as compiled for the host, over 1.6 million random states up to depth 93
+    (tests/gpu_probe/walk_probe.hip; the host side is what tests/cpp/test_ti_host.cpp checks against the oracle)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "gpu_probe", "walk_probe")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", root, exe[len(root) + 1:]])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "WALK PROBE: 0 mismatches" in r.stdout, r.stdout + r.stderr

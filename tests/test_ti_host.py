@@ -1,5 +1,5 @@
 """The arithmetic of the narrow-phase kernels (csrc/ti_math.hpp: ti_step of np_level_k; nq_step on integer domain
-entries, per-query displacements, reciprocal tolerances and per-coordinate constants of np_queue_k) is plain C++:
+entries, per-query displacements, reciprocal tolerances and per-coordinate constants of np_walk_k) is plain C++:
 compile it with the HOST compiler and compare it with the CPU oracle -- constants, single inclusion-function
 evaluations and whole queries walked depth-first, bit for bit, with identical check counts.  No GPU needed; the
 kernels AROUND this arithmetic (queues, stacks, gathers) are what the -m gpu tests cover."""

@@ -32,7 +32,7 @@ for d in sorted(glob.glob("gpurun_out/pmcsq_*/")):
     agg=collections.defaultdict(lambda:[0.0,0])
     for r in csv.DictReader(open(fs[-1])):
         nm=r["Kernel_Name"]
-        if "np_queue_k" not in nm and "np_walk_k" not in nm and "sweep_stq_k" not in nm and "os_pass_k" not in nm: continue
+        if "np_walk_k" not in nm and "np_walk_k" not in nm and "sweep_stq_k" not in nm and "os_pass_k" not in nm: continue
         nm=nm.replace("(anonymous namespace)::","").split("(")[0].replace("void ","")
         agg[(nm,r["Counter_Name"])][0]+=float(r["Counter_Value"]); agg[(nm,r["Counter_Name"])][1]+=1
     for (k,c),(v,n) in agg.items(): out[k][c]=v/n

@@ -17,9 +17,57 @@ def srt(p):
     return p[np.lexsort((p[:, 1], p[:, 0]))] if len(p) else p
 
 
+BATCH = 20          # seeds per child process
+CHILD_TIMEOUT = 420  # seconds of wall clock per child
+RSS_LIMIT_GB = 16    # a child above this ends itself (exit code 86)
+
+
+def supervise(cases, first):
+    """Every batch of seeds runs in a FRESH child process with a wall-clock limit, a resident-set watchdog and a capped
+    level-synchronous GPU budget: a checker that runs away (round 1 lost two GPU boxes to one) ends its own process,
+    not the machine.  The child is started before this process touches the GPU and is never exec'ed over it."""
+    import subprocess
+
+    bad = 0
+    for b0 in range(first, first + cases, BATCH):
+        n = min(BATCH, first + cases - b0)
+        env = dict(os.environ, SCCD_SOAK_CHILD="1", SCCD_LEVEL_BUDGET_MB=os.environ.get("SCCD_LEVEL_BUDGET_MB", "1024"))
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), str(n), str(b0)], env=env, timeout=CHILD_TIMEOUT)
+            rc = r.returncode
+        except subprocess.TimeoutExpired:
+            rc = -1
+            print(f"batch {b0}..{b0 + n - 1}: TIMEOUT after {CHILD_TIMEOUT} s", flush=True)
+        if rc != 0:
+            bad += 1
+            print(f"batch {b0}..{b0 + n - 1}: exit code {rc}", flush=True)
+    print(f"soak supervisor: {cases} cases from seed {first}, {bad} bad batch(es)")
+    return 1 if bad else 0
+
+
+def _watchdog():
+    import threading
+
+    def rss():
+        with open("/proc/self/statm") as f:
+            return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
+
+    def watch():
+        while True:
+            if rss() > RSS_LIMIT_GB * (1 << 30):
+                sys.stderr.write("[soak] resident set above the limit: ending this child\n")
+                os._exit(86)
+            time.sleep(0.25)
+
+    threading.Thread(target=watch, daemon=True).start()
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if os.environ.get("SCCD_SOAK_CHILD") != "1":
+        sys.exit(supervise(cases, first))
+    _watchdog()
     ctx = sccd.default_context()
     bad = 0
     t0 = time.time()
