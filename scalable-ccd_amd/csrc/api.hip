@@ -741,6 +741,7 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     bp->A = A;
     bp->B = B;
     bp->built = true;
+    bp->ranges_done = false;
     bp->cursor = 0;
     bp->n_overlaps = 0;
     bp->candidates = 0;
@@ -938,7 +939,10 @@ static void shard_rows(sccd_ctx* c, bool row_shard, int lo, int hi, int* out_lo,
     *out_hi = lo + (int)(n * (c->shard_rank + 1) / c->shard_count);
 }
 
-static void bp_detect_partial(sccd_broad_phase* bp)
+// phase 0: the whole step.  phase 1: enqueue the first attempt only (ranges + sweep), no read-back -- ccd() starts the
+// edge-edge sweep this way beside the vertex-face narrow phase; phase 2: finish what phase 1 started (read the counters
+// back, rerun on overflow as usual).
+static void bp_detect_partial(sccd_broad_phase* bp, int phase = 0)
 {
     sccd_ctx* c = bp->ctx;
     if (!bp->built) throw SccdError { SCCD_E_NOT_BUILT, "Must initialize build broad phase before detecting overlaps!" };
@@ -954,8 +958,8 @@ static void bp_detect_partial(sccd_broad_phase* bp)
     SweepCounters* d_cnt = c->scalars.as<SweepCounters>();
     unsigned long long* d_cand = d_cnt->cand_parts;
 
-    // ranges are (re)computed on the first chunk of a build
-    if (bp->cursor == 0) {
+    // ranges are (re)computed on the first chunk of a build (phase 3: that and nothing else)
+    if (bp->cursor == 0 && phase != 2 && !bp->ranges_done) {
         SCCD_HIP(hipMemsetAsync(d_cnt, 0, sizeof(SweepCounters), c->stream));
         ProfScope ps(c, SCCD_PROF_RANGES);
         bp->ranges_a.ensure(sizeof(uint2) * (size_t)std::max(A->m, 1));
@@ -968,6 +972,11 @@ static void bp_detect_partial(sccd_broad_phase* bp)
         }
     }
 
+    if (phase == 3) {
+        bp->ranges_done = true;
+        return;
+    }
+    bp->ranges_done = false; // (consumed: the next build computes its own)
     // SCCD_OPT_SWEEP_ALGO: 0/2 filter-queue-confirm STQ (default: measured faster on every workload
     // once its tiles are dealt without tickets), 1 plain SAP cross-check, 3 direct exact sweep.
     const bool direct = c->sweep_algo == 3;
@@ -1006,6 +1015,7 @@ static void bp_detect_partial(sccd_broad_phase* bp)
         shard_rows(c, bp->row_shard, a_lo, a_hi, &a_lo, &a_hi);
         if (B) shard_rows(c, bp->row_shard, b_lo, b_hi, &b_lo, &b_hi);
 
+        if (phase == 2 && attempt == 0) goto launched; // (phase 1 enqueued this attempt)
         if (attempt > 0 || chunk_lo != 0) // (the first chunk's counters were just zeroed as a whole)
             SCCD_HIP(hipMemsetAsync(&d_cnt->n_pairs, 0, sizeof(unsigned long long), c->stream));
         {
@@ -1020,6 +1030,8 @@ static void bp_detect_partial(sccd_broad_phase* bp)
                              bp->capacity, d_cnt, direct);
             }
         }
+        if (phase == 1) return;
+    launched:
         SweepCounters h;
         {
             ReadBack rb(c);
@@ -1254,14 +1266,21 @@ extern "C" int sccd_narrow_phase(sccd_ctx* c, const sccd_mesh* m, const int32_t*
 // (bp may belong to the helper context: its sweeps then run on that context's stream; every sweep ends with a host
 // round trip, so the narrow phase on c->stream starts after the pairs are complete either way)
 static void ccd_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, sccd_broad_phase* bp, bool vf, double ms, int max_iter,
-                     double tol, int allow_zero_toi, double* toi, sccd_stats* st, bool built = false)
+                     double tol, int allow_zero_toi, double* toi, sccd_stats* st, bool built = false, bool swept = false,
+                     std::function<void()>* before_narrow = nullptr)
 {
     if (built) {} // (ccd() had the lists built already, by the helper)
     else if (vf) bp_build(bp, &pl->vb, &pl->fb);
     else bp_build(bp, &pl->eb, nullptr);
+    bool started = swept; // (... and the first sweep enqueued as well: bp_detect_partial(bp, 1))
     while (bp->cursor < bp->total_rows) {
         narrow_counters_upload(c, narrow_counters(c), *toi); // ahead of the sweep: one copy less between sweep and narrow phase
-        bp_detect_partial(bp);
+        bp_detect_partial(bp, started ? 2 : 0);
+        started = false;
+        if (before_narrow && *before_narrow) {
+            (*before_narrow)();
+            *before_narrow = nullptr; // once
+        }
         const NarrowResult r = run_narrow(c, m, bp->overlaps.as<int2>(), bp->n_overlaps, vf ? 1 : 0, max_iter, tol, ms,
                                           allow_zero_toi, toi, nullptr);
         if (st) {
@@ -1296,7 +1315,8 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
     // 1M-triangle cloth; 1.99 instead of 2.11 with the round-2 kernels).  On by default since the whole GPU suite
     // and the soak run with it; SCCD_OVERLAP=0 keeps the passes apart.
     static const bool overlap_env = !(std::getenv("SCCD_OVERLAP") && std::atoi(std::getenv("SCCD_OVERLAP")) == 0);
-    bool helper = false;
+    bool helper = false, presweep_done = false;
+    static const bool presweep_env = !(std::getenv("SCCD_PRESWEEP") && std::atoi(std::getenv("SCCD_PRESWEEP")) == 0);
     if (overlap_env && m->nE > 0) {
         if (!c->side) {
             if (sccd_create(c->device, &c->side) != SCCD_OK) throw SccdError { SCCD_E_NOMEM, "ccd: cannot create the helper context" };
@@ -1321,11 +1341,32 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
             SCCD_HIP(hipSetDevice(device));
             SCCD_HIP(hipStreamWaitEvent(sc->stream, ev, 0));
             bp_build(bp_ee, eb, nullptr);
+            if (presweep_env) bp_detect_partial(bp_ee, 3); // the candidate ranges too (a 25 us kernel that must not queue behind the narrow phase)
         });
         helper = true;
     }
+    // The edge-edge SWEEP runs beside the vertex-face NARROW phase: it is enqueued on the helper's stream right before
+    // that kernel is launched, with half a CU's worth of blocks (they are resident first, the narrow kernel's blocks
+    // take the rest and, being ticket-driven, make do with what they get).  The sweep waits on dependent gathers most
+    // of the time, the narrow phase is bound by vector issue: sharing the CUs, the two take little longer than the
+    // narrow phase alone.  SCCD_PRESWEEP=0 keeps them apart.
+    std::function<void()> start_ee_sweep;
+    if (helper && presweep_env)
+        start_ee_sweep = [&] {
+            pl->worker.wait(); // the lists are built (long since: the build is shorter than the vertex-face broad phase)
+            static const int side_blocks = std::getenv("SCCD_PRESWEEP_BLOCKS") ? std::max(1, std::atoi(std::getenv("SCCD_PRESWEEP_BLOCKS"))) : 2;
+            c->side->sweep_blocks_per_cu = side_blocks;
+            try {
+                bp_detect_partial(&pl->bp_ee, 1);
+            } catch (...) {
+                c->side->sweep_blocks_per_cu = 0;
+                throw;
+            }
+            c->side->sweep_blocks_per_cu = 0;
+            presweep_done = true;
+        };
     try {
-        ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st);
+        ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st, false, false, &start_ee_sweep);
     } catch (...) {
         if (helper) {
             try {
@@ -1338,7 +1379,7 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
     }
     if (helper) {
         pl->worker.wait();
-        ccd_pass(c, m, pl, &pl->bp_ee, false, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true);
+        ccd_pass(c, m, pl, &pl->bp_ee, false, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true, /*swept=*/presweep_done);
     } else {
         ccd_pass(c, m, pl, &pl->bp, false, ms, max_iter, tol, allow_zero_toi, &toi, st);
     }

@@ -102,6 +102,7 @@ struct sccd_ctx {
     int64_t overlap_capacity = 0;
     int profile = 0;
     int scalar_f32 = 0; // SCCD_OPT_SCALAR: 1 = the reference's float build
+    int sweep_blocks_per_cu = 0; // 0 = the sweep kernel's own choice (a full CU); ccd()'s helper context sweeps with half
     int max_iter_fast = 0; // SCCD_OPT_MAX_ITER_FAST: 1 = check limits >= 4096 on the depth-first kernel (conservative)
     // narrow_counters_upload() already put {zeros, this TOI} into the narrow phase's counters (it rides ahead of
     // the sweep in ccd(), so that the narrow kernel can start right behind the sweep's read-back)

@@ -54,6 +54,7 @@ struct sccd_broad_phase {
     const sccd_boxes* A = nullptr;
     const sccd_boxes* B = nullptr; // nullptr: one list
     bool built = false;
+    bool ranges_done = false; // bp_detect_partial(bp, 3) computed the candidate ranges ahead of the sweep
     int64_t cursor = 0;     // thread_start_box_id of broad_phase.cuh:86 (in sorted rows)
     int64_t total_rows = 0; // rows of all sweep classes
     SortedList la, lb;         // sorted entry lists of A and B

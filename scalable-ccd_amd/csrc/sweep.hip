@@ -554,7 +554,8 @@ void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, c
         // for a slot doubles the tail.  128 VGPRs (launch bounds) and 40 KB of LDS -> 4 blocks per CU.
         // (With 156 VGPRs only 3 of the 4 blocks per CU were resident: sweep 0.61 -> 0.47 ms on C4.)
         static const int per_cu = std::getenv("SCCD_SWEEP_BLOCKS") ? std::atoi(std::getenv("SCCD_SWEEP_BLOCKS")) : 4;
-        const int grid = std::max(1, std::min((num_tiles + SW_WAVES - 1) / SW_WAVES, c->num_cus * per_cu));
+        const int grid = std::max(1, std::min((num_tiles + SW_WAVES - 1) / SW_WAVES,
+                                              c->num_cus * (c->sweep_blocks_per_cu > 0 ? c->sweep_blocks_per_cu : per_cu)));
         hipLaunchKernelGGL(sweep_stq_k, dim3(grid), dim3(SW_THREADS), 0, c->stream, rows->filt.as<float4>(),
                            rows->box.as<sccd_aabb>(), rows->key.as<uint32_t>(), ranges, row_begin, row_end,
                            cols->filt.as<float4>(), cols->box.as<sccd_aabb>(), gp, emit, out, (long long)capacity,
