@@ -125,7 +125,7 @@ struct sccd_ctx {
     DevBuf sort_tmp_keys, sort_tmp_vals, sort_hist, sort_status;
     DevBuf scalars;      // small device-side counters block
     PinnedBuf h_scalars; // pinned mirror for async read-back
-    DevBuf np_scratch0, np_scratch1, np_scratch2, np_scratch3, np_scratch4;
+    DevBuf np_scratch0, np_scratch1, np_scratch2, np_scratch3, np_scratch4, np_scratch3_ovf;
     DevBuf tmp0, tmp1, tmp2;
     void* pipeline = nullptr; // cached pipeline objects (api.hip)
     hipEvent_t rb_event = nullptr; // ReadBack: polled, not waited for

@@ -149,7 +149,7 @@ struct NarrowCounters {
     unsigned long long pad1[15];
     unsigned long long n_checks; // inclusion-function evaluations (one atomicAdd per wave)
     unsigned int overflow;
-    unsigned int pad2;
+    unsigned int n_ovf; // queries np_walk_k handed to the level-synchronous path (entries of its overflow list)
     unsigned long long toi_level; // level-synchronous kernels with a check limit: the TOI as of the start of the level
     unsigned long long pad3[13];
     // occupancy diagnostics of np_walk_k (SCCD_NP_DIAG=1 prints them)

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <vector>
 
 namespace {
 
@@ -59,12 +60,13 @@ struct LvlDomain { // CCDDomain (interval.cuh:30-44)
 template <bool VF, bool F32>
 __global__ void np_level_init_k(const double* __restrict__ V, const int2* __restrict__ E, const int4* __restrict__ F,
                                 const int2* __restrict__ pairs, long long first, long long n, double tol, bool use_ms,
-                                LvlData* __restrict__ data, LvlDomain* __restrict__ dom)
+                                LvlData* __restrict__ data, LvlDomain* __restrict__ dom, const int* __restrict__ sel)
 {
-    // queries [first, first + n) of the call: data[] is indexed by query, dom[] by position in the slice
+    // queries [first, first + n) of the call (of the selection `sel`, if given): data[] is indexed by query, dom[] by
+    // position in the slice
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const long long i = first + j;
+    const long long i = sel ? (long long)sel[first + j] : first + j;
     TIQuery q;
     ti_gather<VF>(V, E, F, pairs[i], q.v);
     if (F32) {
@@ -214,17 +216,23 @@ __global__ void np_fill_u64_k(unsigned long long* __restrict__ p, long long n, u
     if (i < n) p[i] = v;
 }
 
-__global__ void np_copy_per_query_k(const LvlData* __restrict__ data, long long n, double* __restrict__ out)
+__global__ void np_copy_per_query_k(const LvlData* __restrict__ data, long long n, double* __restrict__ out,
+                                    const int* __restrict__ sel)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = __longlong_as_double((long long)data[i].toi_bits);
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    if (!sel) out[j] = __longlong_as_double((long long)data[j].toi_bits);
+    else // a selection redone in level order: fold into what the work-queue kernel had found for the query
+        atomicMin(reinterpret_cast<unsigned long long*>(out) + sel[j], data[sel[j]].toi_bits);
 }
 
-template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, long long n,
-                                       double* d_per_query_toi)
+// d_sel / n_sel: only those queries of the call (np_walk_k's overflow list), else all n_all
+template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, long long n_all,
+                                       double* d_per_query_toi, const int* d_sel = nullptr, long long n_sel = 0)
 {
     const bool use_ms = p.ms > 0; // narrow_phase.cu:128
-    c->np_scratch0.ensure(sizeof(LvlData) * (size_t)n);
+    const long long n = d_sel ? n_sel : n_all; // queries to run; data[] / snap[] stay indexed by the query's own number
+    c->np_scratch0.ensure(sizeof(LvlData) * (size_t)n_all);
     LvlData* data = c->np_scratch0.as<LvlData>();
     c->tmp0.ensure(sizeof(unsigned long long));
     unsigned long long* d_n = c->tmp0.as<unsigned long long>();
@@ -244,7 +252,7 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
                                            std::max<size_t>((free_b + c->np_scratch1.cap + c->np_scratch2.cap) / 3, (size_t)64 << 20));
     LvlSnap* snap = nullptr; // (a check limit: level-snapshot serialisation, see LvlSnap)
     if (p.max_iter >= 0) {
-        c->np_scratch4.ensure(sizeof(LvlSnap) * (size_t)n);
+        c->np_scratch4.ensure(sizeof(LvlSnap) * (size_t)n_all);
         snap = c->np_scratch4.as<LvlSnap>();
     }
     long long slice = n;
@@ -253,10 +261,10 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
         c->np_scratch1.ensure(sizeof(LvlDomain) * (size_t)len);
         if (c->scalar_f32)
             hipLaunchKernelGGL((np_level_init_k<VF, true>), dim3((unsigned)((len + TPB - 1) / TPB)), dim3(TPB), 0, c->stream,
-                               p.V, p.E, p.F, p.pairs, q0, len, p.tol, use_ms, data, c->np_scratch1.as<LvlDomain>());
+                               p.V, p.E, p.F, p.pairs, q0, len, p.tol, use_ms, data, c->np_scratch1.as<LvlDomain>(), d_sel);
         else
             hipLaunchKernelGGL((np_level_init_k<VF, false>), dim3((unsigned)((len + TPB - 1) / TPB)), dim3(TPB), 0, c->stream,
-                               p.V, p.E, p.F, p.pairs, q0, len, p.tol, use_ms, data, c->np_scratch1.as<LvlDomain>());
+                               p.V, p.E, p.F, p.pairs, q0, len, p.tol, use_ms, data, c->np_scratch1.as<LvlDomain>(), d_sel);
         long long n_cur = len;
         DevBuf* cur = &c->np_scratch1;
         DevBuf* nxt = &c->np_scratch2;
@@ -301,7 +309,7 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
     }
     if (d_per_query_toi) {
         hipLaunchKernelGGL(np_copy_per_query_k, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, data,
-                           n, d_per_query_toi);
+                           n, d_per_query_toi, d_sel);
         SCCD_HIP(hipGetLastError());
     }
 }
@@ -355,7 +363,13 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
                                    reinterpret_cast<unsigned long long*>(d_per_query_toi), n, 0x7FF0000000000000ull);
                 SCCD_HIP(hipGetLastError());
             }
-            run_walk(c, p, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi));
+            if (d_per_query_toi || p.max_iter >= 0) { // (bookkeeping kernels: they can list queries beyond level 31 themselves)
+                const unsigned cap = (unsigned)std::min<long long>(n, 1 << 20);
+                c->np_scratch3_ovf.ensure(sizeof(int) * (size_t)cap);
+                run_walk(c, p, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi), c->np_scratch3_ovf.as<int>(), cap);
+            } else {
+                run_walk(c, p, d_cnt, n, nullptr);
+            }
         }
     }
 }
@@ -389,18 +403,66 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
                      (double)h.stamp[3] / h.wave_steps, (double)h.stamp[4] / h.wave_steps, (double)h.stamp[5] / h.wave_steps,
                      (double)h.stamp[6] / (double)std::max<unsigned long long>(1, h.refill_execs),
                      (double)h.stamp[7] / (double)std::max<unsigned long long>(1, h.refill_execs));
-    if (h.overflow) {
-        // the persistent kernel gave up (spill stack full, or an interval that cannot be held as
-        // lo + 2^-d): redo the call with the level-synchronous scheme, which has neither limit
-        NarrowCounters h2;
-        std::memset(&h2, 0, sizeof h2);
-        std::memcpy(&h2.toi_bits, h_toi_inout, 8);
-        SCCD_HIP(hipMemcpyAsync(d_cnt, &h2, sizeof h2, hipMemcpyHostToDevice, c->stream));
-        if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi);
-        else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi);
-        SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
-        SCCD_HIP(hipStreamSynchronize(c->stream));
-        if (h.overflow) throw SccdError { SCCD_E_OVERFLOW, "narrow phase: work queue capacity exhausted" };
+    if (h.overflow || h.n_ovf) {
+        // Some bisection cannot be held as (numerator, level <= 31) -- tolerance / (3 x extent) below 2^-31, as in scenes
+        // measured in millimetres -- or a check limit was reached in the opt-in fast mode.  What the kernel found so far
+        // stays valid (accepted domains only ever lower a TOI).  First choice: redo ONLY the queries concerned in level
+        // order.  A launch without the per-query bookkeeping could not name them: it is repeated with bookkeeping and an
+        // overflow list (rare: one extra pass of the fast kernel instead of a level-order pass over everything, which
+        // is several times slower and keeps every live domain of a level in HBM).
+        const unsigned cap = (unsigned)std::min<long long>(n, 1 << 20);
+        auto level_all = [&]() {
+            NarrowCounters h2;
+            std::memset(&h2, 0, sizeof h2);
+            std::memcpy(&h2.toi_bits, h_toi_inout, 8);
+            SCCD_HIP(hipMemcpyAsync(d_cnt, &h2, sizeof h2, hipMemcpyHostToDevice, c->stream));
+            if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi);
+            else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi);
+        };
+        bool done = false;
+        if (!(h.overflow & NQ_OVF_MAXITER)) {
+            c->np_scratch3_ovf.ensure(sizeof(int) * (size_t)cap);
+            int* d_list = c->np_scratch3_ovf.as<int>();
+            unsigned long long checks_so_far = h.n_checks;
+            if (h.overflow & NQ_OVF_INTERVAL) { // no usable list yet: the bookkeeping pass, seeded with the TOI reached
+                NarrowCounters h2;
+                std::memset(&h2, 0, sizeof h2);
+                h2.toi_bits = h.toi_bits;
+                SCCD_HIP(hipMemcpyAsync(d_cnt, &h2, sizeof h2, hipMemcpyHostToDevice, c->stream));
+                run_walk(c, p, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi), d_list, cap);
+                SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+                SCCD_HIP(hipStreamSynchronize(c->stream));
+                for (int k = 0; k < 8; k++) h.n_checks += h.checks_part[k].n;
+                h.n_checks += checks_so_far;
+                checks_so_far = h.n_checks;
+            }
+            if (!h.overflow && h.n_ovf <= cap) {
+                if (h.n_ovf > 0) {
+                    std::vector<int> ids(h.n_ovf);
+                    SCCD_HIP(hipMemcpyAsync(ids.data(), d_list, sizeof(int) * ids.size(), hipMemcpyDeviceToHost, c->stream));
+                    SCCD_HIP(hipStreamSynchronize(c->stream));
+                    std::sort(ids.begin(), ids.end()); // (a query shared among lanes is listed by each of them)
+                    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+                    SCCD_HIP(hipMemcpyAsync(d_list, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, c->stream));
+                    NarrowCounters h2;
+                    std::memset(&h2, 0, sizeof h2);
+                    h2.toi_bits = h.toi_bits;
+                    SCCD_HIP(hipMemcpyAsync(d_cnt, &h2, sizeof h2, hipMemcpyHostToDevice, c->stream));
+                    if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi, d_list, (long long)ids.size());
+                    else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi, d_list, (long long)ids.size());
+                    SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+                    SCCD_HIP(hipStreamSynchronize(c->stream));
+                    h.n_checks += checks_so_far;
+                }
+                done = !h.overflow;
+            }
+        }
+        if (!done) {
+            level_all();
+            SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            SCCD_HIP(hipStreamSynchronize(c->stream));
+            if (h.overflow) throw SccdError { SCCD_E_OVERFLOW, "narrow phase: work queue capacity exhausted" };
+        }
     }
     std::memcpy(h_toi_inout, &h.toi_bits, 8);
     // n_checks is read by the caller through d_cnt mirror

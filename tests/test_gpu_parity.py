@@ -845,9 +845,34 @@ def test_bisection_deeper_than_the_compressed_entries(sccd, ctx, orc, tol):
     F = np.array([[1, 2, 3]], np.int32)
     mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
     for is_vf, pairs in ((True, [[0, 0], [4, 0], [5, 0]]), (False, [[0, 3], [1, 3], [2, 3]])):
-        want, _, _ = orc.narrow_phase(V0, V1, E, F, pairs, is_vf, tol=tol)
+        want, want_pq, _ = orc.narrow_phase(V0, V1, E, F, pairs, is_vf, tol=tol, per_query=True)
         got = sccd.narrow_phase(mesh, pairs, is_vf, tol=tol)
         assert got == want and got < 1.0
+        # the per-query output takes the same route: the queries concerned are listed by the kernel and redone in level order
+        got_t, col = sccd.narrow_phase(mesh, pairs, is_vf, tol=tol, want_collisions=True)
+        hit = want_pq < 1
+        assert got_t == want and len(col) == int(hit.sum()) and np.array_equal(col["toi"], want_pq[hit])
+
+
+def test_only_the_queries_beyond_level_31_are_redone_in_level_order(sccd, ctx, orc):
+    """A scene measured in millimetres: tolerance / (3 x extent) drops below 2^-31 for the queries in contact, which the
+    work-queue kernel cannot hold as (numerator, level).  It lists THOSE queries and they alone are redone by the
+    level-synchronous kernels (round 1 redid the whole call: several times slower, and out of memory on contact-rich
+    scenes) -- the time of impact is the oracle's, and the check count stays far below a level-order pass over all."""
+    V0, V1, E, F = scenes.cloth_ball(24, 1, seed=3)
+    scale = 2000.0
+    V0, V1 = V0 * scale, V1 * scale
+    want, n_vf, n_ee = orc.ccd(V0, V1, E, F, 0.0, -1, 1e-6, True, nthreads=8)
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    got, st = sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True, want_stats=True)
+    assert got == want and got < 1.0
+    try:
+        ctx.set_option(sccd.OPT_NARROW_ALGO, 1)  # everything in level order
+        lvl, st_lvl = sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True, want_stats=True)
+    finally:
+        ctx.set_option(sccd.OPT_NARROW_ALGO, 0)
+    assert lvl == want
+    assert st["n_vf_checks"] + st["n_ee_checks"] < 0.7 * (st_lvl["n_vf_checks"] + st_lvl["n_ee_checks"])
 
 
 @pytest.mark.parametrize("arith", [0, 1])
