@@ -1,4 +1,7 @@
-# SQ counters of the narrow-phase kernels (one rocprofv3 --pmc pass per group of counters):
+# SQ counters of the narrow-phase kernels (one rocprofv3 --pmc pass per group of counters).  gfx950 exposes no
+# SQ_INSTS_CBRANCH(_TAKEN) (profiles/r02_counters_available_gfx950.txt is `rocprofv3 -L` of the box): branch behaviour is
+# read from SQ_INSTS_BRANCH, lane utilisation from SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU), occupancy from
+# 4 x SQ_WAVE_CYCLES / (SIMDs x GRBM_GUI_ACTIVE / 8):
 #   bash tools/pmc_sq.sh [workload]
 W=${1:-cloth1m}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -14,8 +17,7 @@ for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
          "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_SALU" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_VMEM" \
          "SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU" \
-         "SQ_INSTS_CBRANCH SQ_INSTS_CBRANCH_TAKEN SQ_INSTS_CBRANCH_NOT_TAKEN" \
-         "SQ_LEVEL_WAVES SQ_WAVES SQ_BUSY_CYCLES" \
+         "SQ_BUSY_CU_CYCLES SQ_WAVES_LT_64 SQ_WAVES_EQ_64" \
          "SQ_INST_CYCLES_VALU SQ_VALU_MFMA_BUSY_CYCLES" \
          "SQ_WAIT_INST_VALU SQ_WAIT_INST_SCA SQ_WAIT_INST_BRANCH SQ_WAIT_INST_MISC" \
          "GRBM_GUI_ACTIVE GRBM_COUNT"; do
