@@ -162,6 +162,7 @@ struct NarrowCounters {
     unsigned long long pops_reg, pops_mem; // pops served by the register top / by the HBM stack
     unsigned long long wave_hist[16];      // waves by number of check steps, buckets of 16 (last: >= 240)
     unsigned long long xcd_steps[8], xcd_waves[8]; // check steps and waves per XCD (HW_REG_XCC_ID)
+    unsigned long long tail_steps, max_tail_steps, max_tail_cycles, max_total_cycles, sum_tail_cycles; // after the wave's stream ran dry
     // check counts, striped over eight 128-byte lines: every wave adds its count when it ends, and they
     // all end together -- 2048 atomics on one word were a 20 us tail on every launch
     struct alignas(128) Stripe {

@@ -390,6 +390,10 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
                      n, h.n_checks, h.wave_steps, h.waves_run, (double)h.wave_steps / (double)std::max<unsigned long long>(1, h.waves_run),
                      h.max_wave_steps, (double)h.lane_steps / (64.0 * (double)h.wave_steps), h.refill_execs, h.steals,
                      h.pops_reg, h.pops_mem);
+    if (std::getenv("SCCD_NP_DIAG") && h.wave_steps)
+        std::fprintf(stderr, "[sccd np] tail (after a wave's query stream ran dry): %llu of %llu wave-steps, longest %llu steps / %.0f of %.0f kcycles; mean tail %.0f kcycles\n",
+                     h.tail_steps, h.wave_steps, h.max_tail_steps, h.max_tail_cycles / 1e3, h.max_total_cycles / 1e3,
+                     (double)h.sum_tail_cycles / 1e3 / (double)std::max<unsigned long long>(1, h.waves_run));
     if (std::getenv("SCCD_NP_DIAG") && h.wave_steps) {
         std::fprintf(stderr, "[sccd np] waves by steps (x16):");
         for (int k = 0; k < 16; k++) std::fprintf(stderr, " %llu", h.wave_hist[k]);
@@ -397,6 +401,7 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
         for (int k = 0; k < 8; k++) std::fprintf(stderr, " %.0f(%llu)", (double)h.xcd_steps[k] / (double)std::max<unsigned long long>(1, h.xcd_waves[k]), h.xcd_waves[k]);
         std::fprintf(stderr, "\n");
     }
+    if (std::getenv("SCCD_NP_DIAG") && std::atoi(std::getenv("SCCD_NP_DIAG")) >= 3 && h.tail_steps) h.wave_steps = h.tail_steps; // (per tail step)
     if (std::getenv("SCCD_NP_DIAG") && h.stamp[4])
         std::fprintf(stderr, "[sccd np] cycles/wave-step: toi=%.0f pop=%.0f steal=%.0f refill=%.0f check=%.0f push=%.0f | cycles/ingest: total=%.0f gather wait=%.0f\n",
                      (double)h.stamp[0] / h.wave_steps, (double)h.stamp[1] / h.wave_steps, (double)h.stamp[2] / h.wave_steps,

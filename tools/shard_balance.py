@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-rank cost of the multi-GPU shards, measured on ONE GPU by running every rank of an
-N-rank job in turn (prepare + VF pass + EE pass, the TOI threaded through as dist.ccd_sharded
-does).  Prints, per N, the slowest rank's time -- what an N-GPU step would take without the two
+N-rank job in turn (one ccd() on the rank's shard, as bench.py does; --split: prepare + VF pass + EE pass
+with the TOI threaded through as dist.ccd_sharded does).  Prints, per N, the slowest rank's time -- what an N-GPU step would take without the two
 scalar all-reduces -- next to the single-GPU step.
 
     python tools/shard_balance.py [--n 708] [--reps 5] [--worlds 1,2,4,8]
@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--worlds", default="1,2,4,8")
     ap.add_argument("--profile", action="store_true", help="also print rank 0's per-class device time")
+    ap.add_argument("--split", action="store_true", help="the pass-by-pass protocol (prepare + VF pass + EE pass) instead of one ccd() per rank")
     args = ap.parse_args()
 
     V0, V1, E, F = scenes.folded_cloth(args.n, seed=7)
@@ -42,12 +43,16 @@ def main():
             for rep in range(args.reps + 1):
                 ctx.synchronize()
                 t0 = time.perf_counter()
-                sccd.ccd_mesh_prepare(mesh, 0.0)
-                toi = 1.0
-                pairs = 0
-                for is_vf in (True, False):
-                    toi, st = sccd.ccd_mesh_pass(mesh, is_vf, toi)
-                    pairs += st["n_vf_pairs"] + st["n_ee_pairs"]
+                if args.split:
+                    sccd.ccd_mesh_prepare(mesh, 0.0)
+                    toi = 1.0
+                    pairs = 0
+                    for is_vf in (True, False):
+                        toi, st = sccd.ccd_mesh_pass(mesh, is_vf, toi)
+                        pairs += st["n_vf_pairs"] + st["n_ee_pairs"]
+                else:  # what bench.py runs per rank: one ccd() on the rank's shard
+                    toi, st = sccd.ccd_mesh(mesh, want_stats=True)
+                    pairs = st["n_vf_pairs"] + st["n_ee_pairs"]
                 ctx.synchronize()
                 dt = (time.perf_counter() - t0) * 1e3
                 if rep > 0:
@@ -57,10 +62,13 @@ def main():
                 ctx.set_option(sccd.OPT_PROFILE, 1)
                 ctx.reset_profile()
                 for rep in range(args.reps):
-                    sccd.ccd_mesh_prepare(mesh, 0.0)
-                    t = 1.0
-                    for is_vf in (True, False):
-                        t, _ = sccd.ccd_mesh_pass(mesh, is_vf, t)
+                    if args.split:
+                        sccd.ccd_mesh_prepare(mesh, 0.0)
+                        t = 1.0
+                        for is_vf in (True, False):
+                            t, _ = sccd.ccd_mesh_pass(mesh, is_vf, t)
+                    else:
+                        sccd.ccd_mesh(mesh)
                 prof = ctx.profile()
                 ctx.set_option(sccd.OPT_PROFILE, 0)
                 print("  rank 0 device ms/step:", {k: round(v[0] / args.reps, 3) for k, v in prof.items()},
