@@ -926,3 +926,28 @@ def test_walk_helpers_on_the_device_equal_the_host():
         subprocess.check_call(["make", "-s", "-C", root, exe[len(root) + 1:]])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "WALK PROBE: 0 mismatches" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("seed", [9143, 9220, 9040, 9110, 9124, 9348, 9392])
+def test_soak_seeds_that_once_failed(sccd, ctx, orc, seed):
+    """Scenes of tools/soak.py on which a build once returned a later time of impact than the oracle: the wave-local
+    TOI copy was assembled from two `readfirstlane` results (int) without going through `unsigned`, so a low word
+    with its top bit set smeared over the high word and the wave pruned with garbage.  The 1M-triangle cloth and the
+    rest of this suite happened to have TOIs whose low word is positive."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("soak_tool", os.path.join(root, "tools", "soak.py"))
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    V0, V1, E, F, kind, scale, shift, ms, allow_zero, arith, world, sweep_algo, scan_build, narrow_algo = soak.scene_of(seed)
+    want = orc.ccd(V0, V1, E, F, ms, -1, 1e-6, allow_zero, arith=arith, nthreads=8)[0]
+    try:
+        ctx.set_option(sccd.OPT_ARITH, arith)
+        ctx.set_option(sccd.OPT_SWEEP_ALGO, sweep_algo)
+        mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+        for _ in range(3):  # (the failure depended on timing)
+            assert sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero) == want
+    finally:
+        ctx.set_option(sccd.OPT_ARITH, 0)
+        ctx.set_option(sccd.OPT_SWEEP_ALGO, 0)

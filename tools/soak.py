@@ -12,6 +12,29 @@ import sccd
 from sccd import scenes
 
 
+def scene_of(seed):
+    """the scene and the switches of one soak seed (also used by tests/test_gpu_parity.py for seeds that once failed)"""
+    rng = np.random.default_rng(77_000 + seed)
+    kind = seed % 4
+    if kind == 0:
+        V0, V1, E, F = scenes.cloth_ball(int(rng.integers(6, 60)), int(rng.integers(1, 3)), seed=int(rng.integers(1, 10**6)))
+    elif kind == 1:
+        V0, V1, E, F = scenes.folded_cloth(int(rng.integers(10, 120)), seed=int(rng.integers(1, 10**6)))
+    else:
+        V0, V1, E, F = scenes.triangle_soup(int(rng.integers(20, 1500)), seed=int(rng.integers(1, 10**6)),
+                                            size=float(rng.uniform(0.02, 0.3)), motion=float(rng.uniform(0.0, 0.5)))
+    scale, shift = float(10.0 ** rng.uniform(-3, 3)), float(rng.uniform(-1, 1) * 10.0 ** rng.uniform(0, 4))
+    V0, V1 = V0 * scale + shift, V1 * scale + shift
+    ms = float(rng.choice([0.0, 0.0, 1e-4, 3e-3])) * scale
+    allow_zero = bool(rng.integers(0, 2))
+    arith = int(rng.integers(0, 2))
+    world = int(rng.choice([1, 1, 2, 3, 8]))
+    sweep_algo = int(rng.choice([0, 0, 1, 3]))
+    scan_build = bool(rng.integers(0, 4) == 0)
+    narrow_algo = int(rng.integers(0, 8) == 0 and len(F) < 300)  # (level order explodes on big contact-rich scenes)
+    return V0, V1, E, F, kind, scale, shift, ms, allow_zero, arith, world, sweep_algo, scan_build, narrow_algo
+
+
 def srt(p):
     p = np.asarray(p, np.int32).reshape(-1, 2)
     return p[np.lexsort((p[:, 1], p[:, 0]))] if len(p) else p
@@ -72,24 +95,7 @@ def main():
     bad = 0
     t0 = time.time()
     for seed in range(first, first + cases):
-        rng = np.random.default_rng(77_000 + seed)
-        kind = seed % 4
-        if kind == 0:
-            V0, V1, E, F = scenes.cloth_ball(int(rng.integers(6, 60)), int(rng.integers(1, 3)), seed=int(rng.integers(1, 10**6)))
-        elif kind == 1:
-            V0, V1, E, F = scenes.folded_cloth(int(rng.integers(10, 120)), seed=int(rng.integers(1, 10**6)))
-        else:
-            V0, V1, E, F = scenes.triangle_soup(int(rng.integers(20, 1500)), seed=int(rng.integers(1, 10**6)),
-                                                size=float(rng.uniform(0.02, 0.3)), motion=float(rng.uniform(0.0, 0.5)))
-        scale, shift = float(10.0 ** rng.uniform(-3, 3)), float(rng.uniform(-1, 1) * 10.0 ** rng.uniform(0, 4))
-        V0, V1 = V0 * scale + shift, V1 * scale + shift
-        ms = float(rng.choice([0.0, 0.0, 1e-4, 3e-3])) * scale
-        allow_zero = bool(rng.integers(0, 2))
-        arith = int(rng.integers(0, 2))
-        world = int(rng.choice([1, 1, 2, 3, 8]))
-        sweep_algo = int(rng.choice([0, 0, 1, 3]))
-        scan_build = bool(rng.integers(0, 4) == 0)
-        narrow_algo = int(rng.integers(0, 8) == 0 and len(F) < 300)  # (level order explodes on big contact-rich scenes)
+        V0, V1, E, F, kind, scale, shift, ms, allow_zero, arith, world, sweep_algo, scan_build, narrow_algo = scene_of(seed)
         tag = f"seed {seed} kind {kind} nF {len(F)} scale {scale:.3g} shift {shift:.3g} ms {ms:.3g} zero {allow_zero} arith {arith} world {world} sweep {sweep_algo} scan {scan_build} narrow {narrow_algo}"
         vb, eb, fb = orc.build_boxes(V0, V1, E, F, ms)
         want_vf, _, _ = orc.sort_and_sweep(vb, fb, nthreads=8)
