@@ -951,3 +951,44 @@ def test_soak_seeds_that_once_failed(sccd, ctx, orc, seed):
     finally:
         ctx.set_option(sccd.OPT_ARITH, 0)
         ctx.set_option(sccd.OPT_SWEEP_ALGO, 0)
+
+
+@pytest.mark.parametrize("seed", list(range(12_000, 12_048)))
+def test_soak_scenes(sccd, ctx, orc, seed):
+    """48 scenes of tools/soak.py (cloth-ball, folded cloth, triangle soups; scales 1e-3 .. 1e3, shifts up to 1e4, minimum
+    separations, both zero-TOI policies and arithmetic contracts, 1 / 2 / 3 / 8 shards, the three sweep algorithms): pair
+    sets and the time of impact against the oracle.  (The tool itself runs thousands of them; these travel with the suite.)"""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("soak_tool", os.path.join(root, "tools", "soak.py"))
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    V0, V1, E, F, kind, scale, shift, ms, allow_zero, arith, world, sweep_algo, scan_build, narrow_algo = soak.scene_of(seed)
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F, ms)
+    want_vf = orc.sort_and_sweep(vb, fb, nthreads=8)[0]
+    want_ee = orc.sort_and_sweep(eb, nthreads=8)[0]
+    want = orc.ccd(V0, V1, E, F, ms, -1, 1e-6, allow_zero, arith=arith, nthreads=8)[0]
+    try:
+        ctx.set_option(sccd.OPT_ARITH, arith)
+        ctx.set_option(sccd.OPT_SWEEP_ALGO, sweep_algo)
+        mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+        dv, de, df = sccd.DeviceAABBs.from_mesh(mesh, ms)
+        bp = sccd.BroadPhase(ctx)
+        tois, got_vf, got_ee = [], [], []
+        for r in range(world):
+            ctx.set_option(sccd.OPT_SHARD_COUNT, world)
+            ctx.set_option(sccd.OPT_SHARD_RANK, r)
+            bp.build(dv, df)
+            got_vf.append(bp.detect_overlaps().reshape(-1, 2))
+            bp.build(de)
+            got_ee.append(bp.detect_overlaps().reshape(-1, 2))
+            tois.append(sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero))
+        assert np.array_equal(_sorted(np.concatenate(got_vf)), want_vf)  # every pair from exactly one shard
+        assert np.array_equal(_sorted(np.concatenate(got_ee)), want_ee)
+        assert min(tois) == want
+    finally:
+        ctx.set_option(sccd.OPT_SHARD_COUNT, 1)
+        ctx.set_option(sccd.OPT_SHARD_RANK, 0)
+        ctx.set_option(sccd.OPT_ARITH, 0)
+        ctx.set_option(sccd.OPT_SWEEP_ALGO, 0)
