@@ -1365,8 +1365,88 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
             c->side->sweep_blocks_per_cu = 0;
             presweep_done = true;
         };
+    // ... and the edge-edge NARROW kernel starts on the helper's stream the moment that sweep is done, beside the tail of
+    // the vertex-face kernel (a wave-step of a deep query is a long dependent chain: the last part of a narrow launch
+    // keeps few lanes busy).  The two kernels share ONE running TOI (the vertex-face launch's word), so each prunes with
+    // what the other finds -- the final minimum does not depend on the order (Appendix A.20).  Only when both passes are
+    // served by the walk kernel in one chunk each; SCCD_NARROW_BESIDE=0 turns it off.
+    static const bool beside_env = !(std::getenv("SCCD_NARROW_BESIDE") && std::atoi(std::getenv("SCCD_NARROW_BESIDE")) == 0);
+    bool both_done = false;
     try {
-        ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st, false, false, &start_ee_sweep);
+        if (helper && presweep_env && beside_env && c->max_overlap_cutoff == 0) {
+            sccd_ctx* const sc = c->side;
+            sc->arith = c->arith;
+            sc->scalar_f32 = c->scalar_f32;
+            sc->narrow_algo = c->narrow_algo;
+            sc->max_iter_fast = c->max_iter_fast;
+            bp_build(&pl->bp, &pl->vb, &pl->fb);
+            narrow_counters_upload(c, narrow_counters(c), toi);
+            bp_detect_partial(&pl->bp);
+            const bool vf_one_chunk = pl->bp.cursor >= pl->bp.total_rows;
+            const NarrowParams pv = narrow_params(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, 1, max_iter, tol, ms, allow_zero_toi);
+            if (vf_one_chunk && narrow_uses_walk_kernel(c, pv, false)) {
+                start_ee_sweep();
+                start_ee_sweep = nullptr;
+                double toi_vf = toi, toi_ee = toi;
+                narrow_phase_begin(c, pv, narrow_counters(c), &toi_vf, nullptr); // (asynchronous)
+                bp_detect_partial(&pl->bp_ee, 2);                                 // waits for the edge-edge sweep
+                if (pl->bp_ee.cursor >= pl->bp_ee.total_rows) {
+                    NarrowParams pe = narrow_params(sc, m, pl->bp_ee.overlaps.as<int2>(), pl->bp_ee.n_overlaps, 0, max_iter, tol, ms, allow_zero_toi);
+                    pe.toi_word = &narrow_counters(c)->toi_bits;
+                    narrow_counters_upload(sc, narrow_counters(sc), toi_ee);
+                    c->np_peer_stream = sc->stream;
+                    try {
+                        narrow_phase_begin(sc, pe, narrow_counters(sc), &toi_ee, nullptr);
+                        narrow_phase_end(c, pv, narrow_counters(c), &toi_vf, nullptr);
+                    } catch (...) {
+                        c->np_peer_stream = nullptr;
+                        throw;
+                    }
+                    c->np_peer_stream = nullptr;
+                    const NarrowResult rv = narrow_result(c);
+                    narrow_phase_end(sc, pe, narrow_counters(sc), &toi_ee, nullptr);
+                    const NarrowResult re = narrow_result(sc);
+                    toi = std::min(toi_vf, toi_ee);
+                    if (st) {
+                        st->n_vf_pairs += pl->bp.n_overlaps;
+                        st->n_vf_checks += (int64_t)rv.n_checks;
+                        st->n_vf_candidates = pl->bp.candidates;
+                        st->n_ee_pairs += pl->bp_ee.n_overlaps;
+                        st->n_ee_checks += (int64_t)re.n_checks;
+                        st->n_ee_candidates = pl->bp_ee.candidates;
+                    }
+                    both_done = true;
+                } else { // (the edge-edge overlaps come in chunks: finish the vertex-face pass, then chunk by chunk as usual)
+                    narrow_phase_end(c, pv, narrow_counters(c), &toi_vf, nullptr);
+                    const NarrowResult rv = narrow_result(c);
+                    toi = toi_vf;
+                    if (st) {
+                        st->n_vf_pairs += pl->bp.n_overlaps;
+                        st->n_vf_checks += (int64_t)rv.n_checks;
+                        st->n_vf_candidates = pl->bp.candidates;
+                    }
+                    // the first edge-edge chunk is swept already: its narrow phase, then the rest of the loop
+                    const NarrowResult re = run_narrow(c, m, pl->bp_ee.overlaps.as<int2>(), pl->bp_ee.n_overlaps, 0, max_iter, tol, ms,
+                                                       allow_zero_toi, &toi, nullptr);
+                    if (st) {
+                        st->n_ee_pairs += pl->bp_ee.n_overlaps;
+                        st->n_ee_checks += (int64_t)re.n_checks;
+                    }
+                    presweep_done = false; // (consumed)
+                }
+            } else { // not this time: the vertex-face pass as usual (its lists are built and its first chunk swept)
+                const NarrowResult rv = run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, 1, max_iter, tol, ms,
+                                                   allow_zero_toi, &toi, nullptr);
+                if (st) {
+                    st->n_vf_pairs += pl->bp.n_overlaps;
+                    st->n_vf_checks += (int64_t)rv.n_checks;
+                }
+                ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true);
+                start_ee_sweep = nullptr;
+            }
+        } else {
+            ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st, false, false, &start_ee_sweep);
+        }
     } catch (...) {
         if (helper) {
             try {
@@ -1377,7 +1457,9 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
         }
         throw;
     }
-    if (helper) {
+    if (both_done) {
+        // (both passes are behind us)
+    } else if (helper) {
         pl->worker.wait();
         ccd_pass(c, m, pl, &pl->bp_ee, false, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true, /*swept=*/presweep_done);
     } else {

@@ -108,6 +108,9 @@ struct sccd_ctx {
     // the sweep in ccd(), so that the narrow kernel can start right behind the sweep's read-back)
     bool np_uploaded = false;
     double np_uploaded_toi = 0;
+    // a narrow-phase launch of ANOTHER context that shares this one's TOI word is running on that stream: before this
+    // context resets its counters (fallback paths) it waits for it
+    hipStream_t np_peer_stream = nullptr;
     int64_t max_overlap_cutoff = 0;
     int64_t memory_limit_mb = 0;
 

@@ -137,6 +137,9 @@ struct NarrowParams {
     double ms;
     int allow_zero_toi;
     int arith;
+    // the running TOI of this launch lives in ANOTHER launch's counters (ccd(): the edge-edge kernel starts beside the
+    // vertex-face kernel and shares its word, so that each prunes with what the other finds); nullptr: its own
+    unsigned long long* toi_word = nullptr;
 };
 struct NarrowCounters;
 void narrow_counters_upload(sccd_ctx* c, NarrowCounters* d_cnt, double toi);
@@ -178,4 +181,5 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
                       double* d_per_query_toi);
 void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
                       double* d_per_query_toi);
+bool narrow_uses_walk_kernel(const sccd_ctx* c, const NarrowParams& p, bool per_query); // (else: level-synchronous kernels)
 void narrow_selftest_lds_gather(sccd_ctx* c, const double* d_V, const int* d_perm, int n_waves, int n_active, double* d_out);

@@ -332,6 +332,13 @@ void narrow_counters_upload(sccd_ctx* c, NarrowCounters* d_cnt, double toi)
 // begin: upload the counters (unless narrow_counters_upload() already did) and launch; end: read the counters
 // back, handle the work-queue kernel's overflow flags, hand the TOI over.  (Split so that a caller can enqueue
 // unrelated work on another stream in between; narrow_phase_run() is the two back to back.)
+bool narrow_uses_walk_kernel(const sccd_ctx* c, const NarrowParams& p, bool per_query)
+{
+    (void)per_query;
+    return !(c->narrow_algo == 1 || c->scalar_f32 // (the work-queue kernel is double only)
+             || (p.max_iter >= 0 && (p.max_iter < SCCD_QUEUE_MIN_MAX_ITER || !c->max_iter_fast)));
+}
+
 void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, const double* h_toi_inout,
                         double* d_per_query_toi)
 {
@@ -352,8 +359,7 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
         // = 1 (opt-in) serves limits >= 4096 with the work-queue kernel instead: it counts depth-first checks per
         // lane and falls back to level order if a count passes the limit -- equal to the reference whenever no
         // query comes near the limit (the IPC Toolkit passes 1e7), otherwise conservative (TOI <= the reference's).
-        const bool level_sync = c->narrow_algo == 1 || c->scalar_f32 // (the work-queue kernel is double only)
-            || (p.max_iter >= 0 && (p.max_iter < SCCD_QUEUE_MIN_MAX_ITER || !c->max_iter_fast));
+        const bool level_sync = !narrow_uses_walk_kernel(c, p, d_per_query_toi != nullptr);
         if (level_sync) {
             if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi);
             else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi);
@@ -385,6 +391,10 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
         rb.sync();
     }
     for (int k = 0; k < 8; k++) h.n_checks += h.checks_part[k].n; // (the work-queue kernel counts in stripes)
+    if (p.toi_word) { // this launch kept its running TOI in another launch's word: that is its result so far
+        SCCD_HIP(hipMemcpyAsync(&h.toi_bits, p.toi_word, 8, hipMemcpyDeviceToHost, c->stream));
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+    }
     if (std::getenv("SCCD_NP_DIAG") && h.wave_steps)
         std::fprintf(stderr, "[sccd np] n=%lld checks=%llu wave_steps=%llu (waves %llu, mean %.1f, longest %llu) lane_util=%.3f refill_execs=%llu steals=%llu pops reg/mem=%llu/%llu\n",
                      n, h.n_checks, h.wave_steps, h.waves_run, (double)h.wave_steps / (double)std::max<unsigned long long>(1, h.waves_run),
@@ -415,11 +425,16 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
         // order.  A launch without the per-query bookkeeping could not name them: it is repeated with bookkeeping and an
         // overflow list (rare: one extra pass of the fast kernel instead of a level-order pass over everything, which
         // is several times slower and keeps every live domain of a level in HBM).
+        if (c->np_peer_stream) { // a launch of another context shares this TOI word: let it finish before the counters are reset
+            SCCD_HIP(hipStreamSynchronize(c->np_peer_stream));
+            SCCD_HIP(hipMemcpyAsync(&h.toi_bits, &d_cnt->toi_bits, 8, hipMemcpyDeviceToHost, c->stream));
+            SCCD_HIP(hipStreamSynchronize(c->stream));
+        }
         const unsigned cap = (unsigned)std::min<long long>(n, 1 << 20);
         auto level_all = [&]() {
             NarrowCounters h2;
             std::memset(&h2, 0, sizeof h2);
-            std::memcpy(&h2.toi_bits, h_toi_inout, 8);
+            h2.toi_bits = h.toi_bits; // (what was found so far stays valid)
             SCCD_HIP(hipMemcpyAsync(d_cnt, &h2, sizeof h2, hipMemcpyHostToDevice, c->stream));
             if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi);
             else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi);
@@ -436,6 +451,7 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
                 SCCD_HIP(hipMemcpyAsync(d_cnt, &h2, sizeof h2, hipMemcpyHostToDevice, c->stream));
                 run_walk(c, p, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi), d_list, cap);
                 SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+                if (p.toi_word) SCCD_HIP(hipMemcpyAsync(&h.toi_bits, p.toi_word, 8, hipMemcpyDeviceToHost, c->stream));
                 SCCD_HIP(hipStreamSynchronize(c->stream));
                 for (int k = 0; k < 8; k++) h.n_checks += h.checks_part[k].n;
                 h.n_checks += checks_so_far;
