@@ -5,9 +5,6 @@ R=${1:-r02}
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
-for W in cloth1m boxes1m sort16m clothball10k; do
-  python3 bench.py --workload $W 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_$W.json.log
-done
 for W in cloth1m boxes1m sort16m; do
   rm -rf gpurun_out/prof/ks_$W
   rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_$W --output-format csv -- python3 bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof/ks_$W.log 2>&1
@@ -20,7 +17,10 @@ done
 bash tools/pmc_sq.sh cloth1m > gpurun_out/prof/pmc_sq_cloth1m.txt 2>&1
 cp gpurun_out/pmc_sq_cloth1m.json gpurun_out/prof/${R}_pmc_sq_cloth1m.json
 python3 tools/shard_balance.py --profile > gpurun_out/prof/${R}_shard_balance.log 2>&1
-# the line bench.py prints once the traffic files are in place (same build: the hashes match)
+# the lines bench.py prints once the traffic files are in place (same build: the hashes match)
 cp gpurun_out/prof/${R}_pmc_traffic_*.json profiles/ 2>/dev/null
-python3 bench.py 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_with_traffic.json.log
+for W in cloth1m boxes1m sort16m clothball10k; do
+  python3 bench.py --workload $W 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_$W.json.log
+done
+SCCD_OVERLAP=0 python3 bench.py --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_passes_apart.json.log
 ls -la gpurun_out/prof
