@@ -68,47 +68,56 @@ __device__ __forceinline__ void wave_rank_rows(const uint32_t (&key)[RS_ITEMS], 
 }
 
 // ---- onesweep ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(RS_THREADS) void os_hist_k(const uint32_t* __restrict__ keys, long long n, int num_tiles,
-                                                        uint32_t* __restrict__ partial, uint4* __restrict__ zero,
-                                                        long long zero_n)
+constexpr int HS_THREADS = 1024; // one block per CU, sixteen waves: the loads of many waves in flight hide the HBM latency
+__global__ __launch_bounds__(HS_THREADS) void os_hist_k(const uint32_t* __restrict__ keys, long long n, uint32_t* __restrict__ partial,
+                                                        uint4* __restrict__ zero, long long zero_n)
 {
     // every word the passes poll (tickets + look-back status) is zeroed here, not by memsets
-    for (long long i = (long long)blockIdx.x * RS_THREADS + threadIdx.x; i < zero_n; i += (long long)gridDim.x * RS_THREADS)
+    for (long long i = (long long)blockIdx.x * HS_THREADS + threadIdx.x; i < zero_n; i += (long long)gridDim.x * HS_THREADS)
         zero[i] = make_uint4(0u, 0u, 0u, 0u);
     __shared__ uint32_t h[4][256];
-#pragma unroll
-    for (int p = 0; p < 4; p++) h[p][threadIdx.x] = 0;
+    h[threadIdx.x >> 8][threadIdx.x & 255] = 0;
     __syncthreads();
-    for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
-        const long long base = (long long)tile * RS_TILE;
+    // 16 keys per thread and round (four 16-byte loads in flight per thread), rounds strided over the grid
+    const long long quads = (n + 3) / 4;
+    for (long long q0 = ((long long)blockIdx.x * HS_THREADS + threadIdx.x); q0 < quads; q0 += (long long)gridDim.x * HS_THREADS * 4) {
+        uint4 k4[4];
+        int cnt4[4];
 #pragma unroll
-        for (int r = 0; r < RS_ITEMS / 4; r++) {
-            const long long i = base + ((long long)r * RS_THREADS + threadIdx.x) * 4;
-            uint32_t kk[4];
-            int cntk = 0;
-            if (i + 3 < n) {
-                const uint4 k4 = *reinterpret_cast<const uint4*>(keys + i);
-                kk[0] = k4.x;
-                kk[1] = k4.y;
-                kk[2] = k4.z;
-                kk[3] = k4.w;
-                cntk = 4;
-            } else {
-                for (int j = 0; j < 4; j++)
-                    if (i + j < n) kk[cntk++] = keys[i + j];
+        for (int r = 0; r < 4; r++) {
+            const long long q = q0 + (long long)r * gridDim.x * HS_THREADS;
+            const long long i = q * 4;
+            cnt4[r] = 0;
+            k4[r] = make_uint4(0u, 0u, 0u, 0u);
+            if (q < quads) {
+                if (i + 3 < n) {
+                    k4[r] = *reinterpret_cast<const uint4*>(keys + i);
+                    cnt4[r] = 4;
+                } else {
+                    k4[r].x = keys[i];
+                    cnt4[r] = 1;
+                    if (i + 1 < n) { k4[r].y = keys[i + 1]; cnt4[r] = 2; }
+                    if (i + 2 < n) { k4[r].z = keys[i + 2]; cnt4[r] = 3; }
+                }
             }
-            for (int j = 0; j < cntk; j++) {
-                const uint32_t k = kk[j];
-                atomicAdd(&h[0][k & 255u], 1u);
-                atomicAdd(&h[1][(k >> 8) & 255u], 1u);
-                atomicAdd(&h[2][(k >> 16) & 255u], 1u);
-                atomicAdd(&h[3][k >> 24], 1u);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t kk[4] = { k4[r].x, k4[r].y, k4[r].z, k4[r].w };
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (j < cnt4[r]) {
+                    const uint32_t k = kk[j];
+                    atomicAdd(&h[0][k & 255u], 1u);
+                    atomicAdd(&h[1][(k >> 8) & 255u], 1u);
+                    atomicAdd(&h[2][(k >> 16) & 255u], 1u);
+                    atomicAdd(&h[3][k >> 24], 1u);
+                }
             }
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 4; p++) partial[(size_t)blockIdx.x * 1024 + p * 256 + threadIdx.x] = h[p][threadIdx.x];
+    partial[(size_t)blockIdx.x * 1024 + threadIdx.x] = h[threadIdx.x >> 8][threadIdx.x & 255];
 }
 
 // bases[p][d] = number of keys whose digit p is < d.  One block of 1024 threads per pass: four
@@ -161,9 +170,12 @@ __device__ __forceinline__ void tile_load(TileRegs& t, const uint32_t* __restric
     }
 }
 
-// Persistent blocks; tiles are taken by atomic ticket (a tile only ever waits for tiles that
-// already run), TWO tickets ahead, and the next tile's loads are issued before the current tile
-// is ranked, so the ticket and HBM latencies are off the critical path.
+// Persistent blocks; tiles are taken by atomic ticket (a tile only ever waits for tiles that already run -- two sorts
+// of two streams can share the chip, so a static tile order could dead-lock their look-backs).  ONE ticket per block
+// at the start (the ticket word is hot: 8 ns per atomic, and a launch of a few hundred tiles -- the broad phase's size --
+// starts with every block queueing there; two tickets per block up front also left half of such a launch's blocks
+// without a tile while the others did two).  The ticket of the next tile is requested at the top of a tile and used
+// after its ranking: the next tile's loads are then in flight during the look-back, the staging and the writes.
 __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restrict__ keys_in,
                                                         const uint32_t* __restrict__ vals_in,
                                                         uint32_t* __restrict__ keys_out,
@@ -182,12 +194,9 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restri
     uint32_t* wk = s_keys + w * RS_WAVE_SPAN;
     uint32_t* wv = s_vals + w * RS_WAVE_SPAN;
 
-    if (threadIdx.x == 0) {
-        s_tk[0] = atomicAdd(ticket, 1u);
-        s_tk[1] = atomicAdd(ticket, 1u);
-    }
+    if (threadIdx.x == 0) s_tk[0] = atomicAdd(ticket, 1u);
     __syncthreads();
-    uint32_t t0 = s_tk[0], t1 = s_tk[1];
+    uint32_t t0 = s_tk[0];
     TileRegs pre;
     if ((int)t0 < num_tiles) tile_load(pre, keys_in, vals_in, (long long)t0 * RS_TILE + (long long)w * RS_WAVE_SPAN, lane, n);
 
@@ -207,10 +216,9 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restri
             wtot[k][threadIdx.x] = 0;
             wrun[k][threadIdx.x] = 0;
         }
-        // request the ticket after next, start the next tile's loads
-        uint32_t t2_req = 0;
-        if (threadIdx.x == 0) t2_req = atomicAdd(ticket, 1u);
-        if ((int)t1 < num_tiles) tile_load(pre, keys_in, vals_in, (long long)t1 * RS_TILE + (long long)w * RS_WAVE_SPAN, lane, n);
+        // request the next ticket
+        uint32_t t1_req = 0;
+        if (threadIdx.x == 0) t1_req = atomicAdd(ticket, 1u);
         wave_lds_fence();
         uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
         bool valid[RS_ITEMS];
@@ -252,7 +260,11 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restri
         } else {
             wave_rank_rows(key, valid, shift, wrun[w], rank);
         }
+        if (threadIdx.x == 0) s_tk[1] = t1_req;
         __syncthreads(); // dig_gbase scratch consumed before it is overwritten below
+        // the next tile's loads (consumed at the top of the next round)
+        const uint32_t t1 = s_tk[1];
+        if ((int)t1 < num_tiles) tile_load(pre, keys_in, vals_in, (long long)t1 * RS_TILE + (long long)w * RS_WAVE_SPAN, lane, n);
         // 3. decoupled look-back, thread d = digit d, eight predecessor tiles probed per round
         {
             const int d = threadIdx.x;
@@ -277,7 +289,6 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restri
             }
             __hip_atomic_store(my, (excl + cnt) | OS_FLAG_PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             dig_gbase[d] = bases[d] + excl;
-            if (d == 0) s_tk[0] = t2_req;
         }
         // 4. stage the tile in LDS in sorted order (the striped copies were consumed before step 1)
 #pragma unroll
@@ -302,10 +313,8 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restri
                 vals_out[dst] = s_vals[i];
             }
         }
-        const uint32_t t2 = s_tk[0];
         __syncthreads(); // LDS tile buffers and s_tk free for the next tile
         t0 = t1;
-        t1 = t2;
     }
 }
 
@@ -413,7 +422,7 @@ bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
     // later passes see permuted keys; ticket streams without a global order can deadlock the look-back; and a
     // ticket worth two consecutive tiles serialises it -- the second tile publishes its count only after the
     // first is finished, so every predecessor chain runs at one tile time per link: 70x slower.)
-    const int hist_blocks = std::min(num_tiles, c->num_cus);
+    const int hist_blocks = (int)std::min<long long>((n + 4 * HS_THREADS - 1) / (4 * HS_THREADS), c->num_cus); // (>= one 16-byte load per thread)
     const int dbg = std::getenv("SCCD_SORT_DBG") ? std::atoi(std::getenv("SCCD_SORT_DBG")) : 0; // timing ablations only
     const size_t status_bytes = (size_t)passes * num_tiles * 256 * sizeof(uint32_t);
     const size_t off_status = 512, off_bases = off_status + status_bytes, off_partial = off_bases + 4096;
@@ -424,8 +433,8 @@ bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
     uint32_t* partial = reinterpret_cast<uint32_t*>(base + off_partial);
     uint32_t* status = reinterpret_cast<uint32_t*>(base + off_status);
     // every polled word (tickets and status, contiguous) is zeroed by os_hist_k before the passes
-    hipLaunchKernelGGL(os_hist_k, dim3(hist_blocks), dim3(RS_THREADS), 0, c->stream, k_in, (long long)n, num_tiles,
-                       partial, reinterpret_cast<uint4*>(base), (long long)((512 + status_bytes) / 16));
+    hipLaunchKernelGGL(os_hist_k, dim3(hist_blocks), dim3(HS_THREADS), 0, c->stream, k_in, (long long)n, partial,
+                       reinterpret_cast<uint4*>(base), (long long)((512 + status_bytes) / 16));
     hipLaunchKernelGGL(os_bases_k, dim3(4), dim3(1024), 0, c->stream, partial, hist_blocks, bases);
     for (int pass = 0; pass < passes; pass++) {
         static const int pass_blocks = std::getenv("SCCD_SORT_BLOCKS") ? std::atoi(std::getenv("SCCD_SORT_BLOCKS")) : 3;
