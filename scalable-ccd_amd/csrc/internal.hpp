@@ -162,7 +162,7 @@ struct NarrowCounters {
     unsigned long long steals;       // sub-domains moved between lanes
     unsigned long long stamp[8];     // SCCD_NP_DIAG=2: shader cycles per loop section, summed over waves
     unsigned long long max_wave_steps, waves_run; // longest wave (the kernel's critical path), waves that got work
-    unsigned long long pops_reg, pops_mem; // pops served by the register top / by the HBM stack
+    unsigned long long pops_reg, checked_ahead; // pops of deferred halves; nodes checked ahead by idle lanes in the tail
     unsigned long long wave_hist[16];      // waves by number of check steps, buckets of 16 (last: >= 240)
     unsigned long long xcd_steps[8], xcd_waves[8]; // check steps and waves per XCD (HW_REG_XCC_ID)
     unsigned long long tail_steps, max_tail_steps, max_tail_cycles, max_total_cycles, sum_tail_cycles; // after the wave's stream ran dry

@@ -396,10 +396,10 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
         SCCD_HIP(hipStreamSynchronize(c->stream));
     }
     if (std::getenv("SCCD_NP_DIAG") && h.wave_steps)
-        std::fprintf(stderr, "[sccd np] n=%lld checks=%llu wave_steps=%llu (waves %llu, mean %.1f, longest %llu) lane_util=%.3f refill_execs=%llu steals=%llu pops reg/mem=%llu/%llu\n",
+        std::fprintf(stderr, "[sccd np] n=%lld checks=%llu wave_steps=%llu (waves %llu, mean %.1f, longest %llu) lane_util=%.3f refill_execs=%llu steals=%llu pops=%llu checked ahead=%llu\n",
                      n, h.n_checks, h.wave_steps, h.waves_run, (double)h.wave_steps / (double)std::max<unsigned long long>(1, h.waves_run),
                      h.max_wave_steps, (double)h.lane_steps / (64.0 * (double)h.wave_steps), h.refill_execs, h.steals,
-                     h.pops_reg, h.pops_mem);
+                     h.pops_reg, h.checked_ahead);
     if (std::getenv("SCCD_NP_DIAG") && h.wave_steps)
         std::fprintf(stderr, "[sccd np] tail (after a wave's query stream ran dry): %llu of %llu wave-steps, longest %llu steps / %.0f of %.0f kcycles; mean tail %.0f kcycles\n",
                      h.tail_steps, h.wave_steps, h.max_tail_steps, h.max_tail_cycles / 1e3, h.max_total_cycles / 1e3,

@@ -762,6 +762,20 @@ __device__ __forceinline__ unsigned nw_tol_levels(const double tol[3], bool inv_
     }
     return r;
 }
+// split_dimension :200-211 by the reciprocal shortcut (exact: see ti_inv_tol_ok; inexact ones never get here)
+__device__ __forceinline__ int nw_split_of(const NWQuery& q, const double w[3])
+{
+    const double r0 = w[0] * q.inv_tol[0], r1 = w[1] * q.inv_tol[1], r2 = w[2] * q.inv_tol[2];
+    if (r0 >= r1 && r0 >= r2) return 0;
+    if (r1 >= r0 && r1 >= r2) return 1;
+    return 2;
+}
+// the same from the packed levels of a domain entry alone (the dimension a node is split in depends on its depth only)
+__device__ __forceinline__ int nw_split_dim(const NWQuery& q, unsigned d)
+{
+    const double w[3] = { ldexp(1.0, -(int)(d & 255u)), ldexp(1.0, -(int)((d >> 8) & 255u)), ldexp(1.0, -(int)((d >> 16) & 255u)) };
+    return nw_split_of(q, w);
+}
 template <bool VF, int ARITH>
 __device__ __forceinline__ NQStep nw_step(const NWQuery& q, const NQDom& dm, double ms, double co_domain_tol,
                                           bool allow_zero_toi, double prune_toi)
@@ -790,12 +804,7 @@ __device__ __forceinline__ NQStep nw_step(const NWQuery& q, const NQDom& dm, dou
         r.accept = true;
         return r;
     }
-    // split_dimension :200-211 by the reciprocal shortcut (exact: see ti_inv_tol_ok; inexact ones never get here)
-    const double r0 = w[0] * q.inv_tol[0], r1 = w[1] * q.inv_tol[1], r2 = w[2] * q.inv_tol[2];
-    int split;
-    if (r0 >= r1 && r0 >= r2) split = 0;
-    else if (r1 >= r0 && r1 >= r2) split = 1;
-    else split = 2;
+    const int split = nw_split_of(q, w);
     r.split = split;
     r.nk = 1;
     const double slo = split == 0 ? lo[0] : (split == 1 ? lo[1] : lo[2]);
