@@ -1,0 +1,52 @@
+"""The hot kernels' register budgets, checked on the cross-compiled code (no GPU needed): np_walk_k runs three waves per SIMD
+only below 171 VGPRs and has no scalar registers to spare -- a change that tips it into scratch spills costs more than it can
+gain (and one such build hung the GPU in round 2), so the build is checked, not trusted."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only"]
+
+
+def _kernels(src, tmp_path):
+    out = tmp_path / (src + ".s")
+    subprocess.run([HIPCC, *FLAGS, os.path.join(ROOT, "scalable-ccd_amd", "csrc", src + ".hip"), "-o", str(out)],
+                   check=True, stderr=subprocess.DEVNULL, timeout=600)
+    text = out.read_text()
+    res = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
+        body = m.group(2)
+        res[m.group(1)] = {k: int(re.search(r"\.amdhsa_" + k + r" (\d+)", body).group(1))
+                           for k in ("private_segment_fixed_size", "next_free_vgpr", "next_free_sgpr", "group_segment_fixed_size")}
+    return res
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_walk_kernels_keep_three_waves_per_simd_without_scratch(tmp_path):
+    ks = _kernels("narrow", tmp_path)
+    plain = {k: v for k, v in ks.items() if re.match(r"_Z9np_walk_kILb[01]ELi[01]ELi0EE", k)}
+    assert len(plain) == 4  # VF / EE x strict / fused arithmetic
+    for name, r in plain.items():
+        assert r["private_segment_fixed_size"] == 0, (name, r)
+        assert r["next_free_vgpr"] <= 168, (name, r)  # 512 / 3 waves, allocation granule 8
+        assert r["group_segment_fixed_size"] <= 26 * 1024, (name, r)  # six two-wave blocks per CU
+    # the bookkeeping kernels (two waves per SIMD) must not spill either
+    book = {k: v for k, v in ks.items() if re.match(r"_Z9np_walk_kILb[01]ELi[01]ELi1EE", k)}
+    for name, r in book.items():
+        assert r["private_segment_fixed_size"] == 0 and r["next_free_vgpr"] <= 256, (name, r)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_sort_and_sweep_kernels_do_not_spill(tmp_path):
+    for src in ("sort", "sweep"):
+        for name, r in _kernels(src, tmp_path).items():
+            # (sweep_stq_k keeps a handful of per-launch constants in scratch: stored in the prologue, reloaded once per
+            # tile, nothing in its filter / confirm loops -- 128 VGPRs is what gives it four blocks per CU)
+            allowed = 32 if "sweep_stq_k" in name else 0
+            assert r["private_segment_fixed_size"] <= allowed, (name, r)
+            if "sweep_stq_k" in name:
+                assert r["next_free_vgpr"] <= 128, (name, r)
