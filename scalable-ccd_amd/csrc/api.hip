@@ -1322,6 +1322,15 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
             if (sccd_create(c->device, &c->side) != SCCD_OK) throw SccdError { SCCD_E_NOMEM, "ccd: cannot create the helper context" };
             SCCD_HIP(hipEventCreateWithFlags(&c->side_event, hipEventDisableTiming));
             pl->bp_ee.ctx = c->side;
+            // SCCD_HELPER_PRIORITY=low|high: the helper's stream with the lowest / highest queue priority (measurements)
+            if (const char* pe = std::getenv("SCCD_HELPER_PRIORITY")) {
+                int least = 0, greatest = 0;
+                SCCD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                hipStream_t s = nullptr;
+                SCCD_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, std::string(pe) == "high" ? greatest : least));
+                SCCD_HIP(hipStreamDestroy(c->side->stream));
+                c->side->stream = s;
+            }
         }
         sccd_ctx* const sc = c->side;
         sc->sort_axis = c->sort_axis;

@@ -148,7 +148,7 @@ struct NarrowCounters {
     // queued behind every wave's TOI polls and cost tens of microseconds each.
     unsigned long long toi_bits; // running minimum (non-negative double as u64): polled + atomicMin
     unsigned long long pad0[15];
-    unsigned long long ticket;   // query chunk ticket
+    unsigned long long ticket;   // (unused: np_walk_k's chunk tickets are checks_part[].ticket)
     unsigned long long pad1[15];
     unsigned long long n_checks; // inclusion-function evaluations (one atomicAdd per wave)
     unsigned int overflow;
@@ -168,8 +168,11 @@ struct NarrowCounters {
     unsigned long long tail_steps, max_tail_steps, max_tail_cycles, max_total_cycles, sum_tail_cycles; // after the wave's stream ran dry
     // check counts, striped over eight 128-byte lines: every wave adds its count when it ends, and they
     // all end together -- 2048 atomics on one word were a 20 us tail on every launch
+    // (the same lines hold np_walk_k's chunk tickets, one per sub-list of the query list: hot during the launch, when
+    // the check counts are not touched)
     struct alignas(128) Stripe {
         unsigned long long n;
+        unsigned long long ticket;
     } checks_part[8];
 };
 static_assert(sizeof(NarrowCounters) <= 2048, "NarrowCounters must fit its slot of the scalars block");
