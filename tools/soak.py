@@ -143,7 +143,7 @@ def main():
             # (the level-synchronous kernel keeps every live domain of a level in HBM, like the reference's
             # ring buffer: scenes with thousands of touching queries can exhaust any memory -- reported, not a crash)
             print("ERROR", tag, "--", e, flush=True)
-            if narrow_algo == 1 and "out of memory" in str(e):
+            if narrow_algo == 1 and ("out of memory" in str(e) or "memory budget" in str(e)):
                 continue
         finally:
             ctx.set_option(sccd.OPT_SHARD_COUNT, 1)
