@@ -700,6 +700,26 @@ def test_sort_is_a_stable_permutation(sccd, ctx):
         want_k, want_v = torch.sort(keys, stable=True)
         assert torch.equal(k.cpu().to(torch.int64), want_k)
         assert torch.equal(v.cpu().to(torch.int64), want_v)
+    # digit distributions that stress the ranking: one key only (every lane of a row on the same counter), two keys,
+    # keys already sorted, keys that differ in one digit only, and a multi-tile list with a ragged end
+    n = 3_000_017
+    g = torch.Generator().manual_seed(5)
+    cases = {
+        "one key": torch.full((n,), 0x12345678, dtype=torch.int64),
+        "two keys": torch.randint(0, 2, (n,), generator=g, dtype=torch.int64) * 0x01010101,
+        "sorted": torch.arange(n, dtype=torch.int64) * 5,
+        "top digit only": torch.randint(0, 128, (n,), generator=g, dtype=torch.int64) << 24,
+        "few keys in the middle digit": torch.randint(0, 3, (n,), generator=g, dtype=torch.int64) << 8,
+    }
+    for name, keys in cases.items():
+        k = keys.to(torch.int32).cuda()
+        v = torch.arange(n, dtype=torch.int32).cuda()
+        torch.cuda.synchronize()
+        ctx.sort_pairs_u32(k.data_ptr(), v.data_ptr(), n)
+        ctx.synchronize()
+        want_k, want_v = torch.sort(keys, stable=True)
+        assert torch.equal(k.cpu().to(torch.int64), want_k), name
+        assert torch.equal(v.cpu().to(torch.int64), want_v), name
 
 
 # ---- BASELINE.json full size (configs[3]/[4]): 708 x 708 folded cloth, 999,698 triangles ---------
