@@ -48,15 +48,14 @@ struct TIQuery {
 //   fl(w_k / tol_k) == w_k * fl(1 / tol_k)      (no overflow/underflow)
 // so the three divisions per check become three multiplications by per-query constants, with
 // the same bits.  Guard: every reciprocal is 0, +inf or within [2^-500, 2^500].
+__device__ __forceinline__ bool ti_inv_tol_ok_one(double inv_tol_k)
+{
+    const double a = fabs(inv_tol_k);
+    return a == 0.0 || a == __builtin_huge_val() || (a >= 0x1p-500 && a <= 0x1p500);
+}
 __device__ __forceinline__ bool ti_inv_tol_ok(const double inv_tol[3])
 {
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const double a = fabs(inv_tol[k]);
-        ok = ok && (a == 0.0 || a == __builtin_huge_val() || (a >= 0x1p-500 && a <= 0x1p500));
-    }
-    return ok;
+    return ti_inv_tol_ok_one(inv_tol[0]) && ti_inv_tol_ok_one(inv_tol[1]) && ti_inv_tol_ok_one(inv_tol[2]);
 }
 __device__ __forceinline__ void ti_prepare_inv_tol(TIQuery& q)
 {
@@ -749,17 +748,19 @@ struct NWQuery {
     double inv_tol[3];
     unsigned dlev; // D_t | D_u << 8 | D_v << 16 | (inexact reciprocal) << 24
 };
+__device__ __forceinline__ unsigned nw_tol_level_of(double tol_k) // one dimension's level (8 bits)
+{
+    const int be = (int)(((unsigned long long)__double_as_longlong(tol_k) >> 52) & 0x7FFull); // (tolerances are >= 0)
+    int D = 1023 - be; // -floor(log2 tol) for a normal number; subnormal or zero: 1023 (never reached)
+    D = D < 0 ? 0 : (D > 255 ? 255 : D);
+    if (tol_k != tol_k) D = 255;
+    return (unsigned)D;
+}
 __device__ __forceinline__ unsigned nw_tol_levels(const double tol[3], bool inv_ok)
 {
     unsigned r = inv_ok ? 0u : 1u << 24;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int be = (int)(((unsigned long long)__double_as_longlong(tol[k]) >> 52) & 0x7FFull); // (tolerances are >= 0)
-        int D = 1023 - be; // -floor(log2 tol) for a normal number; subnormal or zero: 1023 (never reached)
-        D = D < 0 ? 0 : (D > 255 ? 255 : D);
-        if (tol[k] != tol[k]) D = 255;
-        r |= (unsigned)D << (8 * k);
-    }
+    for (int k = 0; k < 3; k++) r |= nw_tol_level_of(tol[k]) << (8 * k);
     return r;
 }
 // split_dimension :200-211 by the reciprocal shortcut (exact: see ti_inv_tol_ok; inexact ones never get here)
