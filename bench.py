@@ -154,7 +154,10 @@ def main():
         for _ in range(n_prof):
             step()
         prof_all = ctx.profile()
-        dom = max(prof_all, key=lambda k: prof_all[k][0])
+        # the dominant KERNEL: the class with the longest launch.  (By class totals the three sweeps of a step -- one of them
+        # running throttled beside the vertex-face narrow kernel, for the sake of the overlap -- can add up to more than the one
+        # edge-edge narrow launch they overlap with, and the choice would flip from run to run.)
+        dom = max(prof_all, key=lambda k: prof_all[k][0] / max(1, prof_all[k][1]))
         class_id = {"boxes": 0, "sort": 1, "ranges": 2, "sweep": 3, "narrow_vf": 4, "narrow_ee": 5}  # SCCD_PROF_*
         ctx.set_option(sccd.OPT_PROFILE, (1 << class_id[dom]) << 1)
         ctx.reset_profile()
