@@ -726,10 +726,18 @@ __device__ __forceinline__ bool ti_inclusion_mm(const double v[8][3], const doub
     true_tol = ti_max(0.0, wdt); // :183
     box_in = true;
     bool out = false, notin = false;
+    if (ms == 0) { // (x - 0 and x + 0 are x up to the sign of a zero, which no comparison sees: twelve additions fewer per check)
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        out = out || (cmin[k] - ms > err[k]) || (cmax[k] + ms < -err[k]);   // :187-190
-        notin = notin || (cmin[k] + ms < -err[k]) || (cmax[k] - ms > err[k]); // :192-195
+        for (int k = 0; k < 3; k++) {
+            out = out || (cmin[k] > err[k]) || (cmax[k] < -err[k]);
+            notin = notin || (cmin[k] < -err[k]) || (cmax[k] > err[k]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            out = out || (cmin[k] - ms > err[k]) || (cmax[k] + ms < -err[k]);   // :187-190
+            notin = notin || (cmin[k] + ms < -err[k]) || (cmax[k] - ms > err[k]); // :192-195
+        }
     }
     if (out) return false;
     box_in = !notin;
@@ -777,6 +785,14 @@ __device__ __forceinline__ int nw_split_dim(const NWQuery& q, unsigned d)
     const double w[3] = { ldexp(1.0, -(int)(d & 255u)), ldexp(1.0, -(int)((d >> 8) & 255u)), ldexp(1.0, -(int)((d >> 16) & 255u)) };
     return nw_split_of(q, w);
 }
+// nq_bounds with one conversion: hi = (k + 1) 2^-d = lo + w exactly (k + 1 <= 2^31, a multiple of 2^-d below 2^53 of them)
+__device__ __forceinline__ void nw_bounds(unsigned k, unsigned d, double& lo, double& hi, double& w)
+{
+    const int e = -(int)d;
+    lo = ldexp((double)k, e);
+    w = ldexp(1.0, e);
+    hi = lo + w;
+}
 template <bool VF, int ARITH>
 __device__ __forceinline__ NQStep nw_step(const NWQuery& q, const NQDom& dm, double ms, double co_domain_tol,
                                           bool allow_zero_toi, double prune_toi)
@@ -788,9 +804,9 @@ __device__ __forceinline__ NQStep nw_step(const NWQuery& q, const NQDom& dm, dou
     r.split = 0;
     double lo[3], hi[3], w[3];
     const unsigned d0 = dm.d & 255u, d1 = (dm.d >> 8) & 255u, d2 = (dm.d >> 16) & 255u;
-    nq_bounds(dm.k0, d0, lo[0], hi[0], w[0]);
-    nq_bounds(dm.k1, d1, lo[1], hi[1], w[1]);
-    nq_bounds(dm.k2, d2, lo[2], hi[2], w[2]);
+    nw_bounds(dm.k0, d0, lo[0], hi[0], w[0]);
+    nw_bounds(dm.k1, d1, lo[1], hi[1], w[1]);
+    nw_bounds(dm.k2, d2, lo[2], hi[2], w[2]);
     const double min_t = lo[0];
     r.min_t = min_t;
     if (min_t >= prune_toi) return r; // :295
