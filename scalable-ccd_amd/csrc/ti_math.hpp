@@ -724,24 +724,24 @@ __device__ __forceinline__ bool ti_inclusion_mm(const double v[8][3], const doub
     wdt = ti_max(wdt, cmax[1] - cmin[1]);
     wdt = ti_max(wdt, cmax[2] - cmin[2]);
     true_tol = ti_max(0.0, wdt); // :183
-    box_in = true;
+    // (no short-circuits: every lane of the wave runs the check in lockstep, so a skipped comparison saves nothing and
+    // the branches around it cost scalar instructions)
     bool out = false, notin = false;
     if (ms == 0) { // (x - 0 and x + 0 are x up to the sign of a zero, which no comparison sees: twelve additions fewer per check)
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            out = out || (cmin[k] > err[k]) || (cmax[k] < -err[k]);
-            notin = notin || (cmin[k] < -err[k]) || (cmax[k] > err[k]);
+            out = out | (cmin[k] > err[k]) | (cmax[k] < -err[k]);
+            notin = notin | (cmin[k] < -err[k]) | (cmax[k] > err[k]);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            out = out || (cmin[k] - ms > err[k]) || (cmax[k] + ms < -err[k]);   // :187-190
-            notin = notin || (cmin[k] + ms < -err[k]) || (cmax[k] - ms > err[k]); // :192-195
+            out = out | (cmin[k] - ms > err[k]) | (cmax[k] + ms < -err[k]);   // :187-190
+            notin = notin | (cmin[k] + ms < -err[k]) | (cmax[k] - ms > err[k]); // :192-195
         }
     }
-    if (out) return false;
     box_in = !notin;
-    return true;
+    return !out;
 }
 
 // ---- np_walk_k's query and step ---------------------------------------------------------------------------------
@@ -809,30 +809,31 @@ __device__ __forceinline__ NQStep nw_step(const NWQuery& q, const NQDom& dm, dou
     nw_bounds(dm.k2, d2, lo[2], hi[2], w[2]);
     const double min_t = lo[0];
     r.min_t = min_t;
-    if (min_t >= prune_toi) return r; // :295
+    // (straight-line on purpose: the lanes of a wave run this in lockstep; the reference's early exits are the masks below)
+    const bool live = !(min_t >= prune_toi); // :295
     double true_tol;
     bool box_in;
-    r.checked = true;
-    if (!ti_inclusion_mm<VF, ARITH>(q.v, lo, hi, q.err, ms, true_tol, box_in)) return r;
-    const bool zero_ok = allow_zero_toi || min_t > 0;
-    const bool c1 = d0 >= (q.dlev & 255u) && d1 >= ((q.dlev >> 8) & 255u) && d2 >= ((q.dlev >> 16) & 255u); // Condition 1 :322
-    if (c1 || (box_in && zero_ok)                        // Condition 2 :331
-        || (true_tol <= co_domain_tol && zero_ok)) {     // Condition 3 :340
-        r.accept = true;
-        return r;
-    }
+    const bool in = ti_inclusion_mm<VF, ARITH>(q.v, lo, hi, q.err, ms, true_tol, box_in);
+    const bool zero_ok = allow_zero_toi | (min_t > 0);
+    const bool c1 = (d0 >= (q.dlev & 255u)) & (d1 >= ((q.dlev >> 8) & 255u)) & (d2 >= ((q.dlev >> 16) & 255u)); // Condition 1 :322
+    const bool acc = c1 | (box_in & zero_ok)              // Condition 2 :331
+        | ((true_tol <= co_domain_tol) & zero_ok);        // Condition 3 :340
+    r.checked = live;
+    r.accept = live & in & acc;
+    const bool splits = live & in & !acc;
     const int split = nw_split_of(q, w);
     r.split = split;
-    r.nk = 1;
     const double slo = split == 0 ? lo[0] : (split == 1 ? lo[1] : lo[2]);
     const double sw = split == 0 ? w[0] : (split == 1 ? w[1] : w[2]);
     const double mid = slo + 0.5 * sw; // = (lo + hi) / 2, exact
     bool second;
-    if (split == 0) second = mid <= prune_toi; // :229-232
-    else if (VF) {
+    if (VF) {
         const double other = (split == 1) ? lo[2] : lo[1];
-        second = (mid + other) <= 1 / (1 - TI_DBL_EPS); // sum_less_than_one :21-29
-    } else second = true; // :248-250
-    if (second) r.nk = 2;
+        second = split == 0 ? (mid <= prune_toi)                              // :229-232
+                            : ((mid + other) <= 1 / (1 - TI_DBL_EPS));        // sum_less_than_one :21-29
+    } else {
+        second = split == 0 ? (mid <= prune_toi) : true; // :248-250
+    }
+    r.nk = splits ? (second ? 2 : 1) : 0;
     return r;
 }
