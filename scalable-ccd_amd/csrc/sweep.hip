@@ -201,11 +201,12 @@ __device__ __forceinline__ ExactBox load_exact(const sccd_aabb* __restrict__ b)
 // AABB::intersects (aabb.cuh:68-73) && !share_a_vertex (collision.cuh:17-21)
 __device__ __forceinline__ bool exact_pair_ok(const ExactBox& a, const ExactBox& b)
 {
-    const bool geo = a.hi[0] >= b.lo[0] && a.lo[0] <= b.hi[0] && a.hi[1] >= b.lo[1] && a.lo[1] <= b.hi[1]
-        && a.hi[2] >= b.lo[2] && a.lo[2] <= b.hi[2];
-    const bool share = a.v[0] == b.v[0] || a.v[0] == b.v[1] || a.v[0] == b.v[2] || a.v[1] == b.v[0]
-        || a.v[1] == b.v[1] || a.v[1] == b.v[2] || a.v[2] == b.v[0] || a.v[2] == b.v[1] || a.v[2] == b.v[2];
-    return geo && !share;
+    // (no short-circuits: a wave confirms 64 candidates in lockstep, a skipped comparison saves nothing)
+    const bool geo = (a.hi[0] >= b.lo[0]) & (a.lo[0] <= b.hi[0]) & (a.hi[1] >= b.lo[1]) & (a.lo[1] <= b.hi[1])
+        & (a.hi[2] >= b.lo[2]) & (a.lo[2] <= b.hi[2]);
+    const bool share = (a.v[0] == b.v[0]) | (a.v[0] == b.v[1]) | (a.v[0] == b.v[2]) | (a.v[1] == b.v[0])
+        | (a.v[1] == b.v[1]) | (a.v[1] == b.v[2]) | (a.v[2] == b.v[0]) | (a.v[2] == b.v[1]) | (a.v[2] == b.v[2]);
+    return geo & !share;
 }
 // output convention: sweep.cu:152-163 / sort_and_sweep.cpp:106-118
 __device__ __forceinline__ int2 make_pair_out(int emit, int row_eid, int col_eid)
@@ -286,10 +287,9 @@ __device__ __forceinline__ bool owns_pair(const GridParams& g, uint32_t row_key,
 {
     if (g.n_cells <= 1) return true;
     const int cell = (int)((unsigned long long)row_key >> g.xb);
-    const int ca = cell / g.Sb, cb = cell - ca * g.Sb;
     const int ma = max(grid_cell_a(g, sel3(a.lo, g.aa)), grid_cell_a(g, sel3(b.lo, g.aa)));
     const int mb = max(grid_cell_b(g, sel3(a.lo, g.ab)), grid_cell_b(g, sel3(b.lo, g.ab)));
-    return ma == ca && mb == cb;
+    return ma * g.Sb + mb == cell; // (= the row's cell (ca, cb): 0 <= mb < Sb, so the two coordinates need no division to compare)
 }
 
 __device__ __forceinline__ void confirm(bool active, uint2 cand, const sccd_aabb* __restrict__ box_r,
@@ -301,7 +301,7 @@ __device__ __forceinline__ void confirm(bool active, uint2 cand, const sccd_aabb
     if (active) {
         const ExactBox a = load_exact(box_r + cand.x);
         const ExactBox b = load_exact(box_c + cand.y);
-        ok = exact_pair_ok(a, b) && owns_pair(g, key_r[cand.x], a, b);
+        ok = (int)exact_pair_ok(a, b) & (int)owns_pair(g, key_r[cand.x], a, b);
         pr = make_pair_out(emit, a.eid, b.eid);
     }
     em.push(ok, pr);
