@@ -292,8 +292,12 @@ __device__ __forceinline__ bool owns_pair(const GridParams& g, uint32_t row_key,
     return ma * g.Sb + mb == cell; // (= the row's cell (ca, cb): 0 <= mb < Sb, so the two coordinates need no division to compare)
 }
 
+// low_r / low_c: the lowest cells of the boxes per minor axis as entry_gather_k stored them (the values owns_pair would
+// compute again from the exact boxes: twenty FP64 instructions per candidate against two 4-byte loads of lines that the
+// filter stage has just touched)
 __device__ __forceinline__ void confirm(bool active, uint2 cand, const sccd_aabb* __restrict__ box_r,
-                                        const uint32_t* __restrict__ key_r, const sccd_aabb* __restrict__ box_c,
+                                        const uint32_t* __restrict__ key_r, const uint32_t* __restrict__ low_r,
+                                        const sccd_aabb* __restrict__ box_c, const uint32_t* __restrict__ low_c,
                                         const GridParams& g, int emit, Emitter& em)
 {
     bool ok = false;
@@ -301,7 +305,11 @@ __device__ __forceinline__ void confirm(bool active, uint2 cand, const sccd_aabb
     if (active) {
         const ExactBox a = load_exact(box_r + cand.x);
         const ExactBox b = load_exact(box_c + cand.y);
-        ok = (int)exact_pair_ok(a, b) & (int)owns_pair(g, key_r[cand.x], a, b);
+        const uint32_t la = low_r[cand.x], lb = low_c[cand.y];
+        const int cell = (int)((unsigned long long)key_r[cand.x] >> g.xb);
+        const int ma = (int)max(la & 0xFFFFu, lb & 0xFFFFu), mb = (int)max(la >> 16, lb >> 16);
+        const bool owner = (g.n_cells <= 1) | (ma * g.Sb + mb == cell); // owns_pair on the stored cells
+        ok = (int)exact_pair_ok(a, b) & (int)owner;
         pr = make_pair_out(emit, a.eid, b.eid);
     }
     em.push(ok, pr);
@@ -309,9 +317,9 @@ __device__ __forceinline__ void confirm(bool active, uint2 cand, const sccd_aabb
 
 __global__ __launch_bounds__(SW_THREADS, 4) void sweep_stq_k(
     const float4* __restrict__ filt_r, const sccd_aabb* __restrict__ box_r, const uint32_t* __restrict__ key_r,
-    const uint2* __restrict__ ranges, int row_begin, int row_end, const float4* __restrict__ filt_c,
-    const sccd_aabb* __restrict__ box_c, const GridParams* __restrict__ gp, int emit, int2* __restrict__ out,
-    long long capacity, SweepCounters* __restrict__ cnt)
+    const uint32_t* __restrict__ low_r, const uint2* __restrict__ ranges, int row_begin, int row_end,
+    const float4* __restrict__ filt_c, const sccd_aabb* __restrict__ box_c, const uint32_t* __restrict__ low_c,
+    const GridParams* __restrict__ gp, int emit, int2* __restrict__ out, long long capacity, SweepCounters* __restrict__ cnt)
 {
     const GridParams g = *gp;
     __shared__ uint2 q_s[SW_WAVES][SW_QCAP];
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(SW_THREADS, 4) void sweep_stq_k(
                         wave_lds_fence();
                         const uint2 cand = q[qcount - 64 + lane];
                         qcount -= 64;
-                        confirm(true, cand, box_r, key_r, box_c, g, emit, em);
+                        confirm(true, cand, box_r, key_r, low_r, box_c, low_c, g, emit, em);
                     }
                     if (has) {
                         const int b = __ffs((int)m) - 1;
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(SW_THREADS, 4) void sweep_stq_k(
                 wave_lds_fence();
                 const uint2 cand = q[qcount - 64 + lane];
                 qcount -= 64;
-                confirm(true, cand, box_r, key_r, box_c, g, emit, em);
+                confirm(true, cand, box_r, key_r, low_r, box_c, low_c, g, emit, em);
             }
         }
     }
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(SW_THREADS, 4) void sweep_stq_k(
         wave_lds_fence();
         const bool act = lane < qcount;
         const uint2 cand = act ? q[lane] : make_uint2(0u, 0u);
-        confirm(act, cand, box_r, key_r, box_c, g, emit, em);
+        confirm(act, cand, box_r, key_r, low_r, box_c, low_c, g, emit, em);
     }
     wave_lds_fence();
     em.flush_block(reinterpret_cast<unsigned long long*>(&q_s[0][0])); // (the candidate queues are empty now)
@@ -557,9 +565,9 @@ void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, c
         const int grid = std::max(1, std::min((num_tiles + SW_WAVES - 1) / SW_WAVES,
                                               c->num_cus * (c->sweep_blocks_per_cu > 0 ? c->sweep_blocks_per_cu : per_cu)));
         hipLaunchKernelGGL(sweep_stq_k, dim3(grid), dim3(SW_THREADS), 0, c->stream, rows->filt.as<float4>(),
-                           rows->box.as<sccd_aabb>(), rows->key.as<uint32_t>(), ranges, row_begin, row_end,
-                           cols->filt.as<float4>(), cols->box.as<sccd_aabb>(), gp, emit, out, (long long)capacity,
-                           d_cnt);
+                           rows->box.as<sccd_aabb>(), rows->key.as<uint32_t>(), rows->lowcell.as<uint32_t>(), ranges, row_begin,
+                           row_end, cols->filt.as<float4>(), cols->box.as<sccd_aabb>(), cols->lowcell.as<uint32_t>(), gp, emit,
+                           out, (long long)capacity, d_cnt);
     }
     SCCD_HIP(hipGetLastError());
 }
