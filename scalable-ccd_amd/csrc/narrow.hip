@@ -386,15 +386,16 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
     NarrowCounters h;
     const long long n = p.n_pairs;
     {
+        // (a launch that kept its running TOI in another launch's word: that word is its result so far -- read in the same
+        // round trip; a second, blocking copy here was 25 us at the end of every ccd() step)
+        unsigned long long toi_elsewhere = 0;
         ReadBack rb(c);
         rb.add(&h, d_cnt, sizeof h);
+        if (p.toi_word) rb.add(&toi_elsewhere, p.toi_word, 8);
         rb.sync();
+        if (p.toi_word) h.toi_bits = toi_elsewhere;
     }
     for (int k = 0; k < 8; k++) h.n_checks += h.checks_part[k].n; // (the work-queue kernel counts in stripes)
-    if (p.toi_word) { // this launch kept its running TOI in another launch's word: that is its result so far
-        SCCD_HIP(hipMemcpyAsync(&h.toi_bits, p.toi_word, 8, hipMemcpyDeviceToHost, c->stream));
-        SCCD_HIP(hipStreamSynchronize(c->stream));
-    }
     if (std::getenv("SCCD_NP_DIAG") && h.wave_steps)
         std::fprintf(stderr, "[sccd np] n=%lld checks=%llu wave_steps=%llu (waves %llu, mean %.1f, longest %llu) lane_util=%.3f refill_execs=%llu steals=%llu pops=%llu checked ahead=%llu\n",
                      n, h.n_checks, h.wave_steps, h.waves_run, (double)h.wave_steps / (double)std::max<unsigned long long>(1, h.waves_run),
