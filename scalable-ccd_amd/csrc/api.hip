@@ -691,7 +691,8 @@ static void list_finish(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, 
 // does in the DeviceAABBs constructor (aabb.cu:75-111): the lists are sorted HERE because the
 // cell grid is derived from both lists of the build.
 // Both lists of a two-list build in one sort: list B's entries (their keys carry the tag bit, the top bit of the
-// sorted key) are copied behind list A's, the pairs are sorted once, and the result is list A followed by list B.
+// sorted key) sit in list A's buffers among list A's (the fill placed both by one cursor), the pairs are sorted once, and
+// the result is list A followed by list B.
 // list A keeps the merged key array (its first total_a entries); list B gets its keys back without the tag from the
 // gather.  Lists that were filled by the one-pass append only (entries already in key / idx).
 static void lists_finish_merged(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B, const GridParams* gp, uint32_t total_a,
@@ -712,8 +713,6 @@ static void lists_finish_merged(sccd_ctx* c, const sccd_boxes* A, const sccd_box
     }
     {
         ProfScope ps(c, SCCD_PROF_SORT);
-        SCCD_HIP(hipMemcpyAsync(LA->key.as<uint32_t>() + ma, LB->key.p, sizeof(uint32_t) * mb, hipMemcpyDeviceToDevice, c->stream));
-        SCCD_HIP(hipMemcpyAsync(LA->idx.as<uint32_t>() + ma, LB->idx.p, sizeof(uint32_t) * mb, hipMemcpyDeviceToDevice, c->stream));
         c->sort_tmp_keys.ensure(sizeof(uint32_t) * (m + pad));
         c->sort_tmp_vals.ensure(sizeof(uint32_t) * (m + pad));
         if (radix_sort_pairs_u32(c, LA->key.as<uint32_t>(), LA->idx.as<uint32_t>(), (int64_t)m, key_bits)) {
@@ -757,6 +756,7 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     struct GridReadBack {
         GridParams gp;
         uint32_t total[2];
+        uint32_t place; // (device only: the shared placement cursor of a merged two-list fill)
     };
     uint32_t* d_total = reinterpret_cast<uint32_t*>(bp->grid.as<char>() + 512 + offsetof(GridReadBack, total));
     static_assert(512 + sizeof(GridReadBack) <= 4096, "grid buffer layout");
@@ -847,19 +847,28 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
             for (int fill_round = 0;; fill_round++) {
                 SCCD_REQUIRE(cap < (1ull << 31), "broad phase: too many cell entries");
                 const size_t pad = 64;
-                if (fill_round > 0) SCCD_HIP(hipMemsetAsync(d_total, 0, 2 * sizeof(uint32_t), c->stream)); // (grid_setup_k zeroed them for round 0)
+                if (fill_round > 0) SCCD_HIP(hipMemsetAsync(d_total, 0, 3 * sizeof(uint32_t), c->stream)); // (grid_setup_k zeroed them for round 0)
                 {
                     ProfScope ps(c, SCCD_PROF_BOXES);
                     // (merged sort: list A's buffers also take list B's entries behind its own)
                     bp->la.key.ensure(sizeof(uint32_t) * ((want_merged ? 2 : 1) * (size_t)cap + pad));
                     bp->la.idx.ensure(sizeof(uint32_t) * ((want_merged ? 2 : 1) * (size_t)cap + pad));
+                    // (merged sort: both lists fill list A's buffers, placed by ONE shared cursor -- their entries mix, the sort
+                    // separates them by the tag bit; copying list B's entries behind list A's afterwards cost two launches
+                    // of the build's latency chain)
+                    uint32_t* const d_place = want_merged ? d_total + 2 : nullptr;
                     launch_cell_fill_append(c, A->raw.as<sccd_aabb>(), A->n, gp, bp->cell_lo, bp->cell_hi, d_total,
-                                            (uint32_t)cap, bp->la.key.as<uint32_t>(), bp->la.idx.as<uint32_t>());
+                                            (uint32_t)((want_merged ? 2 : 1) * cap), bp->la.key.as<uint32_t>(), bp->la.idx.as<uint32_t>(),
+                                            false, d_place);
                     if (B) {
                         bp->lb.key.ensure(sizeof(uint32_t) * ((size_t)cap + pad));
                         bp->lb.idx.ensure(sizeof(uint32_t) * ((size_t)cap + pad));
-                        launch_cell_fill_append(c, B->raw.as<sccd_aabb>(), B->n, gp, bp->cell_lo, bp->cell_hi, d_total + 1,
-                                                (uint32_t)cap, bp->lb.key.as<uint32_t>(), bp->lb.idx.as<uint32_t>(), want_merged);
+                        if (want_merged)
+                            launch_cell_fill_append(c, B->raw.as<sccd_aabb>(), B->n, gp, bp->cell_lo, bp->cell_hi, d_total + 1,
+                                                    (uint32_t)(2 * cap), bp->la.key.as<uint32_t>(), bp->la.idx.as<uint32_t>(), true, d_place);
+                        else
+                            launch_cell_fill_append(c, B->raw.as<sccd_aabb>(), B->n, gp, bp->cell_lo, bp->cell_hi, d_total + 1,
+                                                    (uint32_t)cap, bp->lb.key.as<uint32_t>(), bp->lb.idx.as<uint32_t>(), false);
                     }
                 }
                 {
@@ -875,8 +884,10 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                 auto over = [&](uint32_t t, int n) { return (int64_t)t > std::max<int64_t>(3 * (int64_t)n, (int64_t)n + 4096); };
                 if (over(total[0], A->n) || (B && over(total[1], B->n))) continue;
             }
-            if (want_merged && total[0] > 0 && total[1] > 0) {
-                lists_finish_merged(c, A, B, gp, total[0], total[1], hgp.key_bits, &bp->la, &bp->lb);
+            if (want_merged) {
+                // (a side without entries in this rank's cells: no pair can come of it -- sort_and_sweep.cpp:221-223)
+                if (total[0] > 0 && total[1] > 0) lists_finish_merged(c, A, B, gp, total[0], total[1], hgp.key_bits, &bp->la, &bp->lb);
+                else bp->la.m = bp->lb.m = 0;
             } else {
                 list_finish(c, A, gp, bp->cell_lo, bp->cell_hi, total[0], hgp.key_bits, &bp->la, true);
                 if (B) list_finish(c, B, gp, bp->cell_lo, bp->cell_hi, total[1], hgp.key_bits, &bp->lb, true);

@@ -244,7 +244,7 @@ __global__ void grid_setup_k(const GridStats* __restrict__ st_a, const double* _
                              uint32_t* __restrict__ cursors /* the two list cursors of the fill pass: zeroed here */,
                              int max_cells, int reserve_tag)
 {
-    if (threadIdx.x < 2) cursors[threadIdx.x] = 0u;
+    if (threadIdx.x < 3) cursors[threadIdx.x] = 0u; // the two list totals and the placement cursor of a merged two-list fill
     // summed extents: lane l adds the block partials l, l + 64, ... of list A, then of list B, in
     // that order, then a fixed shuffle tree -- the same bits on every run and every rank (one wave)
     double sumext[3], glo[3], ghi[3];
@@ -429,9 +429,12 @@ __global__ void cell_hist_k(const sccd_aabb* __restrict__ raw, int n, const Grid
 // order the waves arrive in -- the radix sort that follows is stable, so only the order of EQUAL
 // keys (and with it the order, not the set, of the emitted pairs) varies.  Entries beyond
 // `capacity` are counted but not written (the host grows the buffers and runs the pass again).
+// place != nullptr: the entries go where a SHARED cursor says (both lists of a merged two-list sort fill one buffer, in any
+// order: the sort that follows separates them by the tag bit) while `cursor` only counts this list's entries.
 __global__ void cell_fill_append_k(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp,
                                    int cell_lo, int cell_hi, uint32_t* __restrict__ cursor, uint32_t capacity,
-                                   uint32_t* __restrict__ key, uint32_t* __restrict__ idx, int tagged)
+                                   uint32_t* __restrict__ key, uint32_t* __restrict__ idx, int tagged,
+                                   uint32_t* __restrict__ place)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const GridParams g = *gp;
@@ -460,7 +463,8 @@ __global__ void cell_fill_append_k(const sccd_aabb* __restrict__ raw, int n, con
             wave_base[k] = sum;
             sum += wave_tot[k];
         }
-        const uint32_t b0 = sum ? atomicAdd(cursor, sum) : 0u;
+        uint32_t b0 = sum ? atomicAdd(cursor, sum) : 0u;
+        if (place && sum) b0 = atomicAdd(place, sum);
         for (int k = 0; k < (int)(blockDim.x >> 6); k++) wave_base[k] += b0;
     }
     __syncthreads();
@@ -620,11 +624,11 @@ void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams
     SCCD_HIP(hipGetLastError());
 }
 void launch_cell_fill_append(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
-                             uint32_t* cursor, uint32_t capacity, uint32_t* key, uint32_t* idx, bool tagged)
+                             uint32_t* cursor, uint32_t capacity, uint32_t* key, uint32_t* idx, bool tagged, uint32_t* place)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(cell_fill_append_k, dim3((n + 1023) / 1024), dim3(1024), 0, c->stream, raw, n, g, cell_lo, cell_hi,
-                       cursor, capacity, key, idx, tagged ? 1 : 0);
+                       cursor, capacity, key, idx, tagged ? 1 : 0, place);
     SCCD_HIP(hipGetLastError());
 }
 void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,

@@ -89,7 +89,8 @@ void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a,
                        GridParams* g, uint32_t* cursors, bool reserve_tag = false);
 void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int stride, uint32_t* hist);
 void launch_cell_fill_append(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
-                             uint32_t* cursor, uint32_t capacity, uint32_t* key, uint32_t* idx, bool tagged = false);
+                             uint32_t* cursor, uint32_t capacity, uint32_t* key, uint32_t* idx, bool tagged = false,
+                             uint32_t* place = nullptr);
 void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
                        uint32_t* counts);
 void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
