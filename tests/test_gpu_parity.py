@@ -469,6 +469,33 @@ def test_narrow_phase_known_answers(sccd, ctx):
     assert sccd.narrow_phase(mesh, [[0, 0]], True) == 1.0
 
 
+def test_narrow_lists_around_the_deal_boundaries(sccd, ctx, orc):
+    """np_walk_k deals a list in batches of 21 queries, as one list (fewer than 32 batches or fewer than eight blocks)
+    or as eight interleaved sub-lists of segments of 2^k batches with the rest on sub-list 0: list lengths on and around
+    every one of those boundaries, each against the oracle, each with per-query output (every query must be checked
+    exactly once: a query dealt twice or not at all shows in the collision records)."""
+    V0, V1, E, F = _scene("cloth_ball_10k")
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F)
+    ee, _, _ = orc.sort_and_sweep(eb, nthreads=8)
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    lengths = set()
+    for nb in (1, 2, 31, 32, 33, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025):  # batches
+        for d in (-1, 0, 1):
+            lengths.add(21 * nb + d)
+    lengths |= {1, 20, 22, 41, 43, 21 * 8 * 32 * 4 + 5, len(ee)}
+    for n in sorted(x for x in lengths if 0 < x <= len(ee)):
+        pairs = ee[:n]
+        want = orc.narrow_phase_mt(V0, V1, E, F, pairs, False, nthreads=8)[0]
+        assert sccd.narrow_phase(mesh, pairs, False) == want, n
+    for n in (21 * 32 - 1, 21 * 32, 21 * 256 + 1, min(len(ee), 21 * 1024 + 22)):
+        pairs = ee[:n]
+        _, want_pq, _ = orc.narrow_phase(V0, V1, E, F, pairs, False, per_query=True)
+        _, col = sccd.narrow_phase(mesh, pairs, False, want_collisions=True)
+        hits = want_pq < 1
+        assert len(col) == int(hits.sum()), n
+        assert np.array_equal(col["toi"], want_pq[hits]), n
+
+
 @pytest.mark.parametrize("algo", [0, 1])  # work-queue kernel (per-lane bound, atomicMin per query), level order
 @pytest.mark.parametrize("is_vf", [True, False])
 def test_per_query_collisions(sccd, ctx, orc, algo, is_vf):
