@@ -33,7 +33,7 @@ def test_walk_kernels_keep_three_waves_per_simd_without_scratch(tmp_path):
     for name, r in plain.items():
         assert r["private_segment_fixed_size"] == 0, (name, r)
         assert r["next_free_vgpr"] <= 168, (name, r)  # 512 / 3 waves, allocation granule 8
-        assert r["group_segment_fixed_size"] <= 26 * 1024, (name, r)  # six two-wave blocks per CU
+        assert r["group_segment_fixed_size"] <= 13 * 1024, (name, r)  # twelve one-wave blocks per CU
     # the bookkeeping kernels (two waves per SIMD) must not spill either
     book = {k: v for k, v in ks.items() if re.match(r"_Z9np_walk_kILb[01]ELi[01]ELi1EE", k)}
     for name, r in book.items():
