@@ -496,6 +496,7 @@ static void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline*
         b.have_stats = false;
     };
     pl->vb.n = m->nV;
+    pl->vb.kind = BOX_VERTEX;
     pl->vb.raw.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nV, 1));
     begin_stats(pl->vb);
     pl->vb.n_part = launch_vertex_boxes(c, m->V.as<double>(), m->nV, r, pl->vb.raw.as<sccd_aabb>(), pl->vb.stats_head(),
@@ -503,6 +504,7 @@ static void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline*
     pl->vb.have_stats = true;
     if (want_e) {
         pl->eb.n = m->nE;
+        pl->eb.kind = BOX_EDGE;
         pl->eb.raw.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nE, 1));
         begin_stats(pl->eb);
         pl->eb.n_part = launch_edge_boxes(c, pl->vb.raw.as<sccd_aabb>(), m->E.as<int2>(), m->nE,
@@ -511,6 +513,7 @@ static void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline*
     }
     if (want_f) {
         pl->fb.n = m->nF;
+        pl->fb.kind = BOX_FACE;
         pl->fb.raw.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nF, 1));
         begin_stats(pl->fb);
         pl->fb.n_part = launch_face_boxes(c, pl->vb.raw.as<sccd_aabb>(), m->F.as<int4>(), m->nF,
@@ -533,6 +536,7 @@ static sccd_boxes* clone_boxes(sccd_ctx* c, const sccd_boxes& s)
     std::unique_ptr<sccd_boxes> b(new sccd_boxes());
     b->ctx = c;
     b->n = s.n;
+    b->kind = s.kind; // (device-resident, opaque: the caller cannot have changed the ids)
     b->raw.ensure(sizeof(sccd_aabb) * (size_t)std::max(s.n, 1));
     copy_in(c, b->raw.p, s.raw.p, sizeof(sccd_aabb) * (size_t)s.n, 1);
     return b.release();
@@ -644,25 +648,21 @@ static void list_count(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, i
         exclusive_scan_u32(c, counts, counts, n, d_total);
     }
 }
-// `filled`: key / idx already hold the entries (the one-pass append of the sharded build)
-static void list_finish(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, int cell_lo, int cell_hi, uint32_t total,
-                        int key_bits, SortedList* L, bool filled = false)
+// `filled`: key / idx already hold the entries (the one-pass append of the sharded build).  Sorts the list's (key, box
+// index) pairs; the records follow once BOTH lists of a build are sorted (a row's first column is looked up among the
+// other list's keys).
+static void list_sort(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, int cell_lo, int cell_hi, uint32_t total,
+                      int key_bits, SortedList* L, bool filled = false)
 {
     const int n = b->n;
     L->m = 0;
     if (n == 0 || total == 0) return; // (no box of this list touches the rank's cells)
     SCCD_REQUIRE(total < (1u << 31), "broad phase: too many cell entries");
-    const size_t m = total, pad = 64; // the sweep streams whole 32-column blocks
+    const size_t m = total, pad = SCCD_LIST_PAD;
     L->m = (int)m;
     if (!filled) {
         L->key.ensure(sizeof(uint32_t) * (m + pad));
         L->idx.ensure(sizeof(uint32_t) * (m + pad));
-    }
-    L->kmax.ensure(sizeof(uint32_t) * (m + pad));
-    L->filt.ensure(sizeof(float4) * (m + pad));
-    L->box.ensure(sizeof(sccd_aabb) * (m + 8));
-    L->lowcell.ensure(sizeof(uint32_t) * (m + pad));
-    if (!filled) {
         ProfScope ps(c, SCCD_PROF_BOXES);
         launch_cell_fill(c, b->raw.as<sccd_aabb>(), n, gp, cell_lo, cell_hi, L->offsets.as<uint32_t>(),
                          L->key.as<uint32_t>(), L->idx.as<uint32_t>());
@@ -679,12 +679,22 @@ static void list_finish(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, 
             std::swap(L->idx.cap, c->sort_tmp_vals.cap);
         }
     }
-    {
-        ProfScope ps(c, SCCD_PROF_BOXES);
-        launch_entry_gather(c, b->raw.as<sccd_aabb>(), L->key.as<uint32_t>(), L->idx.as<uint32_t>(), (int)m, gp,
-                            L->box.as<sccd_aabb>(), L->filt.as<float4>(), L->kmax.as<uint32_t>(),
-                            L->lowcell.as<uint32_t>());
+}
+// the sorted records of the lists of a build whose (key, index) pairs are sorted, each list in its own arrays
+static void lists_records(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B, const GridParams* gp, SortedList* LA,
+                          SortedList* LB)
+{
+    ProfScope ps(c, SCCD_PROF_BOXES);
+    if (!B) {
+        launch_entry_records(c, A->raw.as<sccd_aabb>(), LA->key.as<uint32_t>(), LA->idx.as<uint32_t>(), LA->m, gp, 0, nullptr,
+                             0, false, false, LA);
+        return;
     }
+    if (LA->m == 0 || LB->m == 0) return;
+    launch_entry_records(c, A->raw.as<sccd_aabb>(), LA->key.as<uint32_t>(), LA->idx.as<uint32_t>(), LA->m, gp, 1,
+                         LB->key.as<uint32_t>(), LB->m, false, false, LA);
+    launch_entry_records(c, B->raw.as<sccd_aabb>(), LB->key.as<uint32_t>(), LB->idx.as<uint32_t>(), LB->m, gp, 2,
+                         LA->key.as<uint32_t>(), LA->m, false, false, LB);
 }
 
 // BroadPhase::build (broad_phase.cu:29-101) together with the key split + sort the reference
@@ -698,19 +708,12 @@ static void list_finish(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, 
 static void lists_finish_merged(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B, const GridParams* gp, uint32_t total_a,
                                 uint32_t total_b, int key_bits, SortedList* LA, SortedList* LB)
 {
-    const size_t ma = total_a, mb = total_b, m = ma + mb, pad = 64;
+    const size_t ma = total_a, mb = total_b, m = ma + mb, pad = SCCD_LIST_PAD;
     SCCD_REQUIRE(m < (1u << 31), "broad phase: too many cell entries");
     LA->m = (int)ma;
     LB->m = (int)mb;
     SCCD_REQUIRE(LA->key.cap >= sizeof(uint32_t) * (m + pad) && LA->idx.cap >= sizeof(uint32_t) * (m + pad),
                  "broad phase: merged list buffers too small");
-    for (SortedList* L : { LA, LB }) {
-        const size_t k = (size_t)L->m;
-        L->kmax.ensure(sizeof(uint32_t) * (k + pad));
-        L->filt.ensure(sizeof(float4) * (k + pad));
-        L->box.ensure(sizeof(sccd_aabb) * (k + 8));
-        L->lowcell.ensure(sizeof(uint32_t) * (k + pad));
-    }
     {
         ProfScope ps(c, SCCD_PROF_SORT);
         c->sort_tmp_keys.ensure(sizeof(uint32_t) * (m + pad));
@@ -723,13 +726,13 @@ static void lists_finish_merged(sccd_ctx* c, const sccd_boxes* A, const sccd_box
         }
     }
     {
+        // the sorted pairs: list A's (keys as they are), then list B's (keys with the tag).  Each list's rows look their
+        // first column up among the other list's keys, tag and all.
         ProfScope ps(c, SCCD_PROF_BOXES);
-        launch_entry_gather(c, A->raw.as<sccd_aabb>(), LA->key.as<uint32_t>(), LA->idx.as<uint32_t>(), (int)ma, gp,
-                            LA->box.as<sccd_aabb>(), LA->filt.as<float4>(), LA->kmax.as<uint32_t>(),
-                            LA->lowcell.as<uint32_t>());
-        launch_entry_gather(c, B->raw.as<sccd_aabb>(), LA->key.as<uint32_t>() + ma, LA->idx.as<uint32_t>() + ma, (int)mb, gp,
-                            LB->box.as<sccd_aabb>(), LB->filt.as<float4>(), LB->kmax.as<uint32_t>(),
-                            LB->lowcell.as<uint32_t>(), LB->key.as<uint32_t>());
+        const uint32_t* keys = LA->key.as<uint32_t>();
+        const uint32_t* idx = LA->idx.as<uint32_t>();
+        launch_entry_records(c, A->raw.as<sccd_aabb>(), keys, idx, (int)ma, gp, 1, keys + ma, (int)mb, false, true, LA);
+        launch_entry_records(c, B->raw.as<sccd_aabb>(), keys + ma, idx + ma, (int)mb, gp, 2, keys, (int)ma, true, false, LB);
     }
 }
 
@@ -740,11 +743,13 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     bp->A = A;
     bp->B = B;
     bp->built = true;
-    bp->ranges_done = false;
     bp->cursor = 0;
     bp->n_overlaps = 0;
     bp->candidates = 0;
+    bp->candidates_done = 0;
     bp->la.m = bp->lb.m = 0;
+    bp->la.kind = A->kind;
+    bp->lb.kind = B ? B->kind : BOX_UNKNOWN;
     bp->total_rows = 0;
     // two lists with an empty side produce nothing (sort_and_sweep.cpp:221-223)
     if (A->n == 0 || (B && B->n == 0)) return;
@@ -889,8 +894,9 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                 if (total[0] > 0 && total[1] > 0) lists_finish_merged(c, A, B, gp, total[0], total[1], hgp.key_bits, &bp->la, &bp->lb);
                 else bp->la.m = bp->lb.m = 0;
             } else {
-                list_finish(c, A, gp, bp->cell_lo, bp->cell_hi, total[0], hgp.key_bits, &bp->la, true);
-                if (B) list_finish(c, B, gp, bp->cell_lo, bp->cell_hi, total[1], hgp.key_bits, &bp->lb, true);
+                list_sort(c, A, gp, bp->cell_lo, bp->cell_hi, total[0], hgp.key_bits, &bp->la, true);
+                if (B) list_sort(c, B, gp, bp->cell_lo, bp->cell_hi, total[1], hgp.key_bits, &bp->lb, true);
+                lists_records(c, A, B, gp, &bp->la, &bp->lb);
             }
             break;
         }
@@ -906,8 +912,9 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
         const bool windowed = bp->cell_lo > 0 || bp->cell_hi < (1 << 30);
         auto over = [&](uint32_t t, int n) { return (int64_t)t > std::max<int64_t>(3 * (int64_t)n, (int64_t)n + 4096); };
         if (can_shrink && !windowed && (over(total[0], A->n) || (B && over(total[1], B->n)))) continue;
-        list_finish(c, A, gp, bp->cell_lo, bp->cell_hi, total[0], hgp.key_bits, &bp->la);
-        if (B) list_finish(c, B, gp, bp->cell_lo, bp->cell_hi, total[1], hgp.key_bits, &bp->lb);
+        list_sort(c, A, gp, bp->cell_lo, bp->cell_hi, total[0], hgp.key_bits, &bp->la);
+        if (B) list_sort(c, B, gp, bp->cell_lo, bp->cell_hi, total[1], hgp.key_bits, &bp->lb);
+        lists_records(c, A, B, gp, &bp->la, &bp->lb);
         break;
     }
     if (B && (bp->la.m == 0 || bp->lb.m == 0)) bp->la.m = bp->lb.m = 0; // nothing to pair in this window
@@ -967,30 +974,8 @@ static void bp_detect_partial(sccd_broad_phase* bp, int phase = 0)
     int64_t chunk_hi = std::min(bp->cursor + cutoff, bp->total_rows);
 
     SweepCounters* d_cnt = c->scalars.as<SweepCounters>();
-    unsigned long long* d_cand = d_cnt->cand_parts;
-
-    // ranges are (re)computed on the first chunk of a build (phase 3: that and nothing else)
-    if (bp->cursor == 0 && phase != 2 && !bp->ranges_done) {
-        SCCD_HIP(hipMemsetAsync(d_cnt, 0, sizeof(SweepCounters), c->stream));
-        ProfScope ps(c, SCCD_PROF_RANGES);
-        bp->ranges_a.ensure(sizeof(uint2) * (size_t)std::max(A->m, 1));
-        if (!B) {
-            launch_ranges(c, A, A, 0, bp->ranges_a.as<uint2>(), d_cand);
-        } else {
-            bp->ranges_b.ensure(sizeof(uint2) * (size_t)std::max(B->m, 1));
-            launch_ranges(c, A, B, 1, bp->ranges_a.as<uint2>(), d_cand);
-            launch_ranges(c, B, A, 2, bp->ranges_b.as<uint2>(), d_cand);
-        }
-    }
-
-    if (phase == 3) {
-        bp->ranges_done = true;
-        return;
-    }
-    bp->ranges_done = false; // (consumed: the next build computes its own)
-    // SCCD_OPT_SWEEP_ALGO: 0/2 filter-queue-confirm STQ (default: measured faster on every workload
-    // once its tiles are dealt without tickets), 1 plain SAP cross-check, 3 direct exact sweep.
-    const bool direct = c->sweep_algo == 3;
+    if (phase == 3) return; // (round 2 computed candidate ranges ahead of the sweep here; the sweep finds a row's columns itself now)
+    // SCCD_OPT_SWEEP_ALGO: 0 / 2 / 3 the band sweep (window staging -> skewed filter -> queue -> confirm), 1 plain SAP cross-check.
     // Capacity sizing (MemoryHandler, memory_handler.cpp:11-79): the overlap list may use half of
     // the memory limit (SCCD_OPT_MEMORY_LIMIT_MB / ccd()'s memory_limit_GB; default: whatever
     // hipMalloc grants).  A chunk whose pairs do not fit is re-swept over HALF its rows
@@ -1027,18 +1012,14 @@ static void bp_detect_partial(sccd_broad_phase* bp, int phase = 0)
         if (B) shard_rows(c, bp->row_shard, b_lo, b_hi, &b_lo, &b_hi);
 
         if (phase == 2 && attempt == 0) goto launched; // (phase 1 enqueued this attempt)
-        if (attempt > 0 || chunk_lo != 0) // (the first chunk's counters were just zeroed as a whole)
-            SCCD_HIP(hipMemsetAsync(&d_cnt->n_pairs, 0, sizeof(unsigned long long), c->stream));
+        SCCD_HIP(hipMemsetAsync(d_cnt, 0, sizeof(SweepCounters), c->stream)); // pairs and candidate tests of THIS attempt
         {
             ProfScope ps(c, SCCD_PROF_SWEEP);
             if (!B) {
-                launch_sweep(c, A, A, gp, bp->ranges_a.as<uint2>(), a_lo, a_hi, EMIT_ONE_LIST, bp->overlaps.as<int2>(),
-                             bp->capacity, d_cnt, direct);
+                launch_sweep(c, A, A, gp, a_lo, a_hi, EMIT_ONE_LIST, bp->overlaps.as<int2>(), bp->capacity, d_cnt);
             } else {
-                launch_sweep(c, A, B, gp, bp->ranges_a.as<uint2>(), a_lo, a_hi, EMIT_ROWS_A, bp->overlaps.as<int2>(),
-                             bp->capacity, d_cnt, direct);
-                launch_sweep(c, B, A, gp, bp->ranges_b.as<uint2>(), b_lo, b_hi, EMIT_ROWS_B, bp->overlaps.as<int2>(),
-                             bp->capacity, d_cnt, direct);
+                launch_sweep(c, A, B, gp, a_lo, a_hi, EMIT_ROWS_A, bp->overlaps.as<int2>(), bp->capacity, d_cnt);
+                launch_sweep(c, B, A, gp, b_lo, b_hi, EMIT_ROWS_B, bp->overlaps.as<int2>(), bp->capacity, d_cnt);
             }
         }
         if (phase == 1) return;
@@ -1052,7 +1033,11 @@ static void bp_detect_partial(sccd_broad_phase* bp, int phase = 0)
         {
             unsigned long long cs = 0;
             for (int k = 0; k < 32; k++) cs += h.cand_parts[k];
-            bp->candidates = (int64_t)cs;
+            bp->candidates = bp->candidates_done + (int64_t)cs; // (a chunk swept again after an overflow counts once)
+            static const bool diag = std::getenv("SCCD_SWEEP_DIAG") && std::atoi(std::getenv("SCCD_SWEEP_DIAG")) != 0;
+            if (diag)
+                std::fprintf(stderr, "[sweep] rows %lld pairs %llu tests %llu | filter blocks %llu groups %llu confirm rounds %llu segments staged %llu\n",
+                             (long long)(chunk_hi - chunk_lo), (unsigned long long)h.n_pairs, cs, h.diag[0], h.diag[1], h.diag[2], h.diag[3]);
         }
         if ((int64_t)h.n_pairs <= bp->capacity) {
             bp->n_overlaps = (int64_t)h.n_pairs;
@@ -1079,6 +1064,7 @@ static void bp_detect_partial(sccd_broad_phase* bp, int phase = 0)
             chunk_rows = (chunk_rows + 1) / 2;
         }
     }
+    bp->candidates_done = bp->candidates;
     bp->cursor = chunk_hi; // thread_start_box_id += MAX_OVERLAP_CUTOFF (broad_phase.cu:207)
 }
 

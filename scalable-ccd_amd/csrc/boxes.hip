@@ -9,6 +9,7 @@
 #include "internal.hpp"
 #include "ti_math_f32.hpp" // nextafter_up_f / nextafter_down_f of the float build
 #include "grid.hpp"
+#include "search.hpp"
 
 #include <algorithm>
 
@@ -160,6 +161,8 @@ __global__ void vertex_boxes_k(const double* __restrict__ V, int nV, double r, s
     }
     if (st) acc.finish(st, part);
 }
+
+__device__ __forceinline__ double sel3d(const double (&v)[3], int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
 
 struct BoxLoad {
     double lo[3], hi[3];
@@ -480,33 +483,62 @@ __global__ void cell_fill_append_k(const sccd_aabb* __restrict__ raw, int n, con
         }
 }
 
-// payload movement of thrust::sort_by_key (aabb.cu:107-109) as ONE gather after the index sort,
-// fused with the construction of the filter record and the max-key.
-__global__ void entry_gather_k(const sccd_aabb* __restrict__ raw, const uint32_t* __restrict__ key,
-                               const uint32_t* __restrict__ idx, int m, const GridParams* __restrict__ gp,
-                               sccd_aabb* __restrict__ sorted, float4* __restrict__ filt,
-                               uint32_t* __restrict__ kmax, uint32_t* __restrict__ lowcell,
-                               uint32_t* __restrict__ key_out /* list B of a merged sort: the keys without the tag */)
+// payload movement of thrust::sort_by_key (aabb.cu:107-109) as ONE gather after the index sort, fused with what
+// split_boxes derives per box (aabb.cu:40-72): the sorted 80-byte records of the sweep, five 16-byte pieces in five
+// arrays (internal.hpp).  MODE 1 / 2: this list is the row list A / B of a two-list sweep and `other` holds the sorted
+// keys of the column list; every row also gets its FIRST CANDIDATE COLUMN
+//     rows A: lower_bound(keys B, K(min_a))      -- the columns with K(min_a) <= K(min_b) <= K(max_a) start there
+//     rows B: upper_bound(keys A, K(min_b))      -- ... with K(min_b) <  K(min_a) <= K(max_b)
+// (the reference walks j = i + 1, ... of ONE merged list, sweep.cu:125-131; two lists swept as two classes never test
+// a vertex against a vertex or a face against a face).  A block's 1024 consecutive rows all start inside one window of
+// the column keys: two waves find its ends with 64 probes per round, every row then searches inside the window (a few
+// hundred keys in this CU's L1).  The sweep finds the END of a row's columns itself (the first key beyond K(max)).
+// own_tagged / other_tagged: this list's / the column list's keys carry the list tag of a merged sort (grid tag_bit).
+constexpr int ER_THREADS = 1024;
+template <int MODE>
+__global__ __launch_bounds__(ER_THREADS) void entry_record_k(const sccd_aabb* __restrict__ raw, const uint32_t* __restrict__ key,
+                                                             const uint32_t* __restrict__ idx, int m,
+                                                             const GridParams* __restrict__ gp, int own_tagged,
+                                                             const uint32_t* __restrict__ other, int n_other, int other_tagged,
+                                                             uint4* __restrict__ recs, uint32_t pstride)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= m) return;
+    const bool valid = e < m;
     const GridParams g = *gp;
-    const uint32_t k_e = key_out ? key[e] & ~(1u << g.tag_bit) : key[e];
-    if (key_out) key_out[e] = k_e;
+    const uint32_t tag = g.tag_bit >= 0 ? (1u << g.tag_bit) : 0u;
+    const uint32_t own_strip = own_tagged ? tag : 0u, other_or = other_tagged ? tag : 0u;
+    const uint32_t k_e = valid ? (key[e] & ~own_strip) : 0u;
+    uint32_t start = (uint32_t)e + 1u;
+    if (MODE != 0) {
+        __shared__ unsigned s_win[2];
+        const int w = threadIdx.x >> 6;
+        if (w < 2) { // wave 0: the window's lower end from the block's first key; wave 1: its upper end from the last one
+            const int e_first = blockIdx.x * blockDim.x, e_last = min(e_first + (int)blockDim.x, m) - 1;
+            const uint32_t v = (key[w == 0 ? e_first : e_last] & ~own_strip) | other_or;
+            const unsigned at = MODE == 1 ? wave_bound_u32<false>(other, (unsigned)n_other, v)
+                                          : wave_bound_u32<true>(other, (unsigned)n_other, v);
+            if (lane_id() == 0) s_win[w] = at;
+        }
+        __syncthreads();
+        const unsigned w0 = s_win[0], w1 = max(s_win[0], s_win[1]);
+        if (valid)
+            start = MODE == 1 ? lower_bound_in(other, w0, w1, k_e | other_or) : upper_bound_in(other, w0, w1, k_e | other_or);
+    }
+    if (!valid) return;
     const sccd_aabb* src = raw + idx[e];
     const double4 q0 = reinterpret_cast<const double4*>(src)[0];
-    const double4 q1 = reinterpret_cast<const double4*>(src)[1];
-    double4* dst = reinterpret_cast<double4*>(sorted + e);
-    dst[0] = q0;
-    dst[1] = q1;
+    const double2 q1 = reinterpret_cast<const double2*>(src)[2];
+    const int4 ids = reinterpret_cast<const int4*>(src)[3];
     const double lo[3] = { q0.x, q0.y, q0.z };
     const double hi[3] = { q0.w, q1.x, q1.y };
-    // outward rounding keeps the filter conservative: filt.min <= min, filt.max >= max
-    filt[e] = make_float4(__double2float_rd(lo[g.aa]), __double2float_ru(hi[g.aa]), __double2float_rd(lo[g.ab]),
-                          __double2float_ru(hi[g.ab]));
+    reinterpret_cast<double2*>(recs + (size_t)REC_X * pstride)[e] = make_double2(sel3d(lo, g.axis), sel3d(hi, g.axis));
+    reinterpret_cast<double2*>(recs + (size_t)REC_A * pstride)[e] = make_double2(sel3d(lo, g.aa), sel3d(hi, g.aa));
+    reinterpret_cast<double2*>(recs + (size_t)REC_B * pstride)[e] = make_double2(sel3d(lo, g.ab), sel3d(hi, g.ab));
+    reinterpret_cast<int4*>(recs + (size_t)REC_ID * pstride)[e] = ids;
     const uint32_t cellbits = (uint32_t)((((unsigned long long)k_e) >> g.xb) << g.xb);
-    kmax[e] = cellbits | grid_qx(g, hi[g.axis]);
-    lowcell[e] = (uint32_t)grid_cell_a(g, lo[g.aa]) | ((uint32_t)grid_cell_b(g, lo[g.ab]) << 16);
+    const uint32_t kmax = cellbits | grid_qx(g, sel3d(hi, g.axis));
+    const uint32_t lowcell = (uint32_t)grid_cell_a(g, sel3d(lo, g.aa)) | ((uint32_t)grid_cell_b(g, sel3d(lo, g.ab)) << 16);
+    recs[(size_t)REC_AUX * pstride + e] = make_uint4(k_e, kmax, lowcell, start);
 }
 
 // sum and sum of squares of the box centres per axis (sort_and_sweep.cpp:176-186): per-block
@@ -646,13 +678,23 @@ void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams
                        key, idx);
     SCCD_HIP(hipGetLastError());
 }
-void launch_entry_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,
-                         const GridParams* g, sccd_aabb* sorted, float4* filt, uint32_t* kmax, uint32_t* lowcell,
-                         uint32_t* key_out)
+void launch_entry_records(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,
+                          const GridParams* g, int mode, const uint32_t* other, int n_other, bool own_tagged,
+                          bool other_tagged, SortedList* out)
 {
     if (m == 0) return;
-    hipLaunchKernelGGL(entry_gather_k, dim3(grid_for(m)), dim3(TPB), 0, c->stream, raw, key, idx, m, g, sorted, filt,
-                       kmax, lowcell, key_out);
+    const size_t n = ((size_t)m + SCCD_LIST_PAD + 63) & ~(size_t)63;
+    SCCD_REQUIRE(5 * n < (1ull << 28), "broad phase: too many cell entries"); // (32-bit piece offsets in units of 16 bytes)
+    out->recs.ensure(sizeof(uint4) * 5 * n);
+    out->pstride = (uint32_t)n;
+    const dim3 grid((unsigned)((m + ER_THREADS - 1) / ER_THREADS)), block(ER_THREADS);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, block, 0, c->stream, raw, key, idx, m, g, own_tagged ? 1 : 0, other, n_other, other_tagged ? 1 : 0,
+                           out->recs.as<uint4>(), out->pstride);
+    };
+    if (mode == 0) go(entry_record_k<0>);
+    else if (mode == 1) go(entry_record_k<1>);
+    else go(entry_record_k<2>);
     SCCD_HIP(hipGetLastError());
 }
 

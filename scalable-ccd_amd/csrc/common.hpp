@@ -270,6 +270,45 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     return v;
 }
 
+// ---- wave reductions on the DPP path --------------------------------------------------------------
+// __shfl_xor / __shfl_up compile to ds_bpermute_b32: an LDS round trip (~150 cycles) per step, six dependent steps per
+// reduction.  The same reductions as six DPP moves inside the vector ALU (row_shr 1 / 2 / 4 / 8 inside each row of 16,
+// then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3): an INCLUSIVE SCAN over the 64 lanes, its last
+// lane the reduction.  Lanes that would read past their row keep `identity` (old operand, bound_ctrl off).
+// EVERY lane of the wave must be active.
+#define SCCD_DPP_STEP(OP, CTRL, ROWMASK) v = OP(v, (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROWMASK, 0xf, false))
+#define SCCD_DPP_SCAN(OP)            \
+    SCCD_DPP_STEP(OP, 0x111, 0xf);   \
+    SCCD_DPP_STEP(OP, 0x112, 0xf);   \
+    SCCD_DPP_STEP(OP, 0x114, 0xf);   \
+    SCCD_DPP_STEP(OP, 0x118, 0xf);   \
+    SCCD_DPP_STEP(OP, 0x142, 0xa);   \
+    SCCD_DPP_STEP(OP, 0x143, 0xc)
+__device__ __forceinline__ unsigned dpp_op_min(unsigned a, unsigned b) { return min(a, b); }
+__device__ __forceinline__ unsigned dpp_op_max(unsigned a, unsigned b) { return max(a, b); }
+__device__ __forceinline__ unsigned dpp_op_add(unsigned a, unsigned b) { return a + b; }
+// wave-uniform results (scalar registers)
+__device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v)
+{
+    const unsigned identity = 0xFFFFFFFFu;
+    SCCD_DPP_SCAN(dpp_op_min);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_max_u32_dpp(unsigned v)
+{
+    const unsigned identity = 0u;
+    SCCD_DPP_SCAN(dpp_op_max);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// inclusive prefix sum over the 64 lanes; *total (wave-uniform) = the sum
+__device__ __forceinline__ unsigned wave_incl_scan_dpp(unsigned v, unsigned* total)
+{
+    const unsigned identity = 0u;
+    SCCD_DPP_SCAN(dpp_op_add);
+    *total = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+    return v;
+}
+
 // ---- order-preserving 32-bit sort key of a double -------------------------------------------
 // K(x) = top 32 bits of the monotone u64 image of x (+0.0 canonicalises -0.0).  Monotone
 // non-decreasing: a <= b  =>  K(a) <= K(b).  The sweep only needs that (DESIGN.md "Sort key").

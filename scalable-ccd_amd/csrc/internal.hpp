@@ -12,12 +12,15 @@
 //            8-byte gathers per query, narrow_phase.cu:44-66)
 // mesh.E   : int2[nE], mesh.F : int4[nF] = {f0,f1,f2,0}   (row records instead of columns)
 //
-// boxes    : sorted along the sort axis by key32(min[axis])
-//   key    : uint32[n]  ascending                      (reference: Scalar2 sorted_major_intervals)
-//   kmax   : uint32[n]  key32(max[axis]) in the same order
-//   filt   : float4[n]  {a.min (rounded down), a.max (rounded up), b.min, b.max} of the two
-//            non-sort axes -- the 16-byte record the sweep's filter stage streams
-//   box    : sccd_aabb[n] exact 64-byte boxes in sorted order (confirm stage, download)
+// sweep list (SortedList): one ENTRY per (box, overlapped cell), sorted by the composite key of grid.hpp.
+//   An entry is an 80-byte record kept as five 16-byte pieces in five arrays (structure of arrays: the record
+//   builder's stores, the sweep's row loads and its window staging are all consecutive 16-byte accesses):
+//   ra   : double2[m] {min, max} on minor axis a           (reference: MiniBox min / max)
+//   rb   : double2[m] {min, max} on minor axis b
+//   rx   : double2[m] {min, max} on the sort axis         (reference: Scalar2 sorted_major_intervals)
+//   rid  : int4[m]    {vertex ids, element id}             (reference: MiniBox vertex_ids, element_id)
+//   raux : uint4[m]   {key, key of the max on the sort axis, lowest cell per minor axis (a | b << 16),
+//                      first candidate column (two-list sweeps; one list: row + 1)}
 struct sccd_mesh {
     sccd_ctx* ctx = nullptr;
     int nV = 0, nE = 0, nF = 0;
@@ -27,9 +30,12 @@ struct sccd_mesh {
 // DeviceAABBs: the boxes of one list, resident in HBM in element order.  The split into keys and
 // payload and the sort (aabb.cu:75-111 does them in the DeviceAABBs constructor) happen in
 // BroadPhase::build, where the cell grid of BOTH lists is known.
+// what is known about a list's vertex ids: boxes built HERE from a mesh carry the ids of aabb.cpp:57-58,107-109,128-130
+enum BoxKind { BOX_UNKNOWN = 0, BOX_VERTEX = 1 /* {i, -i-1, -i-1} */, BOX_EDGE = 2 /* {e0, e1, -e0-1} */, BOX_FACE = 3 /* {f0, f1, f2} */ };
 struct sccd_boxes {
     sccd_ctx* ctx = nullptr;
     int n = 0;
+    int kind = BOX_UNKNOWN; // (uploaded boxes: unknown)
     DevBuf raw; // sccd_aabb[n]
     // bounds + extent partials of the list ({GridStats, pad to 128 B, double[n_part][3]}): written by the
     // box builders themselves (fused) or, for uploaded boxes, by box_stats_k on first use
@@ -44,26 +50,37 @@ constexpr size_t SCCD_STATS_BYTES = 128 + sizeof(double) * 9 * SCCD_STATS_BLOCKS
 // one sweep list: an entry per (box, overlapped cell), sorted by the composite key of grid.hpp
 struct SortedList {
     int m = 0; // entries (>= number of boxes)
-    DevBuf key, kmax, filt, box, idx;
-    DevBuf lowcell; // uint32[m]: lowest cell of the entry's box on the two minor axes (a | b << 16)
+    int kind = BOX_UNKNOWN;    // of the boxes the entries were made from
+    DevBuf key, idx;           // the (key, box index) pairs the radix sort orders
+    DevBuf recs;               // the sorted records: five arrays of 16-byte pieces, `pstride` entries apart (see above)
+    uint32_t pstride = 0;
     DevBuf offsets; // uint32[n boxes]: first entry of each box (scanned cell counts), build scratch
 };
+// what the sweep kernels take: the five piece arrays of one list -- ONE allocation, piece p of entry e at
+// base[p * pstride + e], in the order the sweep stages them: ra, rb, rx, rid, raux (a wave-uniform base and a 32-bit
+// offset per lane address any piece: no 64-bit address arithmetic in the kernels)
+enum { REC_A = 0, REC_B = 1, REC_X = 2, REC_ID = 3, REC_AUX = 4 };
+struct SweepRecs {
+    const uint4* base;
+    uint32_t pstride;
+};
+inline SweepRecs sweep_recs(const SortedList* L) { return SweepRecs { L->recs.as<uint4>(), L->pstride }; }
+constexpr size_t SCCD_LIST_PAD = 64; // entries allocated past the last one: the sweep stages whole 32-column segments
 
 struct sccd_broad_phase {
     sccd_ctx* ctx = nullptr;
     const sccd_boxes* A = nullptr;
     const sccd_boxes* B = nullptr; // nullptr: one list
     bool built = false;
-    bool ranges_done = false; // bp_detect_partial(bp, 3) computed the candidate ranges ahead of the sweep
     int64_t cursor = 0;     // thread_start_box_id of broad_phase.cuh:86 (in sorted rows)
     int64_t total_rows = 0; // rows of all sweep classes
     SortedList la, lb;         // sorted entry lists of A and B
     DevBuf grid;               // GridStats + GridParams
-    DevBuf ranges_a, ranges_b; // uint2[m] (start,end) per row, per sweep class
     DevBuf overlaps;           // int2[capacity]
     int64_t capacity = 0;
     int64_t n_overlaps = 0;
-    int64_t candidates = 0;
+    int64_t candidates = 0;      // sort-axis candidate tests of the build so far (all chunks)
+    int64_t candidates_done = 0; // ... of the chunks before the current one
     int cell_lo = 0, cell_hi = 1 << 30; // this rank's window of cells (multi-GPU shard)
     bool row_shard = false;             // too few cells to shard by: split the rows instead
 };
@@ -95,9 +112,13 @@ void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParam
                        uint32_t* counts);
 void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
                       const uint32_t* offsets, uint32_t* key, uint32_t* idx);
-void launch_entry_gather(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,
-                         const GridParams* g, sccd_aabb* sorted, float4* filt, uint32_t* kmax, uint32_t* lowcell,
-                         uint32_t* key_out = nullptr);
+// the sorted records of one list from its sorted (key, box index) pairs.  mode 0: one list; 1 / 2: this list is the
+// row list A / B of a two-list sweep and `other` are the sorted keys of the column list (tagged like the merged sort left
+// them): every record also gets its first candidate column (sweep.hip: the three sweep classes)
+// own_tagged / other_tagged: this list's / the column list's keys carry the list tag of a merged sort
+void launch_entry_records(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,
+                          const GridParams* g, int mode, const uint32_t* other, int n_other, bool own_tagged,
+                          bool other_tagged, SortedList* out);
 
 // scan.hip
 void exclusive_scan_u32(sccd_ctx* c, const uint32_t* in, uint32_t* out, int n, uint32_t* d_total);
@@ -114,16 +135,14 @@ struct SweepCounters { // lives in device memory (ctx->scalars)
     unsigned long long candidates; // (host side: sum of cand_parts)
     unsigned int tile_ticket;      // (unused: tiles are dealt statically)
     unsigned int pad;
-    unsigned long long cand_parts[32]; // sum of (end-start) over the rows, spread to avoid one hot word
-    unsigned long long pad2[29];       // 512 bytes: hipMemsetAsync clears an aligned size with ONE fill kernel (280 B took two)
+    unsigned long long cand_parts[32]; // candidate columns tested (key range on the sort axis), summed over the rows; spread to avoid one hot word
+    unsigned long long diag[4];        // SCCD_SWEEP_DIAG=1: filter blocks, filter groups of 8 steps, confirm rounds, segments staged (summed over waves)
+    unsigned long long pad2[25];       // 512 bytes: hipMemsetAsync clears an aligned size with ONE fill kernel (280 B took two)
 };
 static_assert(sizeof(SweepCounters) == 512, "SweepCounters: keep the size a multiple of 256 bytes");
-// ranges for rows of `rows` against columns `cols` (see sweep.hip for the three modes)
-void launch_ranges(sccd_ctx* c, const SortedList* rows, const SortedList* cols, int mode, uint2* ranges,
-                   unsigned long long* d_candidates);
-void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, const GridParams* gp,
-                  const uint2* ranges, int row_begin, int row_end, int emit, int2* out, int64_t capacity,
-                  SweepCounters* d_cnt, bool direct);
+// rows [row_begin, row_end) of `rows` against the columns of `cols` (rows == cols: one list)
+void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, const GridParams* gp, int row_begin,
+                  int row_end, int emit, int2* out, int64_t capacity, SweepCounters* d_cnt);
 
 // narrow.hip
 struct NarrowParams {

@@ -1,4 +1,4 @@
-// sweep.hip -- candidate ranges + the sweep (STQ for wave64) that emits overlap pairs.
+// sweep.hip -- the sweep (STQ for wave64) that emits overlap pairs from the sorted records.
 //
 // Replaces sweep_and_tiniest_queue<> / sweep_and_prune<> with Queue, add_overlap,
 // RawDeviceBuffer::push (src/scalable_ccd/cuda/broad_phase/sweep.cu:48-182, queue.cuh:5-49,
@@ -8,14 +8,26 @@
 // Set semantics (identical to the reference): all (a,b) whose boxes intersect INCLUSIVELY on
 // x, y and z, that share no vertex id, and (two lists) come from different lists.
 //
-// Structure of sweep_stq_k, per wave of 64 lanes, persistent over tiles of 64 sorted rows:
-//   FILTER   lane = row (its conservative float bounds in registers); the column records are
-//            wave-uniform 16-byte loads.  32 columns per block; each lane collects a 32-bit
-//            hit mask.  No cross-lane traffic in the inner loop.
-//   QUEUE    hit masks are expanded into a per-wave LDS queue of (row, col) candidates
-//            (one wave prefix-sum per block) -- the "tiniest queue" of STQ, 64 lanes wide.
-//   CONFIRM  whenever >= 64 candidates are queued, every lane confirms one with the exact
-//            double boxes (6 inclusive compares) and the 3x3 vertex-id test.
+// Sweep classes (the candidate columns of a row are a run of the column list that starts at the row's `start` and ends
+// with the last column key <= the row's max-key; the exact tests decide):
+//   one list : row i against columns j > i with K(min_j) <= K(max_i)                  start = i + 1
+//   rows A   : columns B with K(min_a) <= K(min_b) <= K(max_a)                        start = lower_bound(keys B, K(min_a))
+//   rows B   : columns A with K(min_b) <  K(min_a) <= K(max_b)                        start = upper_bound(keys A, K(min_b))
+// The two two-list classes partition the intersecting cross pairs (exactly one of K(min_a) <= K(min_b),
+// K(min_b) < K(min_a) holds), so no pair is emitted twice and none is lost.
+//
+// Structure of sweep_band_k, per wave of 64 lanes, over tiles of 64 sorted rows (lane = row):
+//   STAGE    the rows' candidate columns lie in a band: row r starts at about start_0 + r.  The wave keeps a WINDOW of up
+//            to 128 columns in LDS (circular, staged in 32-column segments with consecutive 16-byte loads: every column
+//            record leaves HBM once per tile that needs it and is never gathered).
+//   FILTER   SKEWED: at step c lane r tests ITS OWN column start_r + c -- the exact inclusive test on the two minor
+//            axes and the key test on the sort axis, from LDS.  32 steps per block, a 32-bit hit mask per lane.  (Walking
+//            the union of the 64 rows' runs with wave-uniform columns, as round 2 did, tests 64 + len columns per
+//            row for a run of len.)
+//   CONFIRM  every lane walks the hits of its own row: the column's sort-axis interval, ids and lowest cells from the
+//            LDS window, the row's in its registers: the exact sort-axis test, the 3x3 vertex-id test, the owner-cell
+//            test.  No global memory access, no cross-lane traffic.  (STQ's queue -- hits expanded into (row, column)
+//            candidates, confirmed 64 at a time -- cost more per candidate than the idle lanes of this form.)
 //   EMIT     survivors go to a per-wave LDS staging buffer; one global atomic per ~1000 pairs
 //            reserves space, then the pairs are written coalesced (the reference: two global
 //            atomics per pair, collision.cuh:45-54).
@@ -28,186 +40,21 @@ namespace {
 
 constexpr int SW_THREADS = 256;
 constexpr int SW_WAVES = SW_THREADS / 64;
-constexpr int SW_QCAP = 256;  // candidate queue entries per wave
+constexpr int SW_WIN = 128;   // column slots of a wave's window (slot = column & 127)
+constexpr int SW_SEG = 32;    // columns per staging segment = steps per filter block
+constexpr int SW_MIR = SW_SEG; // the filter's arrays repeat their first segment behind the last: a run of 32 steps never wraps
 constexpr int SW_OCAP = 1024; // staged output pairs per wave
-constexpr int SW_BLOCK = 32;  // columns per filter block
 
-// ------------------------------------------------------------------------------------------
-// candidate ranges (prefix information of the sorted keys)
-//   mode 0 one list : cols (i, ub(key, kmax_i))                     pairs i<j, K(min_j) <= K(max_i)
-//   mode 1 rows A   : cols B with K(min_a) <= K(min_b) <= K(max_a)  [lb(keyB,key_a), ub(keyB,kmax_a))
-//   mode 2 rows B   : cols A with K(min_b) <  K(min_a) <= K(max_b)  [ub(keyA,key_b), ub(keyA,kmax_b))
-// Modes 1 and 2 partition the intersecting cross pairs (exactly one of K(min_a) <= K(min_b),
-// K(min_b) < K(min_a) holds), so no pair is emitted twice and none is lost.
-__device__ __forceinline__ unsigned lower_bound_u32(const uint32_t* __restrict__ a, unsigned n, uint32_t v)
-{
-    unsigned lo = 0, hi = n;
-    while (lo < hi) {
-        const unsigned mid = (lo + hi) >> 1;
-        if (a[mid] < v) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo;
-}
-__device__ __forceinline__ unsigned upper_bound_u32(const uint32_t* __restrict__ a, unsigned n, uint32_t v)
-{
-    unsigned lo = 0, hi = n;
-    while (lo < hi) {
-        const unsigned mid = (lo + hi) >> 1;
-        if (a[mid] <= v) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo;
-}
-
-// One block = 1024 consecutive sorted rows.  Their candidate ranges all lie inside one window of
-// the column list ([lb(first row's key), ub(largest max-key of the block))), found with two
-// full binary searches by one lane; every row then searches only inside the window, which is a
-// few hundred entries that stay in this CU's L1.
-__device__ __forceinline__ unsigned lower_bound_in(const uint32_t* __restrict__ a, unsigned lo, unsigned hi, uint32_t v)
-{
-    while (lo < hi) {
-        const unsigned mid = (lo + hi) >> 1;
-        if (a[mid] < v) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo;
-}
-__device__ __forceinline__ unsigned upper_bound_in(const uint32_t* __restrict__ a, unsigned lo, unsigned hi, uint32_t v)
-{
-    while (lo < hi) {
-        const unsigned mid = (lo + hi) >> 1;
-        if (a[mid] <= v) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo;
-}
-
-// lower_bound / upper_bound over a sorted array by ONE WAVE: 64 probes per round instead of one
-// (a 5M-entry list takes 4 dependent rounds of loads instead of 23).  UPPER: first index with
-// a[i] > v, else first index with a[i] >= v.  All 64 lanes must call it with the same arguments.
-template <bool UPPER> __device__ __forceinline__ unsigned wave_bound_u32(const uint32_t* __restrict__ a, unsigned n, uint32_t v)
-{
-    unsigned lo = 0, hi = n; // the answer lies in [lo, hi]
-    const unsigned lane = (unsigned)lane_id();
-    while (hi - lo > 64u) {
-        // 64 probes cut [lo, hi) into 65 pieces
-        const unsigned long long span = (unsigned long long)(hi - lo);
-        const unsigned pos = lo + (unsigned)(span * (lane + 1u) / 65ull);
-        const uint32_t x = a[pos < hi ? pos : hi - 1u];
-        const bool before = (pos < hi) && (UPPER ? (x <= v) : (x < v)); // the answer is beyond pos
-        const unsigned long long m = __ballot(before);
-        // probes are increasing and the predicate is monotone: m is a run of low bits
-        const int k = popc64(m);
-        const unsigned new_lo = k == 0 ? lo : lo + (unsigned)(span * (unsigned long long)k / 65ull) + 1u;
-        const unsigned new_hi = k == 64 ? hi : lo + (unsigned)(span * (unsigned long long)(k + 1) / 65ull);
-        lo = new_lo;
-        hi = new_hi < new_lo ? new_lo : new_hi;
-    }
-    // at most 64 candidates left: one probe each
-    const unsigned pos = lo + lane;
-    const bool before = pos < hi && (UPPER ? (a[pos] <= v) : (a[pos] < v));
-    return lo + (unsigned)popc64(__ballot(before));
-}
-
-constexpr int RG_THREADS = 1024; // rows per block: one window search and one statistics atomic per block
-constexpr int RG_WAVES = RG_THREADS / 64;
-__global__ __launch_bounds__(RG_THREADS) void ranges_k(const uint32_t* __restrict__ key_r, const uint32_t* __restrict__ kmax_r,
-                                                int n_rows, const uint32_t* __restrict__ key_c, int n_cols, int mode,
-                                                uint2* __restrict__ ranges, unsigned long long* __restrict__ candidates)
-{
-    __shared__ uint32_t s_kmax[RG_WAVES];
-    __shared__ unsigned s_win[2];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = i < n_rows;
-    const uint32_t k_lo = valid ? key_r[i] : 0xFFFFFFFFu;
-    const uint32_t k_hi = valid ? kmax_r[i] : 0u;
-    const uint32_t wmax = wave_max_u32(k_hi);
-    if (lane_id() == 0) s_kmax[threadIdx.x >> 6] = wmax;
-    __syncthreads();
-    if (threadIdx.x < 64) { // the first wave finds the window, 64 probes per round
-        uint32_t bmax = s_kmax[0];
-#pragma unroll
-        for (int k = 1; k < RG_WAVES; k++) bmax = max(bmax, s_kmax[k]);
-        // rows are sorted: the first row of the block has the smallest key
-        const uint32_t k_first = (uint32_t)__shfl((int)k_lo, 0, 64);
-        const unsigned i_first = (unsigned)(blockIdx.x * blockDim.x);
-        const unsigned w_lo = (mode == 0) ? i_first + 1u : wave_bound_u32<false>(key_c, (unsigned)n_cols, k_first);
-        unsigned w_hi = wave_bound_u32<true>(key_c, (unsigned)n_cols, bmax);
-        if (w_hi < w_lo) w_hi = w_lo;
-        if (threadIdx.x == 0) {
-            s_win[0] = w_lo;
-            s_win[1] = w_hi;
-        }
-    }
-    __syncthreads();
-    const unsigned w0 = s_win[0], w1 = s_win[1];
-    unsigned long long cnt = 0;
-    if (valid) {
-        unsigned s, e;
-        if (mode == 0) {
-            s = (unsigned)i + 1;
-            e = upper_bound_in(key_c, max(s, w0), w1, k_hi);
-        } else if (mode == 1) {
-            s = lower_bound_in(key_c, w0, w1, k_lo);
-            e = upper_bound_in(key_c, s, w1, k_hi);
-        } else {
-            s = upper_bound_in(key_c, w0, w1, k_lo);
-            e = upper_bound_in(key_c, s, w1, k_hi);
-        }
-        if (e < s) e = s;
-        ranges[i] = make_uint2(s, e);
-        cnt = e - s;
-    }
-    // work metric only: one atomic per BLOCK, spread over 32 words (a single word serialises
-    // at ~90 atomics/us chip-wide, which used to cost more than the searches)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    __shared__ unsigned long long s_cnt[RG_WAVES];
-    if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long tot = 0;
-#pragma unroll
-        for (int k = 0; k < RG_WAVES; k++) tot += s_cnt[k];
-        if (tot) atomicAdd(candidates + (blockIdx.x & 31), tot);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-struct ExactBox {
-    double lo[3], hi[3];
-    int v[3];
-    int eid;
+struct SweepLds { // per wave: 18,560 bytes; four waves per block, two blocks per CU
+    double2 a[SW_WIN + SW_MIR]; // {min, max} on minor axis a
+    double2 b[SW_WIN + SW_MIR];
+    uint4 x[SW_WIN];          // double2 {min, max} on the sort axis
+    uint4 id[SW_WIN];         // vertex ids, element id
+    uint32_t key[SW_WIN + SW_MIR];
+    uint32_t low[SW_WIN];       // lowest cells
+    int2 o[SW_OCAP];
 };
-__device__ __forceinline__ ExactBox load_exact(const sccd_aabb* __restrict__ b)
-{
-    const double4 q0 = reinterpret_cast<const double4*>(b)[0];
-    const double2 q1 = reinterpret_cast<const double2*>(b)[2];
-    const int4 q2 = reinterpret_cast<const int4*>(b)[3];
-    ExactBox r;
-    r.lo[0] = q0.x;
-    r.lo[1] = q0.y;
-    r.lo[2] = q0.z;
-    r.hi[0] = q0.w;
-    r.hi[1] = q1.x;
-    r.hi[2] = q1.y;
-    r.v[0] = q2.x;
-    r.v[1] = q2.y;
-    r.v[2] = q2.z;
-    r.eid = q2.w;
-    return r;
-}
-// AABB::intersects (aabb.cuh:68-73) && !share_a_vertex (collision.cuh:17-21)
-__device__ __forceinline__ bool exact_pair_ok(const ExactBox& a, const ExactBox& b)
-{
-    // (no short-circuits: a wave confirms 64 candidates in lockstep, a skipped comparison saves nothing)
-    const bool geo = (a.hi[0] >= b.lo[0]) & (a.lo[0] <= b.hi[0]) & (a.hi[1] >= b.lo[1]) & (a.lo[1] <= b.hi[1])
-        & (a.hi[2] >= b.lo[2]) & (a.lo[2] <= b.hi[2]);
-    const bool share = (a.v[0] == b.v[0]) | (a.v[0] == b.v[1]) | (a.v[0] == b.v[2]) | (a.v[1] == b.v[0])
-        | (a.v[1] == b.v[1]) | (a.v[1] == b.v[2]) | (a.v[2] == b.v[0]) | (a.v[2] == b.v[1]) | (a.v[2] == b.v[2]);
-    return geo & !share;
-}
+
 // output convention: sweep.cu:152-163 / sort_and_sweep.cpp:106-118
 __device__ __forceinline__ int2 make_pair_out(int emit, int row_eid, int col_eid)
 {
@@ -240,25 +87,33 @@ struct Emitter {
     }
     // The last flush of a kernel, by ALL waves of the block together: one atomic per block.  (Every
     // wave ends at about the same time, and the cursor is one hot word: ~90 atomics/us chip-wide --
-    // a flush per wave made the tail of each launch a queue of 4096 atomics.)
-    // `scratch`: 2 * SW_WAVES u64 of LDS no wave uses any more (the kernel's LDS budget is exactly
-    // 4 blocks per CU: not one byte may be added)
-    __device__ __forceinline__ void flush_block(unsigned long long* scratch)
+    // a flush per wave made the tail of each launch a queue of 4096 atomics.)  The block's count of candidate tests
+    // rides along (one more atomic per block, on one of 32 words).
+    // `scratch`: 3 * SW_WAVES u64 of LDS no wave uses any more
+    __device__ __forceinline__ void flush_block(unsigned long long* scratch, unsigned long long tests, unsigned long long* cand_word)
     {
         unsigned long long* blk_cnt = scratch;
         unsigned long long* blk_base = scratch + SW_WAVES;
+        unsigned long long* blk_tests = scratch + 2 * SW_WAVES;
         const int w = (int)(threadIdx.x >> 6);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tests += __shfl_xor(tests, o, 64);
         __syncthreads(); // every wave is done with the scratch area
-        if (lane_id() == 0) blk_cnt[w] = (unsigned long long)ocount;
+        if (lane_id() == 0) {
+            blk_cnt[w] = (unsigned long long)ocount;
+            blk_tests[w] = tests;
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
-            unsigned long long sum = 0;
+            unsigned long long sum = 0, tsum = 0;
             for (int k = 0; k < SW_WAVES; k++) {
                 blk_base[k] = sum;
                 sum += blk_cnt[k];
+                tsum += blk_tests[k];
             }
             const unsigned long long b0 = sum ? atomicAdd(n_pairs, sum) : 0ull;
             for (int k = 0; k < SW_WAVES; k++) blk_base[k] += b0;
+            if (tsum) atomicAdd(cand_word, tsum);
         }
         __syncthreads();
         const unsigned long long base = blk_base[w];
@@ -268,306 +123,499 @@ struct Emitter {
         }
         ocount = 0;
     }
-    __device__ __forceinline__ void push(bool ok, int2 pr)
+    __device__ __forceinline__ void push(bool ok, int2 pr) { push_mask(__ballot(ok), pr); }
+    // mask: the lanes that emit (wave-uniform)
+    __device__ __forceinline__ void push_mask(unsigned long long mask, int2 pr)
     {
-        const unsigned long long mask = __ballot(ok);
         if (mask == 0) return;
-        if (ok) stage[ocount + mbcnt64(mask)] = pr;
+        if ((mask >> lane_id()) & 1ull) stage[ocount + mbcnt64(mask)] = pr;
         ocount += popc64(mask);
         if (ocount > SW_OCAP - 64) flush();
     }
 };
 
-__device__ __forceinline__ double sel3(const double v[3], int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
-
-// A box listed in several cells meets the same partner in each of them; the pair is reported
-// only from the cell (max of the two boxes' lowest cells per minor axis), which both boxes
-// share iff they overlap on that axis (grid.hpp).
-__device__ __forceinline__ bool owns_pair(const GridParams& g, uint32_t row_key, const ExactBox& a, const ExactBox& b)
+// one row's record in registers
+struct RowRegs {
+    double2 x, a, b;
+    int4 id;
+    uint4 aux; // key, max-key, lowest cells, first column
+};
+__device__ __forceinline__ double2 as_double2(const uint4& u)
 {
-    if (g.n_cells <= 1) return true;
-    const int cell = (int)((unsigned long long)row_key >> g.xb);
-    const int ma = max(grid_cell_a(g, sel3(a.lo, g.aa)), grid_cell_a(g, sel3(b.lo, g.aa)));
-    const int mb = max(grid_cell_b(g, sel3(a.lo, g.ab)), grid_cell_b(g, sel3(b.lo, g.ab)));
-    return ma * g.Sb + mb == cell; // (= the row's cell (ca, cb): 0 <= mb < Sb, so the two coordinates need no division to compare)
+    return make_double2(__hiloint2double((int)u.y, (int)u.x), __hiloint2double((int)u.w, (int)u.z));
+}
+__device__ __forceinline__ void load_row(RowRegs& r, const SweepRecs& R, int row)
+{
+    const uint4* p = R.base + (unsigned)row;
+    const uint4 a = p[REC_A * (size_t)R.pstride], b = p[REC_B * (size_t)R.pstride], x = p[REC_X * (size_t)R.pstride];
+    const uint4 id = p[REC_ID * (size_t)R.pstride];
+    r.aux = p[REC_AUX * (size_t)R.pstride];
+    r.a = as_double2(a);
+    r.b = as_double2(b);
+    r.x = as_double2(x);
+    r.id = make_int4((int)id.x, (int)id.y, (int)id.z, (int)id.w);
 }
 
-// low_r / low_c: the lowest cells of the boxes per minor axis as entry_gather_k stored them (the values owns_pair would
-// compute again from the exact boxes: twenty FP64 instructions per candidate against two 4-byte loads of lines that the
-// filter stage has just touched)
-__device__ __forceinline__ void confirm(bool active, uint2 cand, const sccd_aabb* __restrict__ box_r,
-                                        const uint32_t* __restrict__ key_r, const uint32_t* __restrict__ low_r,
-                                        const sccd_aabb* __restrict__ box_c, const uint32_t* __restrict__ low_c,
-                                        const GridParams& g, int emit, Emitter& em)
-{
-    bool ok = false;
-    int2 pr = make_int2(0, 0);
-    if (active) {
-        const ExactBox a = load_exact(box_r + cand.x);
-        const ExactBox b = load_exact(box_c + cand.y);
-        const uint32_t la = low_r[cand.x], lb = low_c[cand.y];
-        const int cell = (int)((unsigned long long)key_r[cand.x] >> g.xb);
-        const int ma = (int)max(la & 0xFFFFu, lb & 0xFFFFu), mb = (int)max(la >> 16, lb >> 16);
-        const bool owner = (g.n_cells <= 1) | (ma * g.Sb + mb == cell); // owns_pair on the stored cells
-        ok = (int)exact_pair_ok(a, b) & (int)owner;
-        pr = make_pair_out(emit, a.eid, b.eid);
-    }
-    em.push(ok, pr);
-}
-
-__global__ __launch_bounds__(SW_THREADS, 4) void sweep_stq_k(
-    const float4* __restrict__ filt_r, const sccd_aabb* __restrict__ box_r, const uint32_t* __restrict__ key_r,
-    const uint32_t* __restrict__ low_r, const uint2* __restrict__ ranges, int row_begin, int row_end,
-    const float4* __restrict__ filt_c, const sccd_aabb* __restrict__ box_c, const uint32_t* __restrict__ low_c,
-    const GridParams* __restrict__ gp, int emit, int2* __restrict__ out, long long capacity, SweepCounters* __restrict__ cnt)
-{
-    const GridParams g = *gp;
-    __shared__ uint2 q_s[SW_WAVES][SW_QCAP];
-    __shared__ int2 o_s[SW_WAVES][SW_OCAP];
-    const int lane = lane_id(), w = threadIdx.x >> 6;
-    uint2* q = q_s[w];
-    Emitter em { o_s[w], 0, out, capacity, &cnt->n_pairs };
-    int qcount = 0;
-    const int num_tiles = (row_end - row_begin + 63) / 64;
-
-    // Tiles are dealt round-robin to the waves of the grid.  (A ticket per tile made the whole
-    // sweep ticket-bound: one hot word serves ~90 atomics/us chip-wide, and a launch has ~27k
-    // tiles that each take only a few microseconds.)
-    const int n_waves = (int)gridDim.x * SW_WAVES;
-    // the rows of the NEXT tile are requested before the current one is processed (their
-    // latency hides behind the filter / confirm work)
-    uint2 rg_n = make_uint2(0u, 0u);
-    float4 fr_n = make_float4(0.f, 0.f, 0.f, 0.f);
+// 32 columns [c0, c0 + 32) (c0 a multiple of 32) into their window slots: 160 pieces of 16 bytes.  Lane l moves piece
+// (l >> 5) of column l & 31 (minor axis a / b), piece 2 + (l >> 5) (sort axis / ids) and, the lower half of the wave, the
+// aux piece: consecutive lanes, consecutive 16 bytes.  Where each lane reads and writes is fixed for the kernel (Stager),
+// so a segment costs three loads, two 16-byte LDS stores, two 4-byte ones and no address arithmetic to speak of.
+// Columns past the end of the list read the arrays' padding (never tested).  In two halves, so that a segment can be
+// asked for ahead and land in registers meanwhile.
+struct SegRegs {
+    uint4 v0, v1, v2;
+};
+struct Stager {
+    const uint4* base; // the column list's pieces
+    uint32_t g0, g1, g2; // per lane: offsets of its three pieces (units of 16 bytes) for column 0
+    uint4 *d0, *d1;      // per lane: LDS slots of its first two pieces for window slot 0
+    uint32_t *dk, *dl;   // ... of the key and the lowest cells
+    bool low_half;
+    __device__ __forceinline__ Stager(SweepLds& L, const SweepRecs& C)
     {
-        const int row0 = row_begin + ((int)blockIdx.x * SW_WAVES + w) * 64 + lane;
-        if (row0 < row_end) {
-            rg_n = ranges[row0];
-            fr_n = filt_r[row0];
+        const int lane = lane_id();
+        const uint32_t s = (uint32_t)(lane & 31), h = (uint32_t)(lane >> 5);
+        base = C.base;
+        g0 = (REC_A + h) * C.pstride + s;
+        g1 = (REC_X + h) * C.pstride + s;
+        g2 = REC_AUX * C.pstride + s;
+        d0 = reinterpret_cast<uint4*>(h ? L.b : L.a) + s;
+        d1 = (h ? L.id : L.x) + s;
+        dk = L.key + s;
+        dl = L.low + s;
+        low_half = h == 0;
+    }
+    __device__ __forceinline__ SegRegs load(unsigned c0) const
+    {
+        const uint4* b = base + c0; // wave-uniform
+        SegRegs g;
+        g.v0 = b[g0];
+        g.v1 = b[g1];
+        g.v2 = make_uint4(0u, 0u, 0u, 0u);
+        if (low_half) g.v2 = b[g2];
+        return g;
+    }
+    __device__ __forceinline__ void write(const SegRegs& g, unsigned c0) const
+    {
+        const unsigned slot0 = c0 & (unsigned)(SW_WIN - 1); // wave-uniform
+        d0[slot0] = g.v0;
+        d1[slot0] = g.v1;
+        if (low_half) {
+            dk[slot0] = g.v2.x;
+            dl[slot0] = g.v2.z;
+        }
+        if (slot0 == 0) { // the filter's arrays repeat their first segment behind the last
+            d0[SW_WIN] = g.v0;
+            if (low_half) dk[SW_WIN] = g.v2.x;
         }
     }
-    for (int tile = (int)blockIdx.x * SW_WAVES + w; tile < num_tiles; tile += n_waves) {
+};
+
+// CONFIRM one hit of the lane's own row: AABB::intersects on the sort axis (aabb.cuh:68-73; the two minor axes passed the
+// filter) && !share_a_vertex (collision.cuh:17-21; IDS == 0: the filter saw to that already) && this cell owns the pair
+// (grid.hpp: a box listed in several cells meets the same partner in each of them; the pair is reported only from the
+// cell (max of the two boxes' lowest cells per minor axis), which both boxes share iff they overlap on that axis: the
+// packed maximum of the two lowest-cell words equals the row's own cell coordinates, packed alike).  The column comes
+// from the LDS window, the row is in the lane's registers.  The comparisons narrow EXEC one after the other (v_cmpx, as
+// in the filter); what is left of it is the mask of confirmed pairs.  Returns that mask (wave-uniform).
+template <int IDS>
+__device__ __forceinline__ unsigned long long confirm_mask(unsigned has, const double2& rx, const int4& rv, unsigned my_low,
+                                                           unsigned my_cellpack, const double2& cx, const int4& cv, unsigned clow)
+{
+    unsigned long long save, ok;
+    unsigned tmp;
+    if (IDS)
+        asm volatile("s_mov_b64 %[save], exec\n\t"
+                     "v_cmpx_ne_u32_e32 vcc, 0, %[has]\n\t"
+                     "v_pk_max_u16 %[tmp], %[mylow], %[clow]\n\t"
+                     "v_cmpx_eq_u32_e32 vcc, %[tmp], %[mycell]\n\t"
+                     "v_cmpx_ge_f64_e32 vcc, %[rxhi], %[cxlo]\n\t"
+                     "v_cmpx_le_f64_e32 vcc, %[rxlo], %[cxhi]\n\t"
+                     "v_cmpx_ne_u32_e32 vcc, %[r0], %[c0]\n\t"
+                     "v_cmpx_ne_u32_e32 vcc, %[r0], %[c1]\n\t"
+                     "v_cmpx_ne_u32_e32 vcc, %[r0], %[c2]\n\t"
+                     "v_cmpx_ne_u32_e32 vcc, %[r1], %[c0]\n\t"
+                     "v_cmpx_ne_u32_e32 vcc, %[r1], %[c1]\n\t"
+                     "v_cmpx_ne_u32_e32 vcc, %[r1], %[c2]\n\t"
+                     "v_cmpx_ne_u32_e32 vcc, %[r2], %[c0]\n\t"
+                     "v_cmpx_ne_u32_e32 vcc, %[r2], %[c1]\n\t"
+                     "v_cmpx_ne_u32_e32 vcc, %[r2], %[c2]\n\t"
+                     "s_mov_b64 %[ok], exec\n\t"
+                     "s_mov_b64 exec, %[save]"
+                     : [save] "=&s"(save), [ok] "=&s"(ok), [tmp] "=&v"(tmp)
+                     : [has] "v"(has), [mylow] "v"(my_low), [clow] "v"(clow), [mycell] "v"(my_cellpack), [rxlo] "v"(rx.x),
+                       [rxhi] "v"(rx.y), [cxlo] "v"(cx.x), [cxhi] "v"(cx.y), [r0] "v"(rv.x), [r1] "v"(rv.y), [r2] "v"(rv.z),
+                       [c0] "v"(cv.x), [c1] "v"(cv.y), [c2] "v"(cv.z)
+                     : "vcc");
+    else
+        asm volatile("s_mov_b64 %[save], exec\n\t"
+                     "v_cmpx_ne_u32_e32 vcc, 0, %[has]\n\t"
+                     "v_pk_max_u16 %[tmp], %[mylow], %[clow]\n\t"
+                     "v_cmpx_eq_u32_e32 vcc, %[tmp], %[mycell]\n\t"
+                     "v_cmpx_ge_f64_e32 vcc, %[rxhi], %[cxlo]\n\t"
+                     "v_cmpx_le_f64_e32 vcc, %[rxlo], %[cxhi]\n\t"
+                     "s_mov_b64 %[ok], exec\n\t"
+                     "s_mov_b64 exec, %[save]"
+                     : [save] "=&s"(save), [ok] "=&s"(ok), [tmp] "=&v"(tmp)
+                     : [has] "v"(has), [mylow] "v"(my_low), [clow] "v"(clow), [mycell] "v"(my_cellpack), [rxlo] "v"(rx.x),
+                       [rxhi] "v"(rx.y), [cxlo] "v"(cx.x), [cxhi] "v"(cx.y)
+                     : "vcc");
+    return ok;
+}
+
+// One filter step of a lane: is column (key k, minor-axis intervals ca, cb) inside the row's key range (-> bit BIT of km) and
+// does it overlap the row on both minor axes, inclusively (-> bit BIT of m)?  The five conditions narrow the EXEC mask one
+// after the other (v_cmpx) and the two ORs run under it: 7 vector and 2 scalar instructions.  (Written as C the same step
+// is 5 v_cmp + 4 s_and_b64 + 2 v_cndmask + 2 v_or and a v_mov per bit: 9-10 vector and 5 scalar instructions -- and this
+// loop is what the sweep's time goes into.)  EXEC is restored before the statement ends; NaN bounds compare false like in C.
+// KIND: what is known about the vertex ids of the two lists (boxes built HERE from a mesh: aabb.cpp:57-58,107-109,128-130 --
+// vertex {i, -i-1, -i-1}, edge {e0, e1, -e0-1}, face {f0, f1, f2}, all indices >= 0).  A mesh's sweep lists are full of
+// neighbours that overlap and share a vertex (an edge of a cloth has ten of them against three real partners): with the
+// ids known, share_a_vertex (collision.cuh:17-21) is 4 comparisons (edge - edge) or 3 (vertex - face) instead of 9 --
+// cheap enough for the filter, and the confirm loop (as many rounds as the busiest lane has hits) loses 60 % of its hits.
+//   0  unknown (uploaded boxes): the nine comparisons stay in the confirm stage
+//   1  edges x edges: {a0, a1} x {b0, b1}        (a negative filler equals nothing but the filler of the same a0)
+//   2  row vertex, column face: v x {f0, f1, f2}
+//   3  row face, column vertex: {f0, f1, f2} x v
+template <unsigned BIT, int KIND>
+__device__ __forceinline__ void filter_step(unsigned& m, unsigned& km, uint32_t k, uint32_t kmax, const double2& ca,
+                                            const double2& cb, const double2& ra, const double2& rb, const int4& rv,
+                                            const int4& cv)
+{
+    const double calo = ca.x, cahi = ca.y, cblo = cb.x, cbhi = cb.y;
+    unsigned long long save;
+#define SCCD_FILTER_HEAD                                   \
+    "s_mov_b64 %[save], exec\n\t"                          \
+    "v_cmpx_le_u32_e32 vcc, %[k], %[kmax]\n\t"             \
+    "v_or_b32_e32 %[km], %[bit], %[km]\n\t"                \
+    "v_cmpx_le_f64_e32 vcc, %[calo], %[rahi]\n\t"          \
+    "v_cmpx_le_f64_e32 vcc, %[ralo], %[cahi]\n\t"          \
+    "v_cmpx_le_f64_e32 vcc, %[cblo], %[rbhi]\n\t"          \
+    "v_cmpx_le_f64_e32 vcc, %[rblo], %[cbhi]\n\t"
+#define SCCD_FILTER_TAIL                                   \
+    "v_or_b32_e32 %[m], %[bit], %[m]\n\t"                  \
+    "s_mov_b64 exec, %[save]"
+#define SCCD_FILTER_GEO_OPS                                                                                              \
+    [k] "v"(k), [kmax] "v"(kmax), [calo] "v"(calo), [cahi] "v"(cahi), [cblo] "v"(cblo), [cbhi] "v"(cbhi), [ralo] "v"(ra.x), \
+        [rahi] "v"(ra.y), [rblo] "v"(rb.x), [rbhi] "v"(rb.y), [bit] "i"(BIT)
+    if (KIND == 1)
+        asm volatile(SCCD_FILTER_HEAD "v_cmpx_ne_u32_e32 vcc, %[r0], %[c0]\n\t"
+                                      "v_cmpx_ne_u32_e32 vcc, %[r0], %[c1]\n\t"
+                                      "v_cmpx_ne_u32_e32 vcc, %[r1], %[c0]\n\t"
+                                      "v_cmpx_ne_u32_e32 vcc, %[r1], %[c1]\n\t" SCCD_FILTER_TAIL
+                     : [m] "+v"(m), [km] "+v"(km), [save] "=&s"(save)
+                     : SCCD_FILTER_GEO_OPS, [r0] "v"(rv.x), [r1] "v"(rv.y), [c0] "v"(cv.x), [c1] "v"(cv.y)
+                     : "vcc");
+    else if (KIND == 2)
+        asm volatile(SCCD_FILTER_HEAD "v_cmpx_ne_u32_e32 vcc, %[r0], %[c0]\n\t"
+                                      "v_cmpx_ne_u32_e32 vcc, %[r0], %[c1]\n\t"
+                                      "v_cmpx_ne_u32_e32 vcc, %[r0], %[c2]\n\t" SCCD_FILTER_TAIL
+                     : [m] "+v"(m), [km] "+v"(km), [save] "=&s"(save)
+                     : SCCD_FILTER_GEO_OPS, [r0] "v"(rv.x), [c0] "v"(cv.x), [c1] "v"(cv.y), [c2] "v"(cv.z)
+                     : "vcc");
+    else if (KIND == 3)
+        asm volatile(SCCD_FILTER_HEAD "v_cmpx_ne_u32_e32 vcc, %[r0], %[c0]\n\t"
+                                      "v_cmpx_ne_u32_e32 vcc, %[r1], %[c0]\n\t"
+                                      "v_cmpx_ne_u32_e32 vcc, %[r2], %[c0]\n\t" SCCD_FILTER_TAIL
+                     : [m] "+v"(m), [km] "+v"(km), [save] "=&s"(save)
+                     : SCCD_FILTER_GEO_OPS, [r0] "v"(rv.x), [r1] "v"(rv.y), [r2] "v"(rv.z), [c0] "v"(cv.x)
+                     : "vcc");
+    else
+        asm volatile(SCCD_FILTER_HEAD SCCD_FILTER_TAIL
+                     : [m] "+v"(m), [km] "+v"(km), [save] "=&s"(save)
+                     : SCCD_FILTER_GEO_OPS
+                     : "vcc");
+#undef SCCD_FILTER_HEAD
+#undef SCCD_FILTER_TAIL
+#undef SCCD_FILTER_GEO_OPS
+}
+
+// ONE: rows and columns are the same list and a row's first column is the row behind it
+// chunk: consecutive tiles a wave sweeps in a row (inside a chunk the window just moves on).
+template <bool ONE, int KIND>
+__global__ __launch_bounds__(SW_THREADS, 2) void sweep_band_k(SweepRecs R, int row_begin, int row_end, SweepRecs C, int n_cols,
+                                                              const GridParams* __restrict__ gp, int emit, int chunk,
+                                                              int2* __restrict__ out, long long capacity,
+                                                              SweepCounters* __restrict__ cnt, int diag)
+{
+    unsigned d_blocks = 0, d_groups = 0, d_rounds = 0, d_segs = 0; // wave-uniform (SCCD_SWEEP_DIAG)
+    __shared__ SweepLds lds_s[SW_WAVES];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    SweepLds& L = lds_s[w];
+    const int xb = gp->xb, Sb = max(gp->Sb, 1);
+    Emitter em { L.o, 0, out, capacity, &cnt->n_pairs };
+    const Stager st(L, C);
+    unsigned long long tests = 0; // candidate columns of this lane's rows (key range on the sort axis)
+    const unsigned n_cols_up = ((unsigned)n_cols + (unsigned)(SW_SEG - 1)) & ~(unsigned)(SW_SEG - 1);
+    const int num_tiles = (row_end - row_begin + 63) / 64;
+    // Chunks of tiles are dealt statically (a ticket per tile made the sweep ticket-bound: one hot word serves ~90
+    // atomics/us chip-wide), XCD-AWARE: blocks go to the eight XCDs in turn, and XCD x sweeps the x-th eighth of the
+    // tiles with its blocks' waves on neighbouring chunks -- their column windows meet in that XCD's L2.  (Nothing
+    // depends on which XCD a block lands on.)
+    const int xcd = (int)(blockIdx.x & 7u), bi = (int)(blockIdx.x >> 3), nbx = (int)(gridDim.x >> 3);
+    const int tpx = (num_tiles + 7) >> 3;
+    const int t_lo = xcd * tpx, t_hi = min(num_tiles, (xcd + 1) * tpx);
+    const int ch_stride = nbx * SW_WAVES * chunk; // tiles between a wave's chunks
+    int ch_first = t_lo + (bi * SW_WAVES + w) * chunk; // first tile of this wave's current chunk
+    int tile = ch_first;
+    // the rows of the NEXT tile are requested before the current one is processed
+    RowRegs nx;
+    nx.x = nx.a = nx.b = make_double2(0.0, 0.0);
+    nx.id = make_int4(0, 0, 0, 0);
+    nx.aux = make_uint4(0u, 0u, 0u, 0u);
+    {
+        const int row0 = row_begin + tile * 64 + lane;
+        if (tile < t_hi && row0 < row_end) load_row(nx, R, row0);
+    }
+    unsigned w_lo = 0, w_hi = 0; // columns [w_lo, w_hi) are staged (w_lo a multiple of 32, w_hi - w_lo <= 128)
+    bool have = false;           // (the window survives from tile to tile inside a chunk)
+    int ahead = 0;               // segments [ahead_c0, + 32 * ahead) were asked for ahead and sit in `seg`
+    unsigned ahead_c0 = 0;
+    SegRegs seg0, seg1;
+    seg0.v0 = seg0.v1 = seg0.v2 = make_uint4(0u, 0u, 0u, 0u);
+    seg1 = seg0;
+    while (tile < t_hi) {
         const int row = row_begin + tile * 64 + lane;
         const bool valid = row < row_end;
-        const uint2 rg = rg_n;
-        const float4 fr = fr_n;
+        const RowRegs me = nx;
+        // the tile after this one: the next of the chunk, or the first of this wave's next chunk
+        int tile_next = tile + 1;
+        bool next_follows = true;
+        if (tile_next >= ch_first + chunk || tile_next >= t_hi) {
+            ch_first += ch_stride;
+            tile_next = ch_first;
+            next_follows = false;
+        }
         {
-            const int row_next = row + n_waves * 64;
-            rg_n = make_uint2(0u, 0u);
-            fr_n = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tile + n_waves < num_tiles && row_next < row_end) {
-                rg_n = ranges[row_next];
-                fr_n = filt_r[row_next];
-            }
+            const int row_next = row_begin + tile_next * 64 + lane;
+            if (tile_next < t_hi && row_next < row_end) load_row(nx, R, row_next);
         }
-        const bool nonempty = valid && rg.y > rg.x;
-        const unsigned jmin = readfirst_u32(wave_min_u32(nonempty ? rg.x : 0xFFFFFFFFu));
-        const unsigned jmax = readfirst_u32(wave_max_u32(nonempty ? rg.y : 0u));
-        if (jmin >= jmax) continue;
-
-        for (unsigned j0 = jmin & ~(unsigned)(SW_BLOCK - 1); j0 < jmax; j0 += SW_BLOCK) {
-            // this lane's live columns inside [j0, j0+32)
-            const unsigned lo = max(rg.x, j0), hi = min(rg.y, j0 + SW_BLOCK);
-            unsigned live = 0;
-            if (hi > lo) {
-                const unsigned len = hi - lo;
-                live = (len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u)) << (lo - j0);
-            }
-            unsigned m = 0;
-            const float4* __restrict__ cb = filt_c + j0; // wave-uniform address
-#pragma unroll
-            for (int b = 0; b < SW_BLOCK; b++) {
-                const float4 cc = cb[b];
-                const bool hit = (cc.x <= fr.y) & (fr.x <= cc.y) & (cc.z <= fr.w) & (fr.z <= cc.w);
-                m |= hit ? (1u << b) : 0u;
-            }
-            m &= live;
-            if (__ballot(m != 0) == 0) continue;
-
-            // ---- expand the hit masks into the candidate queue
-            const int mine = __popc(m);
-            const int incl = wave_incl_scan(mine);
-            const int total = (int)readfirst_u32((unsigned)__shfl(incl, 63, 64));
-            if (qcount + total <= SW_QCAP) {
-                int pos = qcount + incl - mine;
-                while (m) {
-                    const int b = __ffs((int)m) - 1;
-                    m &= m - 1;
-                    q[pos++] = make_uint2((unsigned)row, j0 + (unsigned)b);
-                }
-                qcount += total;
-            } else {
-                // crowded block: one candidate per lane per round
-                for (;;) {
-                    const bool has = m != 0;
-                    const unsigned long long mask = __ballot(has);
-                    if (mask == 0) break;
-                    while (qcount > SW_QCAP - 64) {
-                        wave_lds_fence();
-                        const uint2 cand = q[qcount - 64 + lane];
-                        qcount -= 64;
-                        confirm(true, cand, box_r, key_r, low_r, box_c, low_c, g, emit, em);
+        unsigned j = ONE ? (unsigned)row + 1u : me.aux.w; // next column of this lane's row
+        bool live = valid && j < (unsigned)n_cols;
+        const uint32_t kmax = me.aux.y;
+        // the row's own cell, packed like the lowest-cell words (a | b << 16); a grid of one cell: all zero
+        const unsigned my_cell = (unsigned)((unsigned long long)me.aux.x >> xb);
+        const unsigned my_cellpack = (my_cell / (unsigned)Sb) | ((my_cell % (unsigned)Sb) << 16);
+        for (;;) {
+            const unsigned base = wave_min_u32_dpp(live ? j : 0xFFFFFFFFu);
+            if (base == 0xFFFFFFFFu) break;
+            const unsigned nlo = base & ~(unsigned)(SW_SEG - 1);
+            const unsigned need = min(n_cols_up, nlo + (unsigned)SW_WIN); // the whole window (a lane can be 96 columns ahead of the first)
+            unsigned from = (have && w_hi > nlo && w_lo <= nlo) ? w_hi : nlo;
+            if (from < need) {
+                // (asked for ahead: they have landed, or are about to)
+                if (ahead >= 1 && ahead_c0 == from && from < need) {
+                    st.write(seg0, from);
+                    from += SW_SEG;
+                    if (ahead >= 2 && from < need) {
+                        st.write(seg1, from);
+                        from += SW_SEG;
                     }
-                    if (has) {
-                        const int b = __ffs((int)m) - 1;
-                        m &= m - 1;
-                        q[qcount + mbcnt64(mask)] = make_uint2((unsigned)row, j0 + (unsigned)b);
-                    }
-                    qcount += popc64(mask);
                 }
-            }
-            // ---- confirm full batches
-            while (qcount >= 64) {
+                for (; from < need; from += SW_SEG) {
+                    seg0 = st.load(from);
+                    st.write(seg0, from);
+                    ++d_segs;
+                }
                 wave_lds_fence();
-                const uint2 cand = q[qcount - 64 + lane];
-                qcount -= 64;
-                confirm(true, cand, box_r, key_r, low_r, box_c, low_c, g, emit, em);
+            }
+            ahead = 0;
+            w_lo = nlo;
+            w_hi = from;
+            have = true;
+
+            // ---- FILTER: lane r tests its own columns j, j + 1, ... (at most 32, inside the window)
+            const unsigned lim = min(w_hi, (unsigned)n_cols);
+            int avail = 0;
+            if (live && j < lim) avail = (int)min(lim - j, (unsigned)SW_SEG);
+            const unsigned s0 = j & (unsigned)(SW_WIN - 1);
+            unsigned m = 0, km = 0;
+            ++d_blocks;
+            // (eight steps at a time: their 72 dwords of LDS reads are in flight together; the whole run unrolled asks for
+            // more registers than a lane has.  A block ends with the longest lane's run.)
+#pragma unroll 1
+            for (int c8 = 0; c8 < SW_SEG; c8 += 8) {
+                if (__ballot(avail > c8) == 0) break;
+                ++d_groups;
+                const unsigned at = s0 + (unsigned)c8;
+                uint32_t k[8];
+                double2 ca[8], cb[8];
+                int4 cv[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    k[i] = L.key[at + i];
+                    ca[i] = L.a[at + i];
+                    cb[i] = L.b[at + i];
+                    cv[i] = make_int4(0, 0, 0, 0);
+                    const unsigned slot = (at + (unsigned)i) & (unsigned)(SW_WIN - 1); // (the ids are not mirrored)
+                    if (KIND == 1) {
+                        const uint2 t = *reinterpret_cast<const uint2*>(&L.id[slot]);
+                        cv[i].x = (int)t.x;
+                        cv[i].y = (int)t.y;
+                    } else if (KIND == 2) {
+                        const uint4 t = L.id[slot];
+                        cv[i] = make_int4((int)t.x, (int)t.y, (int)t.z, 0);
+                    } else if (KIND == 3) {
+                        cv[i].x = (int)L.id[slot].x;
+                    }
+                }
+                unsigned m8 = 0, km8 = 0;
+                filter_step<1u, KIND>(m8, km8, k[0], kmax, ca[0], cb[0], me.a, me.b, me.id, cv[0]);
+                filter_step<2u, KIND>(m8, km8, k[1], kmax, ca[1], cb[1], me.a, me.b, me.id, cv[1]);
+                filter_step<4u, KIND>(m8, km8, k[2], kmax, ca[2], cb[2], me.a, me.b, me.id, cv[2]);
+                filter_step<8u, KIND>(m8, km8, k[3], kmax, ca[3], cb[3], me.a, me.b, me.id, cv[3]);
+                filter_step<16u, KIND>(m8, km8, k[4], kmax, ca[4], cb[4], me.a, me.b, me.id, cv[4]);
+                filter_step<32u, KIND>(m8, km8, k[5], kmax, ca[5], cb[5], me.a, me.b, me.id, cv[5]);
+                filter_step<64u, KIND>(m8, km8, k[6], kmax, ca[6], cb[6], me.a, me.b, me.id, cv[6]);
+                filter_step<128u, KIND>(m8, km8, k[7], kmax, ca[7], cb[7], me.a, me.b, me.id, cv[7]);
+                m |= m8 << c8;
+                km |= km8 << c8;
+            }
+            const unsigned amask = avail >= 32 ? 0xFFFFFFFFu : ((1u << avail) - 1u);
+            m &= amask;
+            km &= amask;
+            bool goes_on = false; // the lane's last column of this block is still inside its key range (keys ascend)
+            if (avail > 0) {
+                goes_on = (km >> (avail - 1)) & 1u;
+                tests += (unsigned)__popc(km); // (the columns inside the row's key range are a prefix of the run)
+                j += (unsigned)avail;
+                live = goes_on && j < (unsigned)n_cols;
+            }
+            // ask for what comes behind the window now: it lands while this block's candidates are confirmed
+            if (w_hi < n_cols_up) {
+                if (__ballot(goes_on) != 0) { // a lane goes on in the next block
+                    ahead = 1;
+                    ahead_c0 = w_hi;
+                    seg0 = st.load(ahead_c0);
+                } else if (next_follows && tile_next < t_hi) { // the tile's last block: the next tile starts 64 columns further on
+                    ahead = 1;
+                    ahead_c0 = w_hi;
+                    seg0 = st.load(ahead_c0);
+                    if (w_hi + (unsigned)SW_SEG < n_cols_up) {
+                        ahead = 2;
+                        seg1 = st.load(ahead_c0 + (unsigned)SW_SEG);
+                    }
+                }
+            }
+            // ---- CONFIRM + EMIT: every lane walks the hits of its own row (the column from the LDS window, the row in its
+            // registers; as many rounds as the busiest lane has hits).  Round 2 queued the hits of a block as (row, column)
+            // candidates and confirmed 64 of them at a time with full lanes -- every candidate then costs a queue write, a
+            // queue read and ten cross-lane moves for its row, which is more than the idle lanes here.
+            const unsigned my_low = me.aux.z;
+            while (__ballot(m != 0) != 0) {
+                ++d_rounds;
+                const unsigned has = m != 0 ? 1u : 0u;
+                const unsigned b = has ? (unsigned)__ffs((int)m) - 1u : 0u;
+                m &= m - 1u;
+                const unsigned slot = (s0 + b) & (unsigned)(SW_WIN - 1);
+                const uint4 cxu = L.x[slot], cvu = L.id[slot];
+                const uint32_t clow = L.low[slot];
+                const double2 cx = as_double2(cxu);
+                const int4 cv = make_int4((int)cvu.x, (int)cvu.y, (int)cvu.z, (int)cvu.w);
+                const unsigned long long ok = confirm_mask<KIND == 0>(has, me.x, me.id, my_low, my_cellpack, cx, cv, clow);
+                em.push_mask(ok, make_pair_out(emit, me.id.w, cv.w));
             }
         }
-    }
-    // drain
-    if (qcount > 0) {
-        wave_lds_fence();
-        const bool act = lane < qcount;
-        const uint2 cand = act ? q[lane] : make_uint2(0u, 0u);
-        confirm(act, cand, box_r, key_r, low_r, box_c, low_c, g, emit, em);
+        if (!next_follows) { // the next tile is somewhere else: its window starts from nothing
+            have = false;
+            ahead = 0;
+        }
+        tile = tile_next;
     }
     wave_lds_fence();
-    em.flush_block(reinterpret_cast<unsigned long long*>(&q_s[0][0])); // (the candidate queues are empty now)
-}
-
-// Direct exact sweep: the kernel of choice once the cell grid has cut the candidates down to a
-// few per emitted pair.  Lane = row with its EXACT box, ids and lowest cell in registers; the
-// column records (64-byte box + lowest cell) are wave-uniform, i.e. scalar loads; the exact
-// inclusive test, the vertex-id test and the owner-cell test run in the loop and survivors go
-// straight to the staged emitter.  No candidate queue, no dependent gathers.
-__global__ __launch_bounds__(SW_THREADS) void sweep_direct_k(
-    const sccd_aabb* __restrict__ box_r, const uint32_t* __restrict__ key_r, const uint32_t* __restrict__ low_r,
-    const uint2* __restrict__ ranges, int row_begin, int row_end, const sccd_aabb* __restrict__ box_c,
-    const uint32_t* __restrict__ low_c, const GridParams* __restrict__ gp, int emit, int2* __restrict__ out,
-    long long capacity, SweepCounters* __restrict__ cnt)
-{
-    __shared__ int2 o_s[SW_WAVES][SW_OCAP];
-    const int lane = lane_id(), w = threadIdx.x >> 6;
-    Emitter em { o_s[w], 0, out, capacity, &cnt->n_pairs };
-    const int xb = gp->xb, Sb = gp->Sb;
-    const bool one_cell = gp->n_cells <= 1;
-    const int num_tiles = (row_end - row_begin + 63) / 64;
-    // Tiles are dealt round-robin to the waves of the grid.  (A ticket per tile made the whole
-    // sweep ticket-bound: one hot word serves ~90 atomics/us chip-wide, and a launch has ~27k
-    // tiles that each take only a few microseconds.)
-    const int n_waves = (int)gridDim.x * SW_WAVES;
-    for (int tile = (int)blockIdx.x * SW_WAVES + w; tile < num_tiles; tile += n_waves) {
-        const int row = row_begin + tile * 64 + lane;
-        const bool valid = row < row_end;
-        uint2 rg = make_uint2(0u, 0u);
-        ExactBox a;
-        int ca = 0, cb = 0, la = 0, lb = 0;
-        if (valid) {
-            rg = ranges[row];
-            a = load_exact(box_r + row);
-            const int cell = (int)((unsigned long long)key_r[row] >> xb);
-            ca = cell / Sb;
-            cb = cell - ca * Sb;
-            const uint32_t lw = low_r[row];
-            la = (int)(lw & 0xFFFFu);
-            lb = (int)(lw >> 16);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                a.lo[k] = 1.0; // empty box: never intersects
-                a.hi[k] = -1.0;
-                a.v[k] = 0;
-            }
-            a.eid = 0;
-        }
-        const bool nonempty = valid && rg.y > rg.x;
-        const unsigned jmin = readfirst_u32(wave_min_u32(nonempty ? rg.x : 0xFFFFFFFFu));
-        const unsigned jmax = readfirst_u32(wave_max_u32(nonempty ? rg.y : 0u));
-        for (unsigned j0 = jmin; j0 < jmax; j0 += 4) { // wave-uniform columns, 4 scalar records per wait
-            ExactBox b[4];
-            uint32_t lw[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { // the arrays are padded: reading past the last column is harmless
-                b[u] = load_exact(box_c + j0 + u);
-                lw[u] = low_c[j0 + u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const unsigned j = j0 + (unsigned)u;
-                bool ok = j >= rg.x && j < rg.y && exact_pair_ok(a, b[u]);
-                if (!one_cell) ok = ok && max(la, (int)(lw[u] & 0xFFFFu)) == ca && max(lb, (int)(lw[u] >> 16)) == cb;
-                em.push(ok, make_pair_out(emit, a.eid, b[u].eid));
-            }
-        }
+    if (diag && lane == 0) {
+        atomicAdd(&cnt->diag[0], (unsigned long long)d_blocks);
+        atomicAdd(&cnt->diag[1], (unsigned long long)d_groups);
+        atomicAdd(&cnt->diag[2], (unsigned long long)d_rounds);
+        atomicAdd(&cnt->diag[3], (unsigned long long)d_segs);
     }
-    em.flush();
+    __shared__ unsigned long long blk_scratch[3 * SW_WAVES];
+    em.flush_block(blk_scratch, tests, &cnt->cand_parts[blockIdx.x & 31u]);
 }
 
 // Plain sweep-and-prune, one thread per row, exact boxes only (the reference's baseline
 // variant sweep_and_prune<>, sweep.cu:48-99).  Kept as an in-library cross-check of the STQ
 // kernel (SCCD_OPT_SWEEP_ALGO = 1); not tuned.
-__global__ void sweep_sap_k(const sccd_aabb* __restrict__ box_r, const uint32_t* __restrict__ key_r,
-                            const uint2* __restrict__ ranges, int row_begin, int row_end,
-                            const sccd_aabb* __restrict__ box_c, const GridParams* __restrict__ gp, int emit,
-                            int2* __restrict__ out, long long capacity, SweepCounters* __restrict__ cnt)
+__global__ void sweep_sap_k(SweepRecs R, int row_begin, int row_end, SweepRecs C, int n_cols, int one,
+                            const GridParams* __restrict__ gp, int emit, int2* __restrict__ out, long long capacity,
+                            SweepCounters* __restrict__ cnt)
 {
     const int row = row_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= row_end) return;
-    const GridParams g = *gp;
-    const uint2 rg = ranges[row];
-    const ExactBox a = load_exact(box_r + row);
-    const uint32_t rk = key_r[row];
-    for (unsigned j = rg.x; j < rg.y; j++) {
-        const ExactBox b = load_exact(box_c + j);
-        if (exact_pair_ok(a, b) && owns_pair(g, rk, a, b)) {
-            const unsigned long long dst = atomicAdd(&cnt->n_pairs, 1ull);
-            if ((long long)dst < capacity) out[dst] = make_pair_out(emit, a.eid, b.eid);
+    unsigned long long tests = 0;
+    if (row < row_end) {
+        const int xb = gp->xb, Sb = gp->Sb;
+        const bool one_cell = gp->n_cells <= 1;
+        RowRegs me;
+        load_row(me, R, row);
+        const int cell = (int)((unsigned long long)me.aux.x >> xb);
+        for (unsigned j = one ? (unsigned)row + 1u : me.aux.w; j < (unsigned)n_cols; j++) {
+            RowRegs col;
+            load_row(col, C, (int)j);
+            const uint4 caux = col.aux;
+            if (caux.x > me.aux.y) break;
+            ++tests;
+            const double2 cx = col.x, ca = col.a, cb = col.b;
+            const int4 cv = col.id;
+            const bool geo = (me.x.y >= cx.x) && (me.x.x <= cx.y) && (me.a.y >= ca.x) && (me.a.x <= ca.y) && (me.b.y >= cb.x)
+                && (me.b.x <= cb.y);
+            const bool share = me.id.x == cv.x || me.id.x == cv.y || me.id.x == cv.z || me.id.y == cv.x || me.id.y == cv.y
+                || me.id.y == cv.z || me.id.z == cv.x || me.id.z == cv.y || me.id.z == cv.z;
+            const int ma = (int)max(me.aux.z & 0xFFFFu, caux.z & 0xFFFFu), mb = (int)max(me.aux.z >> 16, caux.z >> 16);
+            if (geo && !share && (one_cell || ma * Sb + mb == cell)) {
+                const unsigned long long dst = atomicAdd(&cnt->n_pairs, 1ull);
+                if ((long long)dst < capacity) out[dst] = make_pair_out(emit, me.id.w, cv.w);
+            }
         }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tests += __shfl_xor(tests, o, 64);
+    if (lane_id() == 0 && tests) atomicAdd(&cnt->cand_parts[blockIdx.x & 31u], tests);
 }
 
 } // namespace
 
-void launch_ranges(sccd_ctx* c, const SortedList* rows, const SortedList* cols, int mode, uint2* ranges,
-                   unsigned long long* d_candidates)
-{
-    if (rows->m == 0) return;
-    const int grid = (rows->m + RG_THREADS - 1) / RG_THREADS;
-    hipLaunchKernelGGL(ranges_k, dim3(grid), dim3(RG_THREADS), 0, c->stream, rows->key.as<uint32_t>(),
-                       rows->kmax.as<uint32_t>(), rows->m, cols->key.as<uint32_t>(), cols->m, mode, ranges,
-                       d_candidates);
-    SCCD_HIP(hipGetLastError());
-}
-
-void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, const GridParams* gp,
-                  const uint2* ranges, int row_begin, int row_end, int emit, int2* out, int64_t capacity,
-                  SweepCounters* d_cnt, bool direct)
+void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, const GridParams* gp, int row_begin,
+                  int row_end, int emit, int2* out, int64_t capacity, SweepCounters* d_cnt)
 {
     if (row_end <= row_begin || cols->m == 0) return;
+    const bool one = rows == cols;
+    const SweepRecs R = sweep_recs(rows), C = sweep_recs(cols);
     if (c->sweep_algo == 1) {
         const int n = row_end - row_begin;
-        hipLaunchKernelGGL(sweep_sap_k, dim3((n + 255) / 256), dim3(256), 0, c->stream, rows->box.as<sccd_aabb>(),
-                           rows->key.as<uint32_t>(), ranges, row_begin, row_end, cols->box.as<sccd_aabb>(), gp, emit,
-                           out, (long long)capacity, d_cnt);
-    } else if (direct) {
-        const int num_tiles = (row_end - row_begin + 63) / 64;
-        const int grid = std::max(1, std::min((num_tiles + SW_WAVES - 1) / SW_WAVES, c->num_cus * 4));
-        hipLaunchKernelGGL(sweep_direct_k, dim3(grid), dim3(SW_THREADS), 0, c->stream, rows->box.as<sccd_aabb>(),
-                           rows->key.as<uint32_t>(), rows->lowcell.as<uint32_t>(), ranges, row_begin, row_end,
-                           cols->box.as<sccd_aabb>(), cols->lowcell.as<uint32_t>(), gp, emit, out,
-                           (long long)capacity, d_cnt);
+        hipLaunchKernelGGL(sweep_sap_k, dim3((n + 255) / 256), dim3(256), 0, c->stream, R, row_begin, row_end, C, cols->m,
+                           one ? 1 : 0, gp, emit, out, (long long)capacity, d_cnt);
     } else {
         const int num_tiles = (row_end - row_begin + 63) / 64;
         // RESIDENT blocks only: tiles are dealt statically over the grid, so a block that has to wait
-        // for a slot doubles the tail.  128 VGPRs (launch bounds) and 40 KB of LDS -> 4 blocks per CU.
-        // (With 156 VGPRs only 3 of the 4 blocks per CU were resident: sweep 0.61 -> 0.47 ms on C4.)
-        static const int per_cu = std::getenv("SCCD_SWEEP_BLOCKS") ? std::atoi(std::getenv("SCCD_SWEEP_BLOCKS")) : 4;
-        const int grid = std::max(1, std::min((num_tiles + SW_WAVES - 1) / SW_WAVES,
-                                              c->num_cus * (c->sweep_blocks_per_cu > 0 ? c->sweep_blocks_per_cu : per_cu)));
-        hipLaunchKernelGGL(sweep_stq_k, dim3(grid), dim3(SW_THREADS), 0, c->stream, rows->filt.as<float4>(),
-                           rows->box.as<sccd_aabb>(), rows->key.as<uint32_t>(), rows->lowcell.as<uint32_t>(), ranges, row_begin,
-                           row_end, cols->filt.as<float4>(), cols->box.as<sccd_aabb>(), cols->lowcell.as<uint32_t>(), gp, emit,
-                           out, (long long)capacity, d_cnt);
+        // for a slot doubles the tail.  78 KB of LDS per block -> 2 blocks per CU; a multiple of 8 blocks (the XCD-aware deal).
+        static const int per_cu_env = std::getenv("SCCD_SWEEP_BLOCKS") ? std::atoi(std::getenv("SCCD_SWEEP_BLOCKS")) : 2;
+        const int per_cu = c->sweep_blocks_per_cu > 0 ? c->sweep_blocks_per_cu : per_cu_env;
+        int grid = std::min((num_tiles + SW_WAVES - 1) / SW_WAVES, c->num_cus * per_cu);
+        grid = std::max(8, (grid + 7) / 8 * 8);
+        // consecutive tiles per wave and deal (measured on 1M random boxes and the 1M-triangle cloth: a wave has only ~12
+        // tiles per launch, and with 2 / 4 / 8 of them in a row the deal's quantisation costs more than the shared
+        // windows save: 0.27 / 0.28 / 0.29 / 0.32 ms for chunks of 1 / 2 / 4 / 8)
+        static const int chunk_env = std::getenv("SCCD_SWEEP_CHUNK") ? std::max(1, std::atoi(std::getenv("SCCD_SWEEP_CHUNK"))) : 1;
+        const int waves = grid * SW_WAVES;
+        const int chunk = std::max(1, std::min(chunk_env, num_tiles / (2 * waves)));
+        // what the lists' vertex ids are known to be (filter_step): mesh-built lists test shared vertices in the filter
+        static const bool ids_env = !(std::getenv("SCCD_SWEEP_IDS") && std::atoi(std::getenv("SCCD_SWEEP_IDS")) == 0);
+        int kind = 0;
+        if (ids_env) {
+            if (one && rows->kind == BOX_EDGE) kind = 1;
+            else if (!one && rows->kind == BOX_VERTEX && cols->kind == BOX_FACE) kind = 2;
+            else if (!one && rows->kind == BOX_FACE && cols->kind == BOX_VERTEX) kind = 3;
+        }
+        auto go = [&](auto kernel) {
+            static const int diag = std::getenv("SCCD_SWEEP_DIAG") ? std::atoi(std::getenv("SCCD_SWEEP_DIAG")) : 0;
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(SW_THREADS), 0, c->stream, R, row_begin, row_end, C, cols->m, gp, emit,
+                               chunk, out, (long long)capacity, d_cnt, diag);
+        };
+        if (kind == 1) go(sweep_band_k<true, 1>);
+        else if (kind == 2) go(sweep_band_k<false, 2>);
+        else if (kind == 3) go(sweep_band_k<false, 3>);
+        else if (one) go(sweep_band_k<true, 0>);
+        else go(sweep_band_k<false, 0>);
     }
     SCCD_HIP(hipGetLastError());
 }
