@@ -155,6 +155,7 @@ int sccd_create(int device, sccd_ctx** out)
         SCCD_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
         c->scalars.ensure(4096);
+        SCCD_HIP(hipMemsetAsync(c->scalars.p, 0, 4096, c->stream)); // (holds a counter that is never reset: sort.hip)
         c->h_scalars.ensure(16384);
     });
     if (rc != SCCD_OK) {

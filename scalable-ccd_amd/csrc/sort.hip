@@ -115,8 +115,30 @@ __device__ __forceinline__ void wave_rank_rows_match(const uint32_t (&key)[RS_IT
 
 // ---- onesweep ---------------------------------------------------------------------------------
 constexpr int HS_THREADS = 1024; // one block per CU, sixteen waves: the loads of many waves in flight hide the HBM latency
+
+// One more key in the digit histograms of the `passes` passes.  The low digits (quantised sort coordinate) are spread: plain
+// LDS atomics.  The TOP digit of the broad phase's keys is the high bits of the box's cell, and the boxes a wave reads are
+// neighbours: when all 64 keys share it (64 atomics on one LDS word are served one after the other) one lane adds 64.
+// Digits past the key's width are not counted at all (a 24-bit key has 1.7 M zeros there: one word, fully serialised).
+// Wave-wide: every lane of the wave must call it.
+__device__ __forceinline__ void hist_add(uint32_t (*h)[256], uint32_t k, bool valid, int passes)
+{
+    for (int p = 0; p < passes - 1; p++)
+        if (valid) atomicAdd(&h[p][(k >> (8 * p)) & 255u], 1u);
+    const int p = passes - 1;
+    const uint32_t d = (k >> (8 * p)) & 255u;
+    const unsigned long long todo = __ballot(valid);
+    if (todo == 0) return;
+    const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)__builtin_ctzll(todo));
+    if (__ballot(valid && d == dl) == todo) {
+        if (lane_id() == (int)__builtin_ctzll(todo)) atomicAdd(&h[p][dl], (uint32_t)popc64(todo));
+    } else if (valid) {
+        atomicAdd(&h[p][d], 1u);
+    }
+}
+
 __global__ __launch_bounds__(HS_THREADS) void os_hist_k(const uint32_t* __restrict__ keys, long long n, uint32_t* __restrict__ partial,
-                                                        uint4* __restrict__ zero, long long zero_n)
+                                                        uint4* __restrict__ zero, long long zero_n, int passes)
 {
     // every word the passes poll (tickets + look-back status) is zeroed here, not by memsets
     for (long long i = (long long)blockIdx.x * HS_THREADS + threadIdx.x; i < zero_n; i += (long long)gridDim.x * HS_THREADS)
@@ -126,12 +148,15 @@ __global__ __launch_bounds__(HS_THREADS) void os_hist_k(const uint32_t* __restri
     __syncthreads();
     // 16 keys per thread and round (four 16-byte loads in flight per thread), rounds strided over the grid
     const long long quads = (n + 3) / 4;
-    for (long long q0 = ((long long)blockIdx.x * HS_THREADS + threadIdx.x); q0 < quads; q0 += (long long)gridDim.x * HS_THREADS * 4) {
+    const long long span = (long long)gridDim.x * HS_THREADS;
+    // (wave-uniform trip count: hist_add is a wave-wide operation)
+    for (long long q00 = (long long)blockIdx.x * HS_THREADS; q00 < quads; q00 += span * 4) {
+        const long long q0 = q00 + threadIdx.x;
         uint4 k4[4];
         int cnt4[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const long long q = q0 + (long long)r * gridDim.x * HS_THREADS;
+            const long long q = q0 + (long long)r * span;
             const long long i = q * 4;
             cnt4[r] = 0;
             k4[r] = make_uint4(0u, 0u, 0u, 0u);
@@ -151,15 +176,7 @@ __global__ __launch_bounds__(HS_THREADS) void os_hist_k(const uint32_t* __restri
         for (int r = 0; r < 4; r++) {
             const uint32_t kk[4] = { k4[r].x, k4[r].y, k4[r].z, k4[r].w };
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (j < cnt4[r]) {
-                    const uint32_t k = kk[j];
-                    atomicAdd(&h[0][k & 255u], 1u);
-                    atomicAdd(&h[1][(k >> 8) & 255u], 1u);
-                    atomicAdd(&h[2][(k >> 16) & 255u], 1u);
-                    atomicAdd(&h[3][k >> 24], 1u);
-                }
-            }
+            for (int j = 0; j < 4; j++) hist_add(h, kk[j], j < cnt4[r], passes);
         }
     }
     __syncthreads();
@@ -490,7 +507,7 @@ bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
     uint32_t* status = reinterpret_cast<uint32_t*>(base + off_status);
     // every polled word (tickets and status, contiguous) is zeroed by os_hist_k before the passes
     hipLaunchKernelGGL(os_hist_k, dim3(hist_blocks), dim3(HS_THREADS), 0, c->stream, k_in, (long long)n, partial,
-                       reinterpret_cast<uint4*>(base), (long long)((512 + status_bytes) / 16));
+                       reinterpret_cast<uint4*>(base), (long long)((512 + status_bytes) / 16), passes);
     hipLaunchKernelGGL(os_bases_k, dim3(4), dim3(1024), 0, c->stream, partial, hist_blocks, bases);
     for (int pass = 0; pass < passes; pass++) {
         static const int pass_blocks = std::getenv("SCCD_SORT_BLOCKS") ? std::atoi(std::getenv("SCCD_SORT_BLOCKS")) : 3;

@@ -24,10 +24,12 @@
 //            axes and the key test on the sort axis, from LDS.  32 steps per block, a 32-bit hit mask per lane.  (Walking
 //            the union of the 64 rows' runs with wave-uniform columns, as round 2 did, tests 64 + len columns per
 //            row for a run of len.)
-//   CONFIRM  every lane walks the hits of its own row: the column's sort-axis interval, ids and lowest cells from the
-//            LDS window, the row's in its registers: the exact sort-axis test, the 3x3 vertex-id test, the owner-cell
-//            test.  No global memory access, no cross-lane traffic.  (STQ's queue -- hits expanded into (row, column)
-//            candidates, confirmed 64 at a time -- cost more per candidate than the idle lanes of this form.)
+//   QUEUE    hit masks are expanded into a per-wave LDS queue of (row lane, column slot) candidates
+//            (one wave prefix-sum per block) -- the "tiniest queue" of STQ, 64 lanes wide.
+//   CONFIRM  whenever >= 64 candidates are queued, every lane confirms one: the column's sort-axis interval, ids and
+//            lowest cells from the LDS window, the row's from the owning lane's registers (ds_bpermute): the exact
+//            sort-axis test, the 3x3 vertex-id test (mesh-built lists: in the filter already), the owner-cell test.
+//            No global memory access.
 //   EMIT     survivors go to a per-wave LDS staging buffer; one global atomic per ~1000 pairs
 //            reserves space, then the pairs are written coalesced (the reference: two global
 //            atomics per pair, collision.cuh:45-54).
@@ -43,15 +45,17 @@ constexpr int SW_WAVES = SW_THREADS / 64;
 constexpr int SW_WIN = 128;   // column slots of a wave's window (slot = column & 127)
 constexpr int SW_SEG = 32;    // columns per staging segment = steps per filter block
 constexpr int SW_MIR = SW_SEG; // the filter's arrays repeat their first segment behind the last: a run of 32 steps never wraps
+constexpr int SW_QCAP = 256;  // candidate queue entries per wave
 constexpr int SW_OCAP = 1024; // staged output pairs per wave
 
-struct SweepLds { // per wave: 18,560 bytes; four waves per block, two blocks per CU
+struct SweepLds { // per wave: 19,584 bytes; four waves per block, two blocks per CU
     double2 a[SW_WIN + SW_MIR]; // {min, max} on minor axis a
     double2 b[SW_WIN + SW_MIR];
     uint4 x[SW_WIN];          // double2 {min, max} on the sort axis
     uint4 id[SW_WIN];         // vertex ids, element id
     uint32_t key[SW_WIN + SW_MIR];
     uint32_t low[SW_WIN];       // lowest cells
+    uint32_t q[SW_QCAP];        // candidates: row lane << 8 | column slot
     int2 o[SW_OCAP];
 };
 
@@ -345,6 +349,8 @@ __global__ __launch_bounds__(SW_THREADS, 2) void sweep_band_k(SweepRecs R, int r
     const int xb = gp->xb, Sb = max(gp->Sb, 1);
     Emitter em { L.o, 0, out, capacity, &cnt->n_pairs };
     const Stager st(L, C);
+    int qcount = 0;               // queued candidates (wave-uniform)
+    unsigned q_lo = 0;            // the window's first column when the oldest queued candidate was queued
     unsigned long long tests = 0; // candidate columns of this lane's rows (key range on the sort axis)
     const unsigned n_cols_up = ((unsigned)n_cols + (unsigned)(SW_SEG - 1)) & ~(unsigned)(SW_SEG - 1);
     const int num_tiles = (row_end - row_begin + 63) / 64;
@@ -367,6 +373,37 @@ __global__ __launch_bounds__(SW_THREADS, 2) void sweep_band_k(SweepRecs R, int r
         const int row0 = row_begin + tile * 64 + lane;
         if (tile < t_hi && row0 < row_end) load_row(nx, R, row0);
     }
+    // CONFIRM + EMIT a batch of queued candidates: the column from the LDS window, the row from the registers of the lane
+    // that owns it (ds_bpermute).  EVERY lane takes part in the moves; lanes >= n carry no candidate.
+    auto confirm_batch = [&](int n, const RowRegs& me, unsigned my_cellpack) {
+        wave_lds_fence();
+        const unsigned has = lane < n ? 1u : 0u;
+        const uint32_t e = has ? L.q[qcount - n + lane] : 0u;
+        qcount -= n;
+        const int r = (int)((e >> 8) & 63u);
+        const unsigned slot = e & (unsigned)(SW_WIN - 1);
+        const uint4 cxu = L.x[slot], cvu = L.id[slot];
+        const uint32_t clow = L.low[slot];
+        const double2 cx = as_double2(cxu);
+        const int4 cv = make_int4((int)cvu.x, (int)cvu.y, (int)cvu.z, (int)cvu.w);
+        double2 rx;
+        rx.x = __shfl(me.x.x, r, 64);
+        rx.y = __shfl(me.x.y, r, 64);
+        int4 rv = make_int4(0, 0, 0, 0);
+        if (KIND == 0) {
+            rv.x = __shfl(me.id.x, r, 64);
+            rv.y = __shfl(me.id.y, r, 64);
+            rv.z = __shfl(me.id.z, r, 64);
+        }
+        const int reid = __shfl(me.id.w, r, 64);
+        const unsigned rlow = (unsigned)__shfl((int)me.aux.z, r, 64);
+        const unsigned rcell = (unsigned)__shfl((int)my_cellpack, r, 64);
+        const unsigned long long ok = confirm_mask<KIND == 0>(has, rx, rv, rlow, rcell, cx, cv, clow);
+        em.push_mask(ok, make_pair_out(emit, reid, cv.w));
+    };
+    auto drain = [&](const RowRegs& me, unsigned my_cellpack) {
+        while (qcount > 0) confirm_batch(min(qcount, 64), me, my_cellpack);
+    };
     unsigned w_lo = 0, w_hi = 0; // columns [w_lo, w_hi) are staged (w_lo a multiple of 32, w_hi - w_lo <= 128)
     bool have = false;           // (the window survives from tile to tile inside a chunk)
     int ahead = 0;               // segments [ahead_c0, + 32 * ahead) were asked for ahead and sit in `seg`
@@ -403,6 +440,9 @@ __global__ __launch_bounds__(SW_THREADS, 2) void sweep_band_k(SweepRecs R, int r
             const unsigned need = min(n_cols_up, nlo + (unsigned)SW_WIN); // the whole window (a lane can be 96 columns ahead of the first)
             unsigned from = (have && w_hi > nlo && w_lo <= nlo) ? w_hi : nlo;
             if (from < need) {
+                // a segment [c0, c0 + 32) takes the slots of columns [c0 - 128, c0 - 96): candidates queued since the window
+                // started at q_lo may still name those
+                if (qcount > 0 && need > q_lo + (unsigned)SW_WIN) drain(me, my_cellpack);
                 // (asked for ahead: they have landed, or are about to)
                 if (ahead >= 1 && ahead_c0 == from && from < need) {
                     st.write(seg0, from);
@@ -433,9 +473,10 @@ __global__ __launch_bounds__(SW_THREADS, 2) void sweep_band_k(SweepRecs R, int r
             ++d_blocks;
             // (eight steps at a time: their 72 dwords of LDS reads are in flight together; the whole run unrolled asks for
             // more registers than a lane has.  A block ends with the longest lane's run.)
+            bool inside = true; // the lane's last tested column was still inside its key range (keys ascend: once out, out)
 #pragma unroll 1
             for (int c8 = 0; c8 < SW_SEG; c8 += 8) {
-                if (__ballot(avail > c8) == 0) break;
+                if (__ballot(inside && avail > c8) == 0) break; // the block ends with the longest run
                 ++d_groups;
                 const unsigned at = s0 + (unsigned)c8;
                 uint32_t k[8];
@@ -470,6 +511,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void sweep_band_k(SweepRecs R, int r
                 filter_step<128u, KIND>(m8, km8, k[7], kmax, ca[7], cb[7], me.a, me.b, me.id, cv[7]);
                 m |= m8 << c8;
                 km |= km8 << c8;
+                inside = (km8 & 0x80u) != 0;
             }
             const unsigned amask = avail >= 32 ? 0xFFFFFFFFu : ((1u << avail) - 1u);
             m &= amask;
@@ -497,25 +539,46 @@ __global__ __launch_bounds__(SW_THREADS, 2) void sweep_band_k(SweepRecs R, int r
                     }
                 }
             }
-            // ---- CONFIRM + EMIT: every lane walks the hits of its own row (the column from the LDS window, the row in its
-            // registers; as many rounds as the busiest lane has hits).  Round 2 queued the hits of a block as (row, column)
-            // candidates and confirmed 64 of them at a time with full lanes -- every candidate then costs a queue write, a
-            // queue read and ten cross-lane moves for its row, which is more than the idle lanes here.
-            const unsigned my_low = me.aux.z;
-            while (__ballot(m != 0) != 0) {
+            if (__ballot(m != 0) == 0) continue;
+
+            // ---- QUEUE: expand the hit masks into (row lane, column slot) candidates -- STQ's queue, 64 lanes wide.
+            // (Every lane walking the hits of its own row instead, with the row in its registers, was measured: as many
+            // rounds as the busiest lane has hits, 8 per block where the average lane has 1.4 -- the queue's full lanes win.)
+            const int mine = __popc(m);
+            unsigned total_u;
+            const int incl = (int)wave_incl_scan_dpp((unsigned)mine, &total_u);
+            const int total = (int)total_u;
+            if (qcount == 0) q_lo = w_lo;
+            if (qcount + total <= SW_QCAP) {
+                int pos = qcount + incl - mine;
+                while (m) {
+                    const int b = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    L.q[pos++] = ((uint32_t)lane << 8) | ((s0 + (unsigned)b) & (unsigned)(SW_WIN - 1));
+                }
+                qcount += total;
+            } else {
+                // crowded block: one candidate per lane per round
+                for (;;) {
+                    const bool hasm = m != 0;
+                    const unsigned long long mask = __ballot(hasm);
+                    if (mask == 0) break;
+                    while (qcount > SW_QCAP - 64) confirm_batch(64, me, my_cellpack);
+                    if (hasm) {
+                        const int b = __ffs((int)m) - 1;
+                        m &= m - 1;
+                        L.q[qcount + mbcnt64(mask)] = ((uint32_t)lane << 8) | ((s0 + (unsigned)b) & (unsigned)(SW_WIN - 1));
+                    }
+                    qcount += popc64(mask);
+                }
+            }
+            // ---- CONFIRM + EMIT full batches
+            while (qcount >= 64) {
                 ++d_rounds;
-                const unsigned has = m != 0 ? 1u : 0u;
-                const unsigned b = has ? (unsigned)__ffs((int)m) - 1u : 0u;
-                m &= m - 1u;
-                const unsigned slot = (s0 + b) & (unsigned)(SW_WIN - 1);
-                const uint4 cxu = L.x[slot], cvu = L.id[slot];
-                const uint32_t clow = L.low[slot];
-                const double2 cx = as_double2(cxu);
-                const int4 cv = make_int4((int)cvu.x, (int)cvu.y, (int)cvu.z, (int)cvu.w);
-                const unsigned long long ok = confirm_mask<KIND == 0>(has, me.x, me.id, my_low, my_cellpack, cx, cv, clow);
-                em.push_mask(ok, make_pair_out(emit, me.id.w, cv.w));
+                confirm_batch(64, me, my_cellpack);
             }
         }
+        drain(me, my_cellpack); // (the rows leave the registers)
         if (!next_follows) { // the next tile is somewhere else: its window starts from nothing
             have = false;
             ahead = 0;
