@@ -508,15 +508,26 @@ static void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline*
         pl->eb.kind = BOX_EDGE;
         pl->eb.raw.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nE, 1));
         begin_stats(pl->eb);
-        pl->eb.n_part = launch_edge_boxes(c, pl->vb.raw.as<sccd_aabb>(), m->E.as<int2>(), m->nE,
-                                          pl->eb.raw.as<sccd_aabb>(), pl->eb.stats_head(), pl->eb.stats_part());
-        pl->eb.have_stats = true;
     }
     if (want_f) {
         pl->fb.n = m->nF;
         pl->fb.kind = BOX_FACE;
         pl->fb.raw.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nF, 1));
         begin_stats(pl->fb);
+    }
+    if (want_e && want_f && m->nE > 0 && m->nF > 0) { // both in one launch
+        launch_edge_face_boxes(c, pl->vb.raw.as<sccd_aabb>(), m->E.as<int2>(), m->nE, pl->eb.raw.as<sccd_aabb>(), pl->eb.stats_head(),
+                               pl->eb.stats_part(), &pl->eb.n_part, m->F.as<int4>(), m->nF, pl->fb.raw.as<sccd_aabb>(),
+                               pl->fb.stats_head(), pl->fb.stats_part(), &pl->fb.n_part);
+        pl->eb.have_stats = pl->fb.have_stats = true;
+        return;
+    }
+    if (want_e) {
+        pl->eb.n_part = launch_edge_boxes(c, pl->vb.raw.as<sccd_aabb>(), m->E.as<int2>(), m->nE,
+                                          pl->eb.raw.as<sccd_aabb>(), pl->eb.stats_head(), pl->eb.stats_part());
+        pl->eb.have_stats = true;
+    }
+    if (want_f) {
         pl->fb.n_part = launch_face_boxes(c, pl->vb.raw.as<sccd_aabb>(), m->F.as<int4>(), m->nF,
                                           pl->fb.raw.as<sccd_aabb>(), pl->fb.stats_head(), pl->fb.stats_part());
         pl->fb.have_stats = true;
@@ -692,10 +703,8 @@ static void lists_records(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B,
         return;
     }
     if (LA->m == 0 || LB->m == 0) return;
-    launch_entry_records(c, A->raw.as<sccd_aabb>(), LA->key.as<uint32_t>(), LA->idx.as<uint32_t>(), LA->m, gp, 1,
-                         LB->key.as<uint32_t>(), LB->m, false, false, LA);
-    launch_entry_records(c, B->raw.as<sccd_aabb>(), LB->key.as<uint32_t>(), LB->idx.as<uint32_t>(), LB->m, gp, 2,
-                         LA->key.as<uint32_t>(), LA->m, false, false, LB);
+    launch_entry_records_two(c, A->raw.as<sccd_aabb>(), LA->key.as<uint32_t>(), LA->idx.as<uint32_t>(), LA->m,
+                             B->raw.as<sccd_aabb>(), LB->key.as<uint32_t>(), LB->idx.as<uint32_t>(), LB->m, /*b_tagged=*/false, gp, LA, LB);
 }
 
 // BroadPhase::build (broad_phase.cu:29-101) together with the key split + sort the reference
@@ -732,8 +741,8 @@ static void lists_finish_merged(sccd_ctx* c, const sccd_boxes* A, const sccd_box
         ProfScope ps(c, SCCD_PROF_BOXES);
         const uint32_t* keys = LA->key.as<uint32_t>();
         const uint32_t* idx = LA->idx.as<uint32_t>();
-        launch_entry_records(c, A->raw.as<sccd_aabb>(), keys, idx, (int)ma, gp, 1, keys + ma, (int)mb, false, true, LA);
-        launch_entry_records(c, B->raw.as<sccd_aabb>(), keys + ma, idx + ma, (int)mb, gp, 2, keys, (int)ma, true, false, LB);
+        launch_entry_records_two(c, A->raw.as<sccd_aabb>(), keys, idx, (int)ma, B->raw.as<sccd_aabb>(), keys + ma, idx + ma, (int)mb,
+                                 /*b_tagged=*/true, gp, LA, LB);
     }
 }
 
@@ -863,16 +872,18 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                     // separates them by the tag bit; copying list B's entries behind list A's afterwards cost two launches
                     // of the build's latency chain)
                     uint32_t* const d_place = want_merged ? d_total + 2 : nullptr;
-                    launch_cell_fill_append(c, A->raw.as<sccd_aabb>(), A->n, gp, bp->cell_lo, bp->cell_hi, d_total,
-                                            (uint32_t)((want_merged ? 2 : 1) * cap), bp->la.key.as<uint32_t>(), bp->la.idx.as<uint32_t>(),
-                                            false, d_place);
                     if (B) {
                         bp->lb.key.ensure(sizeof(uint32_t) * ((size_t)cap + pad));
                         bp->lb.idx.ensure(sizeof(uint32_t) * ((size_t)cap + pad));
-                        if (want_merged)
-                            launch_cell_fill_append(c, B->raw.as<sccd_aabb>(), B->n, gp, bp->cell_lo, bp->cell_hi, d_total + 1,
-                                                    (uint32_t)(2 * cap), bp->la.key.as<uint32_t>(), bp->la.idx.as<uint32_t>(), true, d_place);
-                        else
+                    }
+                    if (want_merged) {
+                        launch_cell_fill_append_two(c, A->raw.as<sccd_aabb>(), A->n, B->raw.as<sccd_aabb>(), B->n, gp, bp->cell_lo,
+                                                    bp->cell_hi, d_total, (uint32_t)(2 * cap), bp->la.key.as<uint32_t>(),
+                                                    bp->la.idx.as<uint32_t>());
+                    } else {
+                        launch_cell_fill_append(c, A->raw.as<sccd_aabb>(), A->n, gp, bp->cell_lo, bp->cell_hi, d_total,
+                                                (uint32_t)cap, bp->la.key.as<uint32_t>(), bp->la.idx.as<uint32_t>(), false, d_place);
+                        if (B)
                             launch_cell_fill_append(c, B->raw.as<sccd_aabb>(), B->n, gp, bp->cell_lo, bp->cell_hi, d_total + 1,
                                                     (uint32_t)cap, bp->lb.key.as<uint32_t>(), bp->lb.idx.as<uint32_t>(), false);
                     }
@@ -1019,8 +1030,7 @@ static void bp_detect_partial(sccd_broad_phase* bp, int phase = 0)
             if (!B) {
                 launch_sweep(c, A, A, gp, a_lo, a_hi, EMIT_ONE_LIST, bp->overlaps.as<int2>(), bp->capacity, d_cnt);
             } else {
-                launch_sweep(c, A, B, gp, a_lo, a_hi, EMIT_ROWS_A, bp->overlaps.as<int2>(), bp->capacity, d_cnt);
-                launch_sweep(c, B, A, gp, b_lo, b_hi, EMIT_ROWS_B, bp->overlaps.as<int2>(), bp->capacity, d_cnt);
+                launch_sweep_two(c, A, B, gp, a_lo, a_hi, b_lo, b_hi, bp->overlaps.as<int2>(), bp->capacity, d_cnt);
             }
         }
         if (phase == 1) return;
@@ -1361,6 +1371,10 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
     if (helper && presweep_env)
         start_ee_sweep = [&] {
             pl->worker.wait(); // the lists are built (long since: the build is shorter than the vertex-face broad phase)
+            // ... behind whatever this context's stream holds now (the vertex-face sweep): ordered on the DEVICE, so the
+            // edge-edge sweep starts the moment that sweep ends -- not a host round trip later
+            SCCD_HIP(hipEventRecord(c->side_event, c->stream));
+            SCCD_HIP(hipStreamWaitEvent(c->side->stream, c->side_event, 0));
             static const int side_blocks = std::getenv("SCCD_PRESWEEP_BLOCKS") ? std::max(1, std::atoi(std::getenv("SCCD_PRESWEEP_BLOCKS"))) : 2;
             c->side->sweep_blocks_per_cu = side_blocks;
             try {
@@ -1388,12 +1402,16 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
             sc->max_iter_fast = c->max_iter_fast;
             bp_build(&pl->bp, &pl->vb, &pl->fb);
             narrow_counters_upload(c, narrow_counters(c), toi);
-            bp_detect_partial(&pl->bp);
+            // the vertex-face sweep is enqueued, the edge-edge sweep behind it (on the helper's stream, by an event), and only
+            // then does the host wait for the vertex-face pairs: the narrow kernel it launches next finds the edge-edge
+            // sweep's blocks resident already and takes the rest of the chip
+            bp_detect_partial(&pl->bp, 1);
+            start_ee_sweep();
+            start_ee_sweep = nullptr;
+            bp_detect_partial(&pl->bp, 2);
             const bool vf_one_chunk = pl->bp.cursor >= pl->bp.total_rows;
             const NarrowParams pv = narrow_params(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, 1, max_iter, tol, ms, allow_zero_toi);
             if (vf_one_chunk && narrow_uses_walk_kernel(c, pv, false)) {
-                start_ee_sweep();
-                start_ee_sweep = nullptr;
                 double toi_vf = toi, toi_ee = toi;
                 narrow_phase_begin(c, pv, narrow_counters(c), &toi_vf, nullptr); // (asynchronous)
                 bp_detect_partial(&pl->bp_ee, 2);                                 // waits for the edge-edge sweep
@@ -1449,7 +1467,6 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
                     st->n_vf_checks += (int64_t)rv.n_checks;
                 }
                 ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true);
-                start_ee_sweep = nullptr;
             }
         } else {
             ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st, false, false, &start_ee_sweep);

@@ -82,7 +82,9 @@ struct StatsAcc {
         }
     }
     // every thread of the block must call this
-    __device__ __forceinline__ void finish(GridStats* __restrict__ st, double* __restrict__ part)
+    __device__ __forceinline__ void finish(GridStats* __restrict__ st, double* __restrict__ part) { finish(st, part, (int)blockIdx.x); }
+    // block: this block's index among the blocks that build THIS list
+    __device__ __forceinline__ void finish(GridStats* __restrict__ st, double* __restrict__ part, int block)
     {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -116,9 +118,9 @@ struct StatsAcc {
             // one partial per block, no atomics (nine hot words shared by every block cost more than the
             // reduction grid_setup_k does instead)
             (void)st;
-            part[blockIdx.x * 9 + k] = l;
-            part[blockIdx.x * 9 + 3 + k] = h;
-            part[blockIdx.x * 9 + 6 + k] = s;
+            part[block * 9 + k] = l;
+            part[block * 9 + 3 + k] = h;
+            part[block * 9 + 6 + k] = s;
         }
     }
 };
@@ -182,11 +184,12 @@ __device__ __forceinline__ BoxLoad load_box_geom(const sccd_aabb* b)
 }
 
 // AABB(a, b): component-wise min/max (aabb.cuh:18-29); ids aabb.cu:200-203
-__global__ void edge_boxes_k(const sccd_aabb* __restrict__ vb, const int2* __restrict__ E, int nE,
-                             sccd_aabb* __restrict__ out, GridStats* __restrict__ st, double* __restrict__ part)
+__device__ __forceinline__ void edge_boxes_body(const sccd_aabb* __restrict__ vb, const int2* __restrict__ E, int nE,
+                                                sccd_aabb* __restrict__ out, GridStats* __restrict__ st, double* __restrict__ part,
+                                                int block, int n_blocks)
 {
     StatsAcc acc;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nE; i += gridDim.x * blockDim.x) {
+    for (int i = block * (int)blockDim.x + (int)threadIdx.x; i < nE; i += n_blocks * (int)blockDim.x) {
         const int2 e = E[i];
         const BoxLoad a = load_box_geom(vb + e.x), b = load_box_geom(vb + e.y);
         double lo[3], hi[3];
@@ -198,15 +201,21 @@ __global__ void edge_boxes_k(const sccd_aabb* __restrict__ vb, const int2* __res
         store_box(out + i, lo, hi, e.x, e.y, -e.x - 1, i);
         acc.add(lo, hi);
     }
-    if (st) acc.finish(st, part);
+    if (st) acc.finish(st, part, block);
+}
+__global__ void edge_boxes_k(const sccd_aabb* __restrict__ vb, const int2* __restrict__ E, int nE,
+                             sccd_aabb* __restrict__ out, GridStats* __restrict__ st, double* __restrict__ part)
+{
+    edge_boxes_body(vb, E, nE, out, st, part, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // AABB(a, b, c) (aabb.cuh:31-42); ids aabb.cu:223-225
-__global__ void face_boxes_k(const sccd_aabb* __restrict__ vb, const int4* __restrict__ F, int nF,
-                             sccd_aabb* __restrict__ out, GridStats* __restrict__ st, double* __restrict__ part)
+__device__ __forceinline__ void face_boxes_body(const sccd_aabb* __restrict__ vb, const int4* __restrict__ F, int nF,
+                                                sccd_aabb* __restrict__ out, GridStats* __restrict__ st, double* __restrict__ part,
+                                                int block, int n_blocks)
 {
     StatsAcc acc;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nF; i += gridDim.x * blockDim.x) {
+    for (int i = block * (int)blockDim.x + (int)threadIdx.x; i < nF; i += n_blocks * (int)blockDim.x) {
         const int4 f = F[i];
         const BoxLoad a = load_box_geom(vb + f.x), b = load_box_geom(vb + f.y), c = load_box_geom(vb + f.z);
         double lo[3], hi[3];
@@ -222,7 +231,22 @@ __global__ void face_boxes_k(const sccd_aabb* __restrict__ vb, const int4* __res
         store_box(out + i, lo, hi, f.x, f.y, f.z, i);
         acc.add(lo, hi);
     }
-    if (st) acc.finish(st, part);
+    if (st) acc.finish(st, part, block);
+}
+__global__ void face_boxes_k(const sccd_aabb* __restrict__ vb, const int4* __restrict__ F, int nF,
+                             sccd_aabb* __restrict__ out, GridStats* __restrict__ st, double* __restrict__ part)
+{
+    face_boxes_body(vb, F, nF, out, st, part, (int)blockIdx.x, (int)gridDim.x);
+}
+// the edge and the face boxes of a mesh in ONE launch (both depend on the vertex boxes only; the first blocks_e blocks build
+// the edges': ccd() builds all three lists at the head of every step)
+__global__ void edge_face_boxes_k(const sccd_aabb* __restrict__ vb, const int2* __restrict__ E, int nE, sccd_aabb* __restrict__ out_e,
+                                  GridStats* __restrict__ st_e, double* __restrict__ part_e, int blocks_e,
+                                  const int4* __restrict__ F, int nF, sccd_aabb* __restrict__ out_f, GridStats* __restrict__ st_f,
+                                  double* __restrict__ part_f)
+{
+    if ((int)blockIdx.x < blocks_e) edge_boxes_body(vb, E, nE, out_e, st_e, part_e, (int)blockIdx.x, blocks_e);
+    else face_boxes_body(vb, F, nF, out_f, st_f, part_f, (int)blockIdx.x - blocks_e, (int)gridDim.x - blocks_e);
 }
 
 // ---- composite key: cell on the minor axes + quantised sort coordinate (grid.hpp) ------------
@@ -241,43 +265,46 @@ __global__ void box_stats_k(const sccd_aabb* __restrict__ raw, int n, GridStats*
 }
 
 // cell size = cell_factor x mean box extent on that axis; at most 2^10 cells in total
-__global__ void grid_setup_k(const GridStats* __restrict__ st_a, const double* __restrict__ part_a, int n_part_a,
+__global__ __launch_bounds__(SCCD_STATS_BLOCKS) void grid_setup_k(const GridStats* __restrict__ st_a, const double* __restrict__ part_a, int n_part_a,
                              const GridStats* __restrict__ st_b, const double* __restrict__ part_b, int n_part_b,
                              int n_total, int axis, double cell_factor, int shrink, GridParams* __restrict__ g,
                              uint32_t* __restrict__ cursors /* the two list cursors of the fill pass: zeroed here */,
                              int max_cells, int reserve_tag)
 {
     if (threadIdx.x < 3) cursors[threadIdx.x] = 0u; // the two list totals and the placement cursor of a merged two-list fill
-    // summed extents: lane l adds the block partials l, l + 64, ... of list A, then of list B, in
-    // that order, then a fixed shuffle tree -- the same bits on every run and every rank (one wave)
-    double sumext[3], glo[3], ghi[3];
+    // Bounds and summed extents of both lists from the builders' block partials: thread j takes partial j of list A and of
+    // list B (18 loads in flight, ONE memory round trip -- the kernel is on the critical path of every build and used to
+    // make 72 of them in a row), then a tree in LDS that adds in a FIXED order: the same bits on every run and every rank
+    // (a multi-GPU run needs identical grid parameters everywhere, which floating-point atomics would not give).
+    static_assert(SCCD_STATS_BLOCKS == 512, "grid_setup_k: one thread per block partial");
+    __shared__ double red[SCCD_STATS_BLOCKS][9];
     {
-        const int lane = lane_id();
+        const int j = threadIdx.x;
+        double v[9];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            double s = 0.0, l = TI_INF, h = -TI_INF;
-            for (int j = lane; j < n_part_a; j += 64) {
-                l = fmin(l, part_a[j * 9 + k]);
-                h = fmax(h, part_a[j * 9 + 3 + k]);
-                s += part_a[j * 9 + 6 + k];
-            }
-            for (int j = lane; j < n_part_b; j += 64) {
-                l = fmin(l, part_b[j * 9 + k]);
-                h = fmax(h, part_b[j * 9 + 3 + k]);
-                s += part_b[j * 9 + 6 + k];
-            }
+        for (int k = 0; k < 9; k++) {
+            const double dflt = k < 3 ? TI_INF : (k < 6 ? -TI_INF : 0.0);
+            const double a = (j < n_part_a) ? part_a[j * 9 + k] : dflt;
+            const double bb = (j < n_part_b) ? part_b[j * 9 + k] : dflt;
+            v[k] = k < 3 ? fmin(a, bb) : (k < 6 ? fmax(a, bb) : a + bb);
+        }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                s += __shfl_xor(s, o, 64);
-                l = fmin(l, __shfl_xor(l, o, 64));
-                h = fmax(h, __shfl_xor(h, o, 64));
+        for (int k = 0; k < 9; k++) red[j][k] = v[k];
+        __syncthreads();
+        for (int half = SCCD_STATS_BLOCKS / 2; half > 0; half >>= 1) {
+            if (j < half) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const double x = red[j][k], y = red[j + half][k];
+                    red[j][k] = k < 3 ? fmin(x, y) : (k < 6 ? fmax(x, y) : x + y);
+                }
             }
-            sumext[k] = s;
-            glo[k] = l;
-            ghi[k] = h;
+            __syncthreads();
         }
     }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double glo[3] = { red[0][0], red[0][1], red[0][2] }, ghi[3] = { red[0][3], red[0][4], red[0][5] };
+    const double sumext[3] = { red[0][6], red[0][7], red[0][8] };
     const int aa = (axis == 0) ? 1 : 0, ab = (axis == 2) ? 1 : 2;
     double lo[3], hi[3];
     (void)st_a;
@@ -434,12 +461,12 @@ __global__ void cell_hist_k(const sccd_aabb* __restrict__ raw, int n, const Grid
 // `capacity` are counted but not written (the host grows the buffers and runs the pass again).
 // place != nullptr: the entries go where a SHARED cursor says (both lists of a merged two-list sort fill one buffer, in any
 // order: the sort that follows separates them by the tag bit) while `cursor` only counts this list's entries.
-__global__ void cell_fill_append_k(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp,
-                                   int cell_lo, int cell_hi, uint32_t* __restrict__ cursor, uint32_t capacity,
-                                   uint32_t* __restrict__ key, uint32_t* __restrict__ idx, int tagged,
-                                   uint32_t* __restrict__ place)
+__device__ __forceinline__ void cell_fill_append_body(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp,
+                                                      int cell_lo, int cell_hi, uint32_t* __restrict__ cursor, uint32_t capacity,
+                                                      uint32_t* __restrict__ key, uint32_t* __restrict__ idx, int tagged,
+                                                      uint32_t* __restrict__ place, int block)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = block * (int)blockDim.x + (int)threadIdx.x;
     const GridParams g = *gp;
     const uint32_t tag = (tagged && g.tag_bit >= 0) ? (1u << g.tag_bit) : 0u; // list B of a merged two-list sort
     CellSpan s = { 0, -1, 0, -1 };
@@ -483,6 +510,26 @@ __global__ void cell_fill_append_k(const sccd_aabb* __restrict__ raw, int n, con
         }
 }
 
+__global__ void cell_fill_append_k(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp,
+                                   int cell_lo, int cell_hi, uint32_t* __restrict__ cursor, uint32_t capacity,
+                                   uint32_t* __restrict__ key, uint32_t* __restrict__ idx, int tagged,
+                                   uint32_t* __restrict__ place)
+{
+    cell_fill_append_body(raw, n, gp, cell_lo, cell_hi, cursor, capacity, key, idx, tagged, place, (int)blockIdx.x);
+}
+// both lists of a merged two-list build in ONE launch (the first blocks_a blocks: list A): they fill the same buffers by the
+// same placement cursor and only count apart
+__global__ void cell_fill_append2_k(const sccd_aabb* __restrict__ raw_a, int na, const sccd_aabb* __restrict__ raw_b, int nb,
+                                    int blocks_a, const GridParams* __restrict__ gp, int cell_lo, int cell_hi,
+                                    uint32_t* __restrict__ cursors /* [0] A, [1] B, [2] placement */, uint32_t capacity,
+                                    uint32_t* __restrict__ key, uint32_t* __restrict__ idx)
+{
+    if ((int)blockIdx.x < blocks_a)
+        cell_fill_append_body(raw_a, na, gp, cell_lo, cell_hi, cursors, capacity, key, idx, 0, cursors + 2, (int)blockIdx.x);
+    else
+        cell_fill_append_body(raw_b, nb, gp, cell_lo, cell_hi, cursors + 1, capacity, key, idx, 1, cursors + 2, (int)blockIdx.x - blocks_a);
+}
+
 // payload movement of thrust::sort_by_key (aabb.cu:107-109) as ONE gather after the index sort, fused with what
 // split_boxes derives per box (aabb.cu:40-72): the sorted 80-byte records of the sweep, five 16-byte pieces in five
 // arrays (internal.hpp).  MODE 1 / 2: this list is the row list A / B of a two-list sweep and `other` holds the sorted
@@ -495,14 +542,27 @@ __global__ void cell_fill_append_k(const sccd_aabb* __restrict__ raw, int n, con
 // hundred keys in this CU's L1).  The sweep finds the END of a row's columns itself (the first key beyond K(max)).
 // own_tagged / other_tagged: this list's / the column list's keys carry the list tag of a merged sort (grid tag_bit).
 constexpr int ER_THREADS = 1024;
+struct RecordArgs { // one list's share of a record launch
+    const sccd_aabb* raw;
+    const uint32_t *key, *idx;
+    int m;
+    int own_tagged;
+    const uint32_t* other;
+    int n_other, other_tagged;
+    uint4* recs;
+    uint32_t pstride;
+};
 template <int MODE>
-__global__ __launch_bounds__(ER_THREADS) void entry_record_k(const sccd_aabb* __restrict__ raw, const uint32_t* __restrict__ key,
-                                                             const uint32_t* __restrict__ idx, int m,
-                                                             const GridParams* __restrict__ gp, int own_tagged,
-                                                             const uint32_t* __restrict__ other, int n_other, int other_tagged,
-                                                             uint4* __restrict__ recs, uint32_t pstride)
+__device__ __forceinline__ void entry_record_body(const RecordArgs& a, const GridParams* __restrict__ gp, unsigned* s_win, int block)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const sccd_aabb* __restrict__ raw = a.raw;
+    const uint32_t* __restrict__ key = a.key;
+    const uint32_t* __restrict__ idx = a.idx;
+    const uint32_t* __restrict__ other = a.other;
+    uint4* __restrict__ recs = a.recs;
+    const int m = a.m, own_tagged = a.own_tagged, n_other = a.n_other, other_tagged = a.other_tagged;
+    const uint32_t pstride = a.pstride;
+    const int e = block * (int)blockDim.x + (int)threadIdx.x;
     const bool valid = e < m;
     const GridParams g = *gp;
     const uint32_t tag = g.tag_bit >= 0 ? (1u << g.tag_bit) : 0u;
@@ -510,10 +570,9 @@ __global__ __launch_bounds__(ER_THREADS) void entry_record_k(const sccd_aabb* __
     const uint32_t k_e = valid ? (key[e] & ~own_strip) : 0u;
     uint32_t start = (uint32_t)e + 1u;
     if (MODE != 0) {
-        __shared__ unsigned s_win[2];
         const int w = threadIdx.x >> 6;
         if (w < 2) { // wave 0: the window's lower end from the block's first key; wave 1: its upper end from the last one
-            const int e_first = blockIdx.x * blockDim.x, e_last = min(e_first + (int)blockDim.x, m) - 1;
+            const int e_first = block * (int)blockDim.x, e_last = min(e_first + (int)blockDim.x, m) - 1;
             const uint32_t v = (key[w == 0 ? e_first : e_last] & ~own_strip) | other_or;
             const unsigned at = MODE == 1 ? wave_bound_u32<false>(other, (unsigned)n_other, v)
                                           : wave_bound_u32<true>(other, (unsigned)n_other, v);
@@ -539,6 +598,20 @@ __global__ __launch_bounds__(ER_THREADS) void entry_record_k(const sccd_aabb* __
     const uint32_t kmax = cellbits | grid_qx(g, sel3d(hi, g.axis));
     const uint32_t lowcell = (uint32_t)grid_cell_a(g, sel3d(lo, g.aa)) | ((uint32_t)grid_cell_b(g, sel3d(lo, g.ab)) << 16);
     recs[(size_t)REC_AUX * pstride + e] = make_uint4(k_e, kmax, lowcell, start);
+}
+template <int MODE>
+__global__ __launch_bounds__(ER_THREADS) void entry_record_k(RecordArgs a, const GridParams* __restrict__ gp)
+{
+    __shared__ unsigned s_win[2];
+    entry_record_body<MODE>(a, gp, s_win, (int)blockIdx.x);
+}
+// both lists of a two-list build in ONE launch (the first blocks_a blocks: list A's rows; two launches in a row sat on the
+// critical path of every vertex-face pass)
+__global__ __launch_bounds__(ER_THREADS) void entry_record2_k(RecordArgs a, RecordArgs b, int blocks_a, const GridParams* __restrict__ gp)
+{
+    __shared__ unsigned s_win[2];
+    if ((int)blockIdx.x < blocks_a) entry_record_body<1>(a, gp, s_win, (int)blockIdx.x);
+    else entry_record_body<2>(b, gp, s_win, (int)blockIdx.x - blocks_a);
 }
 
 // sum and sum of squares of the box centres per axis (sort_and_sweep.cpp:176-186): per-block
@@ -627,6 +700,17 @@ int launch_face_boxes(sccd_ctx* c, const sccd_aabb* vb, const int4* F, int nF, s
     SCCD_HIP(hipGetLastError());
     return grid;
 }
+// edge and face boxes in one launch; *n_part_e / *n_part_f: block partials written per list
+void launch_edge_face_boxes(sccd_ctx* c, const sccd_aabb* vb, const int2* E, int nE, sccd_aabb* out_e, GridStats* st_e, double* part_e,
+                            int* n_part_e, const int4* F, int nF, sccd_aabb* out_f, GridStats* st_f, double* part_f, int* n_part_f)
+{
+    const int ge = std::min(grid_for(nE), SCCD_STATS_BLOCKS), gf = std::min(grid_for(nF), SCCD_STATS_BLOCKS);
+    *n_part_e = ge;
+    *n_part_f = gf;
+    hipLaunchKernelGGL(edge_face_boxes_k, dim3((unsigned)(ge + gf)), dim3(TPB), 0, c->stream, vb, E, nE, out_e, st_e, part_e, ge, F, nF,
+                       out_f, st_f, part_f);
+    SCCD_HIP(hipGetLastError());
+}
 // returns the number of block partials written to `part` (at most SCCD_STATS_BLOCKS)
 int launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st, double* part)
 {
@@ -643,7 +727,7 @@ void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a,
     // SCCD_MAX_CELLS_ENV: experiments with coarser grids (<= SCCD_MAX_CELLS)
     const char* mc = std::getenv("SCCD_MAX_CELLS");
     const int max_cells = mc ? std::max(1, std::min(SCCD_MAX_CELLS, std::atoi(mc))) : SCCD_DEFAULT_CELLS;
-    hipLaunchKernelGGL(grid_setup_k, dim3(1), dim3(64), 0, c->stream, st_a, part_a, n_part_a, st_b, part_b, n_part_b,
+    hipLaunchKernelGGL(grid_setup_k, dim3(1), dim3(SCCD_STATS_BLOCKS), 0, c->stream, st_a, part_a, n_part_a, st_b, part_b, n_part_b,
                        n_total, axis, cell_factor, shrink, g, cursors, max_cells, reserve_tag ? 1 : 0);
     SCCD_HIP(hipGetLastError());
 }
@@ -663,6 +747,15 @@ void launch_cell_fill_append(sccd_ctx* c, const sccd_aabb* raw, int n, const Gri
                        cursor, capacity, key, idx, tagged ? 1 : 0, place);
     SCCD_HIP(hipGetLastError());
 }
+void launch_cell_fill_append_two(sccd_ctx* c, const sccd_aabb* raw_a, int na, const sccd_aabb* raw_b, int nb, const GridParams* g,
+                                 int cell_lo, int cell_hi, uint32_t* cursors, uint32_t capacity, uint32_t* key, uint32_t* idx)
+{
+    const int blocks_a = (na + 1023) / 1024, blocks_b = (nb + 1023) / 1024;
+    if (blocks_a + blocks_b == 0) return;
+    hipLaunchKernelGGL(cell_fill_append2_k, dim3((unsigned)(blocks_a + blocks_b)), dim3(1024), 0, c->stream, raw_a, na, raw_b, nb,
+                       blocks_a, g, cell_lo, cell_hi, cursors, capacity, key, idx);
+    SCCD_HIP(hipGetLastError());
+}
 void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
                        uint32_t* counts)
 {
@@ -678,23 +771,37 @@ void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams
                        key, idx);
     SCCD_HIP(hipGetLastError());
 }
+static RecordArgs record_args(const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m, const uint32_t* other, int n_other,
+                              bool own_tagged, bool other_tagged, SortedList* out)
+{
+    const size_t n = ((size_t)m + SCCD_LIST_PAD + 63) & ~(size_t)63;
+    SCCD_REQUIRE(5 * n < (1ull << 28), "broad phase: too many cell entries"); // (32-bit piece offsets in units of 16 bytes)
+    out->recs.ensure(sizeof(uint4) * 5 * n);
+    out->pstride = (uint32_t)n;
+    return RecordArgs { raw, key, idx, m, own_tagged ? 1 : 0, other, n_other, other_tagged ? 1 : 0, out->recs.as<uint4>(), out->pstride };
+}
 void launch_entry_records(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,
                           const GridParams* g, int mode, const uint32_t* other, int n_other, bool own_tagged,
                           bool other_tagged, SortedList* out)
 {
     if (m == 0) return;
-    const size_t n = ((size_t)m + SCCD_LIST_PAD + 63) & ~(size_t)63;
-    SCCD_REQUIRE(5 * n < (1ull << 28), "broad phase: too many cell entries"); // (32-bit piece offsets in units of 16 bytes)
-    out->recs.ensure(sizeof(uint4) * 5 * n);
-    out->pstride = (uint32_t)n;
+    const RecordArgs a = record_args(raw, key, idx, m, other, n_other, own_tagged, other_tagged, out);
     const dim3 grid((unsigned)((m + ER_THREADS - 1) / ER_THREADS)), block(ER_THREADS);
-    auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, block, 0, c->stream, raw, key, idx, m, g, own_tagged ? 1 : 0, other, n_other, other_tagged ? 1 : 0,
-                           out->recs.as<uint4>(), out->pstride);
-    };
-    if (mode == 0) go(entry_record_k<0>);
-    else if (mode == 1) go(entry_record_k<1>);
-    else go(entry_record_k<2>);
+    if (mode == 0) hipLaunchKernelGGL(entry_record_k<0>, grid, block, 0, c->stream, a, g);
+    else if (mode == 1) hipLaunchKernelGGL(entry_record_k<1>, grid, block, 0, c->stream, a, g);
+    else hipLaunchKernelGGL(entry_record_k<2>, grid, block, 0, c->stream, a, g);
+    SCCD_HIP(hipGetLastError());
+}
+// the records of both lists of a two-list build in one launch (list A's rows look their first column up among keys_b, ...)
+void launch_entry_records_two(sccd_ctx* c, const sccd_aabb* raw_a, const uint32_t* key_a, const uint32_t* idx_a, int ma,
+                              const sccd_aabb* raw_b, const uint32_t* key_b, const uint32_t* idx_b, int mb, bool b_tagged,
+                              const GridParams* g, SortedList* out_a, SortedList* out_b)
+{
+    if (ma == 0 || mb == 0) return;
+    const RecordArgs a = record_args(raw_a, key_a, idx_a, ma, key_b, mb, false, b_tagged, out_a);
+    const RecordArgs b = record_args(raw_b, key_b, idx_b, mb, key_a, ma, b_tagged, false, out_b);
+    const int blocks_a = (ma + ER_THREADS - 1) / ER_THREADS, blocks_b = (mb + ER_THREADS - 1) / ER_THREADS;
+    hipLaunchKernelGGL(entry_record2_k, dim3((unsigned)(blocks_a + blocks_b)), dim3(ER_THREADS), 0, c->stream, a, b, blocks_a, g);
     SCCD_HIP(hipGetLastError());
 }
 

@@ -100,6 +100,9 @@ int launch_face_boxes(sccd_ctx* c, const sccd_aabb* vb, const int4* F, int nF, s
                       double* part = nullptr);
 struct GridStats;
 struct GridParams;
+// edge and face boxes in one launch (nE, nF > 0); *n_part_e / *n_part_f: block partials written per list
+void launch_edge_face_boxes(sccd_ctx* c, const sccd_aabb* vb, const int2* E, int nE, sccd_aabb* out_e, GridStats* st_e, double* part_e,
+                            int* n_part_e, const int4* F, int nF, sccd_aabb* out_f, GridStats* st_f, double* part_f, int* n_part_f);
 int launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st, double* part);
 void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a, int n_part_a, const GridStats* st_b,
                        const double* part_b, int n_part_b, int n_total, int axis, double cell_factor, int shrink,
@@ -108,6 +111,9 @@ void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams
 void launch_cell_fill_append(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
                              uint32_t* cursor, uint32_t capacity, uint32_t* key, uint32_t* idx, bool tagged = false,
                              uint32_t* place = nullptr);
+// both lists of a merged two-list build in one launch: cursors[0] / [1] count list A's / B's entries, cursors[2] places both
+void launch_cell_fill_append_two(sccd_ctx* c, const sccd_aabb* raw_a, int na, const sccd_aabb* raw_b, int nb, const GridParams* g,
+                                 int cell_lo, int cell_hi, uint32_t* cursors, uint32_t capacity, uint32_t* key, uint32_t* idx);
 void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
                        uint32_t* counts);
 void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
@@ -115,6 +121,10 @@ void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams
 // the sorted records of one list from its sorted (key, box index) pairs.  mode 0: one list; 1 / 2: this list is the
 // row list A / B of a two-list sweep and `other` are the sorted keys of the column list (tagged like the merged sort left
 // them): every record also gets its first candidate column (sweep.hip: the three sweep classes)
+// both lists of a two-list build in one launch (b_tagged: list B's keys carry the list tag of a merged sort)
+void launch_entry_records_two(sccd_ctx* c, const sccd_aabb* raw_a, const uint32_t* key_a, const uint32_t* idx_a, int ma,
+                              const sccd_aabb* raw_b, const uint32_t* key_b, const uint32_t* idx_b, int mb, bool b_tagged,
+                              const GridParams* g, SortedList* out_a, SortedList* out_b);
 // own_tagged / other_tagged: this list's / the column list's keys carry the list tag of a merged sort
 void launch_entry_records(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,
                           const GridParams* g, int mode, const uint32_t* other, int n_other, bool own_tagged,
@@ -143,6 +153,9 @@ static_assert(sizeof(SweepCounters) == 512, "SweepCounters: keep the size a mult
 // rows [row_begin, row_end) of `rows` against the columns of `cols` (rows == cols: one list)
 void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, const GridParams* gp, int row_begin,
                   int row_end, int emit, int2* out, int64_t capacity, SweepCounters* d_cnt);
+// both classes of a two-list sweep: rows [a_begin, a_end) of A against B and rows [b_begin, b_end) of B against A
+void launch_sweep_two(sccd_ctx* c, const SortedList* A, const SortedList* B, const GridParams* gp, int a_begin, int a_end,
+                      int b_begin, int b_end, int2* out, int64_t capacity, SweepCounters* d_cnt);
 
 // narrow.hip
 struct NarrowParams {

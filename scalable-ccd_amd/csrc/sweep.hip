@@ -336,14 +336,14 @@ __device__ __forceinline__ void filter_step(unsigned& m, unsigned& km, uint32_t 
 
 // ONE: rows and columns are the same list and a row's first column is the row behind it
 // chunk: consecutive tiles a wave sweeps in a row (inside a chunk the window just moves on).
+// block / n_blocks: this block's place among the blocks that sweep THIS class (a launch can sweep two classes: below)
 template <bool ONE, int KIND>
-__global__ __launch_bounds__(SW_THREADS, 2) void sweep_band_k(SweepRecs R, int row_begin, int row_end, SweepRecs C, int n_cols,
-                                                              const GridParams* __restrict__ gp, int emit, int chunk,
-                                                              int2* __restrict__ out, long long capacity,
-                                                              SweepCounters* __restrict__ cnt, int diag)
+__device__ __forceinline__ void sweep_band_body(SweepLds* lds_s, unsigned long long* blk_scratch, const SweepRecs& R, int row_begin,
+                                                int row_end, const SweepRecs& C, int n_cols, const GridParams* __restrict__ gp,
+                                                int emit, int chunk, int2* __restrict__ out, long long capacity,
+                                                SweepCounters* __restrict__ cnt, int diag, unsigned block, unsigned n_blocks)
 {
     unsigned d_blocks = 0, d_groups = 0, d_rounds = 0, d_segs = 0; // wave-uniform (SCCD_SWEEP_DIAG)
-    __shared__ SweepLds lds_s[SW_WAVES];
     const int lane = lane_id(), w = threadIdx.x >> 6;
     SweepLds& L = lds_s[w];
     const int xb = gp->xb, Sb = max(gp->Sb, 1);
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(SW_THREADS, 2) void sweep_band_k(SweepRecs R, int r
     // atomics/us chip-wide), XCD-AWARE: blocks go to the eight XCDs in turn, and XCD x sweeps the x-th eighth of the
     // tiles with its blocks' waves on neighbouring chunks -- their column windows meet in that XCD's L2.  (Nothing
     // depends on which XCD a block lands on.)
-    const int xcd = (int)(blockIdx.x & 7u), bi = (int)(blockIdx.x >> 3), nbx = (int)(gridDim.x >> 3);
+    const int xcd = (int)(block & 7u), bi = (int)(block >> 3), nbx = (int)(n_blocks >> 3);
     const int tpx = (num_tiles + 7) >> 3;
     const int t_lo = xcd * tpx, t_hi = min(num_tiles, (xcd + 1) * tpx);
     const int ch_stride = nbx * SW_WAVES * chunk; // tiles between a wave's chunks
@@ -592,8 +592,38 @@ __global__ __launch_bounds__(SW_THREADS, 2) void sweep_band_k(SweepRecs R, int r
         atomicAdd(&cnt->diag[2], (unsigned long long)d_rounds);
         atomicAdd(&cnt->diag[3], (unsigned long long)d_segs);
     }
-    __shared__ unsigned long long blk_scratch[3 * SW_WAVES];
     em.flush_block(blk_scratch, tests, &cnt->cand_parts[blockIdx.x & 31u]);
+}
+
+template <bool ONE, int KIND>
+__global__ __launch_bounds__(SW_THREADS, 2) void sweep_band_k(SweepRecs R, int row_begin, int row_end, SweepRecs C, int n_cols,
+                                                              const GridParams* __restrict__ gp, int emit, int chunk,
+                                                              int2* __restrict__ out, long long capacity,
+                                                              SweepCounters* __restrict__ cnt, int diag)
+{
+    __shared__ SweepLds lds_s[SW_WAVES];
+    __shared__ unsigned long long blk_scratch[3 * SW_WAVES];
+    sweep_band_body<ONE, KIND>(lds_s, blk_scratch, R, row_begin, row_end, C, n_cols, gp, emit, chunk, out, capacity, cnt, diag,
+                               blockIdx.x, gridDim.x);
+}
+
+// Both classes of a two-list sweep in ONE launch: every block sweeps its share of rows A against columns B, then its share
+// of rows B against columns A -- two launches in a row cost a launch gap and a second ramp-up and tail on the critical
+// path of every vertex-face pass.  (Splitting the BLOCKS between the classes by their numbers of tiles was measured:
+// a vertex row and a face row do not cost the same, the lighter class's blocks idle: 135 us against 111 for two launches.)
+template <int KIND_A, int KIND_B>
+__global__ __launch_bounds__(SW_THREADS, 2) void sweep_band2_k(SweepRecs A, int a_begin, int a_end, int n_a, SweepRecs B, int b_begin,
+                                                               int b_end, int n_b, const GridParams* __restrict__ gp, int chunk_a,
+                                                               int chunk_b, int2* __restrict__ out, long long capacity,
+                                                               SweepCounters* __restrict__ cnt, int diag)
+{
+    __shared__ SweepLds lds_s[SW_WAVES];
+    __shared__ unsigned long long blk_scratch[3 * SW_WAVES];
+    sweep_band_body<false, KIND_A>(lds_s, blk_scratch, A, a_begin, a_end, B, n_b, gp, EMIT_ROWS_A, chunk_a, out, capacity, cnt, diag,
+                                   blockIdx.x, gridDim.x);
+    __syncthreads(); // (the scratch words of the class's last flush)
+    sweep_band_body<false, KIND_B>(lds_s, blk_scratch, B, b_begin, b_end, A, n_a, gp, EMIT_ROWS_B, chunk_b, out, capacity, cnt, diag,
+                                   blockIdx.x, gridDim.x);
 }
 
 // Plain sweep-and-prune, one thread per row, exact boxes only (the reference's baseline
@@ -680,5 +710,34 @@ void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, c
         else if (one) go(sweep_band_k<true, 0>);
         else go(sweep_band_k<false, 0>);
     }
+    SCCD_HIP(hipGetLastError());
+}
+
+// Both classes of a two-list sweep (rows A x columns B, rows B x columns A) in one launch.
+void launch_sweep_two(sccd_ctx* c, const SortedList* A, const SortedList* B, const GridParams* gp, int a_begin, int a_end,
+                      int b_begin, int b_end, int2* out, int64_t capacity, SweepCounters* d_cnt)
+{
+    const int tiles_a = std::max(0, (a_end - a_begin + 63) / 64), tiles_b = std::max(0, (b_end - b_begin + 63) / 64);
+    static const bool fuse_env = !(std::getenv("SCCD_SWEEP_FUSE") && std::atoi(std::getenv("SCCD_SWEEP_FUSE")) == 0);
+    if (c->sweep_algo == 1 || !fuse_env || tiles_a == 0 || tiles_b == 0 || A->m == 0 || B->m == 0) {
+        launch_sweep(c, A, B, gp, a_begin, a_end, EMIT_ROWS_A, out, capacity, d_cnt);
+        launch_sweep(c, B, A, gp, b_begin, b_end, EMIT_ROWS_B, out, capacity, d_cnt);
+        return;
+    }
+    static const int per_cu_env = std::getenv("SCCD_SWEEP_BLOCKS") ? std::atoi(std::getenv("SCCD_SWEEP_BLOCKS")) : 2;
+    const int per_cu = c->sweep_blocks_per_cu > 0 ? c->sweep_blocks_per_cu : per_cu_env;
+    const int tiles = std::max(tiles_a, tiles_b);
+    int grid = std::min((tiles + SW_WAVES - 1) / SW_WAVES, c->num_cus * per_cu);
+    grid = std::max(8, (grid + 7) / 8 * 8);
+    static const bool ids_env = !(std::getenv("SCCD_SWEEP_IDS") && std::atoi(std::getenv("SCCD_SWEEP_IDS")) == 0);
+    const bool vf = ids_env && A->kind == BOX_VERTEX && B->kind == BOX_FACE;
+    static const int diag = std::getenv("SCCD_SWEEP_DIAG") ? std::atoi(std::getenv("SCCD_SWEEP_DIAG")) : 0;
+    const SweepRecs RA = sweep_recs(A), RB = sweep_recs(B);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(SW_THREADS), 0, c->stream, RA, a_begin, a_end, A->m, RB, b_begin, b_end, B->m, gp,
+                           1, 1, out, (long long)capacity, d_cnt, diag);
+    };
+    if (vf) go(sweep_band2_k<2, 3>);
+    else go(sweep_band2_k<0, 0>);
     SCCD_HIP(hipGetLastError());
 }
