@@ -539,6 +539,27 @@ def test_ccd_matches_golden(sccd, ctx, name, arith):
     assert st["n_vf_pairs"] == G["n_vf"] and st["n_ee_pairs"] == G["n_ee"]
 
 
+@pytest.mark.parametrize("arith", [0, 1])
+def test_golden_case_that_tells_the_arithmetic_contracts_apart(sccd, ctx, arith):
+    """Every other golden case has toi_fma == toi_strict: a build whose fused path were silently off would pass them.  In
+    this one (tests/golden/make_contract_case.py) the minimum separation sits where the two contracts decide differently."""
+    G = json.load(open(GOLDEN))["contract_split"]
+    V0 = np.array([[float.fromhex(x) for x in r] for r in G["V0"]])
+    V1 = np.array([[float.fromhex(x) for x in r] for r in G["V1"]])
+    E, F, ms = np.array(G["E"], np.int32), np.array(G["F"], np.int32), float.fromhex(G["ms"])
+    assert G["toi_strict"] != G["toi_fma"]
+    ctx.set_option(sccd.OPT_ARITH, arith)
+    try:
+        toi = sccd.ccd(V0, V1, E, F, ms, -1, 1e-6, True, ctx=ctx)
+        ctx.set_option(sccd.OPT_NARROW_ALGO, 1)  # ... and the level-order kernels
+        toi_level = sccd.ccd(V0, V1, E, F, ms, -1, 1e-6, True, ctx=ctx)
+    finally:
+        ctx.set_option(sccd.OPT_ARITH, 0)
+        ctx.set_option(sccd.OPT_NARROW_ALGO, 0)
+    want = float.fromhex(G["toi_fma" if arith else "toi_strict"])
+    assert toi == want and toi_level == want
+
+
 @pytest.mark.parametrize("seed", list(range(12)))
 def test_randomised_scenes_against_the_oracle(sccd, ctx, orc, seed):
     """Triangle soups and cloth-ball scenes with seeded random size, density, motion, minimum

@@ -277,3 +277,20 @@ def test_f32_traversal_orders_agree_and_track_the_double_result(orc):
         assert t_a == t_b and (nvf, nee) == (nvf_b, nee_b)
         assert nvf >= nvf64 and nee >= nee64
         assert abs(t_a - t64) < 1e-3 and t_a == float(np.float32(t_a))
+
+
+def test_golden_case_that_tells_the_arithmetic_contracts_apart():
+    """tests/golden/make_contract_case.py placed a minimum separation where the strict and the fused evaluation of
+    root_finder.cu:137-198 decide differently: the two expected values differ, and the oracle reproduces each."""
+    import json
+
+    import orc
+
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.json")))["contract_split"]
+    V0 = np.array([[float.fromhex(x) for x in r] for r in G["V0"]])
+    V1 = np.array([[float.fromhex(x) for x in r] for r in G["V1"]])
+    E, F, ms = np.array(G["E"], np.int32), np.array(G["F"], np.int32), float.fromhex(G["ms"])
+    want = {0: float.fromhex(G["toi_strict"]), 1: float.fromhex(G["toi_fma"])}
+    assert want[0] != want[1]
+    for arith in (0, 1):
+        assert orc.ccd(V0, V1, E, F, ms, -1, 1e-6, True, arith=arith)[0] == want[arith]
