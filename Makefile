@@ -8,7 +8,7 @@ OUT     := scalable-ccd_amd/sccd/libsccd_hip.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
             -Wall -Wextra -Wno-unused-parameter -Wno-unused-function -Wno-missing-field-initializers
 SRCS    := $(CSRC)/api.hip $(CSRC)/boxes.hip $(CSRC)/scan.hip $(CSRC)/sort.hip $(CSRC)/sweep.hip $(CSRC)/narrow.hip
-OBJS    := $(SRCS:.hip=.o)
+OBJS    := $(SRCS:.hip=.o) $(CSRC)/ti_census.o
 CPPTEST := tests/cpp/test_ccd_api
 HDRS    := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inc) include/sccd.h
 
@@ -18,6 +18,10 @@ all: $(OUT) oracle $(CPPTEST) $(WALKPROBE)
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+# host-only: one query's bisection in level order (the certificate of a check limit); same contract flags as the kernels
+$(CSRC)/ti_census.o: $(CSRC)/ti_census.cpp $(CSRC)/ti_math.hpp
+	g++ -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra -Wno-unknown-pragmas -c $< -o $@
 
 $(OUT): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -pthread -o $@ $(OBJS)

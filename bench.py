@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--cloth-n", type=int, default=708, help="cloth grid side for cloth1m (708 -> 999,698 tris)")
     ap.add_argument("--arith", type=int, default=0, help="0 strict, 1 fused multiply-add contract")
     ap.add_argument("--sweep-algo", type=int, default=0, help="0 auto, 1 plain SAP, 2 filter/queue/confirm, 3 direct")
+    ap.add_argument("--max-iter", type=int, default=-1, help="Tight-Inclusion check limit per query (the IPC Toolkit passes 10000000); -1: none")
+    ap.add_argument("--limit-level-order", action="store_true", help="SCCD_OPT_LIMIT_LEVEL_ORDER: check limits on the level-synchronous kernels (round 2's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="cloth side of the CPU sample (0 = auto)")
     return ap.parse_args()
@@ -131,7 +133,9 @@ def main():
         torch.cuda.synchronize()
         mesh = sccd.Mesh(tV0.data_ptr(), tV1.data_ptr(), tE.data_ptr(), tF.data_ptr(), ctx=ctx, on_device=True,
                          nV=len(V0), nE=len(E), nF=len(F))
-        params = dict(min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow_zero_toi=True)
+        params = dict(min_distance=0.0, max_iterations=args.max_iter, tolerance=1e-6, allow_zero_toi=True)
+        if args.limit_level_order:
+            ctx.set_option(sccd.OPT_LIMIT_LEVEL_ORDER, 1)
 
         def step():
             # one ccd() per rank on its shard of the cell grid (SHARD_RANK / SHARD_COUNT options of the context),

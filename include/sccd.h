@@ -86,10 +86,11 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        cast to float first, boxes / tolerances / inclusion function / TOI are float arithmetic
                                        (values travel widened in the same double-typed interfaces); narrow phase on the
                                        level-synchronous kernels (bit-equal to the oracle's float twin on the GPU, tests/test_gpu_parity.py) */
-#define SCCD_OPT_MAX_ITER_FAST 12   /* check limits (max_iter >= 0): 0 (default) level-synchronous kernels -- the reference's
-                                       own order, in which alone its per-query check count (root_finder.cu:287-305) is
-                                       defined; 1: limits >= 4096 on the depth-first work-queue kernel, equal whenever no
-                                       query comes near the limit, otherwise conservative (TOI <= the reference's)          */
+#define SCCD_OPT_LIMIT_LEVEL_ORDER 12 /* check limits (max_iter >= 0, root_finder.cu:287-305): 0 (default) the fast kernel runs
+                                       * without the limit and the library proves that the limit would not have changed the
+                                       * answer (one query redone in the reference's level order on the host), falling back to the
+                                       * level-synchronous kernels where the proof fails; 1: level-synchronous kernels always
+                                       * (cross-check).  Either way the result is that of the reference's level order. */
 int sccd_set_option(sccd_ctx* ctx, int option, int64_t value);
 int64_t sccd_get_option(const sccd_ctx* ctx, int option);
 

@@ -231,7 +231,7 @@ int sccd_set_option(sccd_ctx* c, int opt, int64_t v)
     case SCCD_OPT_MAX_OVERLAP_CUTOFF: c->max_overlap_cutoff = v; break;
     case SCCD_OPT_MEMORY_LIMIT_MB: c->memory_limit_mb = v; break;
     case SCCD_OPT_SCALAR: c->scalar_f32 = v ? 1 : 0; break;
-    case SCCD_OPT_MAX_ITER_FAST: c->max_iter_fast = v ? 1 : 0; break;
+    case SCCD_OPT_LIMIT_LEVEL_ORDER: c->limit_level_order = v ? 1 : 0; break;
     default: c->err = "unknown option"; return SCCD_E_INVALID;
     }
     return SCCD_OK;
@@ -252,7 +252,7 @@ int64_t sccd_get_option(const sccd_ctx* c, int opt)
     case SCCD_OPT_MAX_OVERLAP_CUTOFF: return c->max_overlap_cutoff;
     case SCCD_OPT_MEMORY_LIMIT_MB: return c->memory_limit_mb;
     case SCCD_OPT_SCALAR: return c->scalar_f32;
-    case SCCD_OPT_MAX_ITER_FAST: return c->max_iter_fast;
+    case SCCD_OPT_LIMIT_LEVEL_ORDER: return c->limit_level_order;
     default: return 0;
     }
 }
@@ -1394,12 +1394,14 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
     static const bool beside_env = !(std::getenv("SCCD_NARROW_BESIDE") && std::atoi(std::getenv("SCCD_NARROW_BESIDE")) == 0);
     bool both_done = false;
     try {
-        if (helper && presweep_env && beside_env && c->max_overlap_cutoff == 0) {
+        // (a check limit: each pass proves on its own that the limit did not matter -- narrow.hip, the certificate -- which needs
+        // the pass's own running TOI: the passes stay in sequence)
+        if (helper && presweep_env && beside_env && c->max_overlap_cutoff == 0 && max_iter < 0) {
             sccd_ctx* const sc = c->side;
             sc->arith = c->arith;
             sc->scalar_f32 = c->scalar_f32;
             sc->narrow_algo = c->narrow_algo;
-            sc->max_iter_fast = c->max_iter_fast;
+            sc->limit_level_order = c->limit_level_order;
             bp_build(&pl->bp, &pl->vb, &pl->fb);
             narrow_counters_upload(c, narrow_counters(c), toi);
             // the vertex-face sweep is enqueued, the edge-edge sweep behind it (on the helper's stream, by an event), and only

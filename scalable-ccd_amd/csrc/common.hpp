@@ -103,7 +103,7 @@ struct sccd_ctx {
     int profile = 0;
     int scalar_f32 = 0; // SCCD_OPT_SCALAR: 1 = the reference's float build
     int sweep_blocks_per_cu = 0; // 0 = the sweep kernel's own choice (a full CU); ccd()'s helper context sweeps with half
-    int max_iter_fast = 0; // SCCD_OPT_MAX_ITER_FAST: 1 = check limits >= 4096 on the depth-first kernel (conservative)
+    int limit_level_order = 0; // SCCD_OPT_LIMIT_LEVEL_ORDER: 1 = every check limit on the level-synchronous kernels (cross-check)
     // narrow_counters_upload() already put {zeros, this TOI} into the narrow phase's counters (it rides ahead of
     // the sweep in ccd(), so that the narrow kernel can start right behind the sweep's read-back)
     bool np_uploaded = false;
@@ -111,6 +111,9 @@ struct sccd_ctx {
     // a narrow-phase launch of ANOTHER context that shares this one's TOI word is running on that stream: before this
     // context resets its counters (fallback paths) it waits for it
     hipStream_t np_peer_stream = nullptr;
+    // a narrow-phase call with a check limit that runs on the fast kernel (narrow.hip: the certificate): the TOI it started from
+    bool np_limit_fast = false;
+    double np_toi_init = 0;
     int64_t max_overlap_cutoff = 0;
     int64_t memory_limit_mb = 0;
 

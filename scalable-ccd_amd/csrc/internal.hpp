@@ -187,7 +187,9 @@ struct NarrowCounters {
     unsigned int overflow;
     unsigned int n_ovf; // queries np_walk_k handed to the level-synchronous path (entries of its overflow list)
     unsigned long long toi_level; // level-synchronous kernels with a check limit: the TOI as of the start of the level
-    unsigned long long pad3[13];
+    unsigned int n_arg;           // np_walk_k with a check limit: (query, time) records of the lanes that lowered the TOI (narrow.hip: the certificate)
+    unsigned int pad_arg;
+    unsigned long long pad3[12];
     // occupancy diagnostics of np_walk_k (SCCD_NP_DIAG=1 prints them)
     unsigned long long wave_steps;   // check steps executed by waves
     unsigned long long lane_steps;   // live lanes summed over those steps
@@ -218,4 +220,7 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
 void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
                       double* d_per_query_toi);
 bool narrow_uses_walk_kernel(const sccd_ctx* c, const NarrowParams& p, bool per_query); // (else: level-synchronous kernels)
+// ti_census.cpp (host): ONE query bisected alone in the reference's level order with the check limit
+double ti_census_level_order(const double v[8][3], int is_vf, int arith, double ms, double tol, int max_iter, int allow_zero_toi,
+                             double toi_init, long long max_live, bool* gave_up);
 void narrow_selftest_lds_gather(sccd_ctx* c, const double* d_V, const int* d_perm, int n_waves, int n_active, double* d_out);

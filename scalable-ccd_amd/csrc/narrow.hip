@@ -314,6 +314,29 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
     }
 }
 
+// ---- the certificate of a check limit (narrow_phase_end) -------------------------------------------------
+// among the (query, time) records np_walk_k left, the smallest query number whose time is the final TOI
+__global__ void np_argmin_k(const int* __restrict__ rec, unsigned n_rec, const unsigned long long* __restrict__ toi_word,
+                            unsigned* __restrict__ best)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    const unsigned long long t = __hip_atomic_load(toi_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)rec[3 * i + 1] == (unsigned)t && (unsigned)rec[3 * i + 2] == (unsigned)(t >> 32)) atomicMin(best, (unsigned)rec[3 * i]);
+}
+// that query's vertices (narrow_phase.cu:41-67), for the host
+template <bool VF>
+__global__ void np_fetch_query_k(const double* __restrict__ V, const int2* __restrict__ E, const int4* __restrict__ F,
+                                 const int2* __restrict__ pairs, long long n, const unsigned* __restrict__ best, double* __restrict__ out)
+{
+    const unsigned qid = *best;
+    if (qid >= (unsigned long long)n) return;
+    double v[8][3];
+    ti_gather<VF>(V, E, F, pairs[qid], v);
+    for (int a = 0; a < 8; a++)
+        for (int k = 0; k < 3; k++) out[3 * a + k] = v[a][k];
+}
+
 } // namespace
 
 #include "narrow_walk.inc"
@@ -335,8 +358,9 @@ void narrow_counters_upload(sccd_ctx* c, NarrowCounters* d_cnt, double toi)
 bool narrow_uses_walk_kernel(const sccd_ctx* c, const NarrowParams& p, bool per_query)
 {
     (void)per_query;
+    // (check limits below SCCD_QUEUE_MIN_MAX_ITER cut queries off as a rule: straight to level order)
     return !(c->narrow_algo == 1 || c->scalar_f32 // (the work-queue kernel is double only)
-             || (p.max_iter >= 0 && (p.max_iter < SCCD_QUEUE_MIN_MAX_ITER || !c->max_iter_fast)));
+             || (p.max_iter >= 0 && (p.max_iter < SCCD_QUEUE_MIN_MAX_ITER || per_query || c->limit_level_order)));
 }
 
 void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, const double* h_toi_inout,
@@ -353,12 +377,13 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
     const long long n = p.n_pairs;
     if (run && n > 0) {
         ProfScope ps(c, p.is_vf ? SCCD_PROF_NARROW_VF : SCCD_PROF_NARROW_EE);
-        // A check limit (max_iter >= 0) is exact only in the reference's level order: it counts the domains of a
-        // query as the breadth-first launches pop them (root_finder.cu:287-305), several times what a depth-first
-        // walk with pruning checks.  Such calls therefore run on the level-synchronous kernels.  SCCD_OPT_MAX_ITER_FAST
-        // = 1 (opt-in) serves limits >= 4096 with the work-queue kernel instead: it counts depth-first checks per
-        // lane and falls back to level order if a count passes the limit -- equal to the reference whenever no
-        // query comes near the limit (the IPC Toolkit passes 1e7), otherwise conservative (TOI <= the reference's).
+        // A check limit (max_iter >= 0: the IPC Toolkit passes 10^7) is defined in the reference's LEVEL ORDER: it counts the
+        // domains of a query as the breadth-first launches pop them (root_finder.cu:287-305), several times what a
+        // depth-first walk with pruning checks.  Round 2 ran every such call on the level-synchronous kernels: 35.6 ms for
+        // the 1M-triangle cloth against 1.35 ms without a limit.  Now the fast kernel runs WITHOUT the limit and
+        // narrow_phase_end proves that the limit could not have changed the answer (ti_census.cpp: "the certificate");
+        // only where that proof fails -- and for limits below 4096, per-query output and the float build -- the call is
+        // (re)done in level order, bit-equal to the oracle's level-order restatement either way.
         const bool level_sync = !narrow_uses_walk_kernel(c, p, d_per_query_toi != nullptr);
         if (level_sync) {
             if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi);
@@ -369,7 +394,15 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
                                    reinterpret_cast<unsigned long long*>(d_per_query_toi), n, 0x7FF0000000000000ull);
                 SCCD_HIP(hipGetLastError());
             }
-            if (d_per_query_toi || p.max_iter >= 0) { // (bookkeeping kernels: they can list queries beyond level 31 themselves)
+            if (p.max_iter >= 0) { // the fast kernel WITHOUT the limit, recording who lowered the TOI (behind the overflow list)
+                const unsigned cap = (unsigned)std::min<long long>(std::max<long long>(n, 1024), 1 << 20);
+                c->np_scratch3_ovf.ensure(sizeof(int) * 4 * (size_t)cap + 256);
+                NarrowParams pn = p;
+                pn.max_iter = -2;
+                c->np_limit_fast = true;
+                c->np_toi_init = *h_toi_inout;
+                run_walk(c, pn, d_cnt, n, nullptr, c->np_scratch3_ovf.as<int>(), cap);
+            } else if (d_per_query_toi) { // (bookkeeping kernels: they can list queries beyond level 31 themselves)
                 const unsigned cap = (unsigned)std::min<long long>(n, 1 << 20);
                 c->np_scratch3_ovf.ensure(sizeof(int) * (size_t)cap);
                 run_walk(c, p, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi), c->np_scratch3_ovf.as<int>(), cap);
@@ -396,6 +429,59 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
         if (p.toi_word) h.toi_bits = toi_elsewhere;
     }
     for (int k = 0; k < 8; k++) h.n_checks += h.checks_part[k].n; // (the work-queue kernel counts in stripes)
+    if (c->np_limit_fast) {
+        // ---- the certificate (ti_census.cpp).  T* = h.toi_bits is the earliest accept of the full bisection trees; the
+        // limited level-order run of the reference returns T* too if the query that holds it, bisected ALONE in level
+        // order WITH the limit, still reaches it.  Otherwise -- or if anything about the fast pass was irregular -- the
+        // call is redone in level order from the TOI it started with.
+        c->np_limit_fast = false;
+        const double toi_init = c->np_toi_init;
+        double t_star;
+        std::memcpy(&t_star, &h.toi_bits, 8);
+        const unsigned cap = (unsigned)std::min<long long>(std::max<long long>(n, 1024), 1 << 20);
+        bool certified = false;
+        if (!h.overflow && !h.n_ovf) {
+            if (!(t_star < toi_init)) certified = true; // nothing was accepted below the TOI the call started with
+            else if (h.n_arg <= cap && h.n_arg > 0) {
+                int* const rec = c->np_scratch3_ovf.as<int>() + cap;
+                unsigned* const d_best = reinterpret_cast<unsigned*>(c->np_scratch3_ovf.as<int>() + 4 * (size_t)cap);
+                double* const d_v = reinterpret_cast<double*>(d_best + 2);
+                SCCD_HIP(hipMemsetAsync(d_best, 0xFF, sizeof(unsigned), c->stream));
+                hipLaunchKernelGGL(np_argmin_k, dim3((h.n_arg + 255) / 256), dim3(256), 0, c->stream, rec, h.n_arg,
+                                   p.toi_word ? p.toi_word : &d_cnt->toi_bits, d_best);
+                if (p.is_vf) hipLaunchKernelGGL(np_fetch_query_k<true>, dim3(1), dim3(1), 0, c->stream, p.V, p.E, p.F, p.pairs, n, d_best, d_v);
+                else hipLaunchKernelGGL(np_fetch_query_k<false>, dim3(1), dim3(1), 0, c->stream, p.V, p.E, p.F, p.pairs, n, d_best, d_v);
+                SCCD_HIP(hipGetLastError());
+                unsigned best = 0xFFFFFFFFu;
+                double v[8][3];
+                {
+                    ReadBack rb(c);
+                    rb.add(&best, d_best, sizeof best);
+                    rb.add(&v[0][0], d_v, sizeof v);
+                    rb.sync();
+                }
+                if (best < (unsigned long long)n) {
+                    bool gave_up = false;
+                    const double alone = ti_census_level_order(v, p.is_vf, p.arith, p.ms, p.tol, p.max_iter, p.allow_zero_toi, toi_init,
+                                                               /*max_live=*/1 << 22, &gave_up);
+                    certified = !gave_up && alone == t_star;
+                }
+            }
+        }
+        if (!certified) {
+            NarrowCounters h2;
+            std::memset(&h2, 0, sizeof h2);
+            std::memcpy(&h2.toi_bits, &toi_init, 8);
+            SCCD_HIP(hipMemcpyAsync(d_cnt, &h2, sizeof h2, hipMemcpyHostToDevice, c->stream));
+            if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, nullptr);
+            else run_level_sync<false>(c, p, d_cnt, n, nullptr);
+            SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            SCCD_HIP(hipStreamSynchronize(c->stream));
+            if (h.overflow) throw SccdError { SCCD_E_OVERFLOW, "narrow phase: work queue capacity exhausted" };
+        }
+        h.overflow = 0;
+        h.n_ovf = 0;
+    }
     if (std::getenv("SCCD_NP_DIAG") && h.wave_steps)
         std::fprintf(stderr, "[sccd np] n=%lld checks=%llu wave_steps=%llu (waves %llu, mean %.1f, longest %llu) lane_util=%.3f refill_execs=%llu steals=%llu pops=%llu checked ahead=%llu\n",
                      n, h.n_checks, h.wave_steps, h.waves_run, (double)h.wave_steps / (double)std::max<unsigned long long>(1, h.waves_run),
@@ -441,7 +527,7 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
             else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi);
         };
         bool done = false;
-        if (!(h.overflow & NQ_OVF_MAXITER)) {
+        {
             c->np_scratch3_ovf.ensure(sizeof(int) * (size_t)cap);
             int* d_list = c->np_scratch3_ovf.as<int>();
             unsigned long long checks_so_far = h.n_checks;

@@ -675,31 +675,70 @@ def test_ipc_ccd_strategy_matches_the_oracle_twin(sccd, ctx, orc, case):
 
 
 def test_check_limit_that_no_query_reaches_runs_on_the_fast_kernel(sccd, ctx, orc):
-    """SCCD_OPT_MAX_ITER_FAST = 1 (opt-in): a limit no query comes near (the IPC Toolkit passes 1e7) changes
-    nothing and is served by the work-queue kernel (same check count as max_iter = -1, far fewer than the
-    level-order scheme needs).  Default: every limit follows the reference's level order (oracle)."""
+    """A limit no query comes near (the IPC Toolkit passes 1e7) changes nothing, and the library proves that instead of
+    paying for the reference's level order: the fast kernel runs without the limit, then ONE query -- the one that holds
+    the earliest impact -- is bisected alone in level order with the limit on the host (csrc/ti_census.cpp).  Same TOI,
+    a check count like max_iter = -1 (level order needs several times as many).  SCCD_OPT_LIMIT_LEVEL_ORDER = 1 runs the
+    level-synchronous kernels regardless: the same answers."""
     V0, V1, E, F = _scene("cloth_ball_10k")
     mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
     t_free, st_free = sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True, want_stats=True)
+    free_checks = st_free["n_vf_checks"] + st_free["n_ee_checks"]
+    for limit in (4096, 10_000_000):
+        t, st = sccd.ccd_mesh(mesh, 0.0, limit, 1e-6, True, want_stats=True)
+        assert t == t_free
+        # depth-first with pruning: the count depends a little on timing, never by a factor
+        assert st["n_vf_checks"] + st["n_ee_checks"] < 1.5 * free_checks
+    t_ipc = sccd.ipc_ccd_strategy(V0, V1, E, F, 0.0, 10_000_000, 1e-6, ctx=ctx)
+    assert t_ipc == sccd.ipc_ccd_strategy(V0, V1, E, F, 0.0, -1, 1e-6, ctx=ctx)
     try:
-        ctx.set_option(sccd.OPT_MAX_ITER_FAST, 1)
-        for limit in (4096, 10_000_000):
-            t, st = sccd.ccd_mesh(mesh, 0.0, limit, 1e-6, True, want_stats=True)
-            assert t == t_free
-            # depth-first with pruning: the count depends a little on timing, never by a factor
-            assert st["n_vf_checks"] + st["n_ee_checks"] < 1.5 * (st_free["n_vf_checks"] + st_free["n_ee_checks"])
-        t_ipc = sccd.ipc_ccd_strategy(V0, V1, E, F, 0.0, 10_000_000, 1e-6, ctx=ctx)
-        assert t_ipc == sccd.ipc_ccd_strategy(V0, V1, E, F, 0.0, -1, 1e-6, ctx=ctx)
+        ctx.set_option(sccd.OPT_LIMIT_LEVEL_ORDER, 1)
+        t, st = sccd.ccd_mesh(mesh, 0.0, 10_000_000, 1e-6, True, want_stats=True)
+        assert t == t_free
+        level_checks = st["n_vf_checks"] + st["n_ee_checks"]
     finally:
-        ctx.set_option(sccd.OPT_MAX_ITER_FAST, 0)
-    # default: level-synchronous kernels, the reference's own order
-    t, st = sccd.ccd_mesh(mesh, 0.0, 10_000_000, 1e-6, True, want_stats=True)
-    # (check counts are not compared: how much the depth-first walk prunes depends on how many queries are in flight at once)
-    assert t == t_free
+        ctx.set_option(sccd.OPT_LIMIT_LEVEL_ORDER, 0)
+    assert level_checks != free_checks  # (another traversal: it did run in level order)
     want, _, _ = orc.ccd(V0, V1, E, F, 0.0, 3, 1e-6, True)
     got = sccd.ccd_mesh(mesh, 0.0, 3, 1e-6, True)
     assert got >= t_free  # truncation can only lose collisions
     assert got == want
+
+
+@pytest.mark.parametrize("arith", [0, 1])
+def test_check_limits_where_the_certificate_fails_fall_back_to_level_order(sccd, ctx, orc, arith):
+    """Limits >= 4096 start on the fast kernel.  The heaviest vertex-face queries of this soup are popped 13,424, 12,657 and
+    8,883 times in the reference's level order; handed over without the rest of the scene they also hold the earliest
+    impact, so limits of 4,096 ... 10,000 DO cut it off (TOI 1 instead of 0.125): the host-side proof fails and the call is
+    redone in level order.  The oracle's answer, bit for bit, whichever way each limit went; different limits, different
+    answers."""
+    V0, V1, E, F = _scene("soup_dense")
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F, 0.0)
+    pv = orc.sort_and_sweep(vb, fb)[0]
+    _, pq, _ = orc.narrow_phase(V0, V1, E, F, pv, True, per_query=True, arith=arith)
+    hits = np.nonzero(pq < 1)[0]
+    counts = [(orc.narrow_phase(V0, V1, E, F, pv[i:i + 1], True, arith=arith)[2]["max_checks_per_query"], int(i)) for i in hits]
+    heavy = [i for _, i in sorted(counts, reverse=True)[:3]]
+    assert sorted(counts, reverse=True)[2][0] > 8000
+    misses = np.nonzero(pq >= 1)[0][:300]  # (queries without an impact ride along)
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    try:
+        ctx.set_option(sccd.OPT_ARITH, arith)
+        for sel in ([heavy[0]], heavy[:2], heavy):
+            pairs = np.ascontiguousarray(np.concatenate([pv[sel], pv[misses]]))
+            seen = set()
+            for k in (4096, 6000, 10_000, 13_000, 20_000):
+                want = orc.narrow_phase(V0, V1, E, F, pairs, True, 0.0, k, 1e-6, True, arith=arith)[0]
+                got = sccd.narrow_phase(mesh, pairs, True, k, 1e-6, 0.0, True)
+                assert got == want, (sel, k)
+                ctx.set_option(sccd.OPT_LIMIT_LEVEL_ORDER, 1)
+                assert sccd.narrow_phase(mesh, pairs, True, k, 1e-6, 0.0, True) == want, (sel, k)
+                ctx.set_option(sccd.OPT_LIMIT_LEVEL_ORDER, 0)
+                seen.add(want)
+            assert len(seen) >= 2, sel
+    finally:
+        ctx.set_option(sccd.OPT_ARITH, 0)
+        ctx.set_option(sccd.OPT_LIMIT_LEVEL_ORDER, 0)
 
 
 @pytest.mark.parametrize("arith", [0, 1])
