@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -227,8 +228,10 @@ __global__ void np_copy_per_query_k(const LvlData* __restrict__ data, long long 
 }
 
 // d_sel / n_sel: only those queries of the call (np_walk_k's overflow list), else all n_all
+// walk_range(first, count): finish those queries of the call depth first (see below); may be empty
 template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, long long n_all,
-                                       double* d_per_query_toi, const int* d_sel = nullptr, long long n_sel = 0)
+                                       double* d_per_query_toi, const int* d_sel = nullptr, long long n_sel = 0,
+                                       const std::function<void(long long, long long)>& walk_range = nullptr)
 {
     const bool use_ms = p.ms > 0; // narrow_phase.cu:128
     const long long n = d_sel ? n_sel : n_all; // queries to run; data[] / snap[] stay indexed by the query's own number
@@ -273,8 +276,18 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
             if (sizeof(LvlDomain) * (size_t)(2 * n_cur) > budget) {
                 // (a single contact-rich query can have ~(1/tolerance)^2 live domains in level order: no
                 // slice size helps then.  The depth-first work-queue kernel, or a check limit, is the way out.)
-                if (len <= 4096)
+                if (len <= 4096) {
+                    // Without a check limit and per-query output the result does not depend on the traversal (Appendix A.20):
+                    // these queries are finished depth first by the work-queue kernel, which holds no domains in HBM at all,
+                    // seeded with the TOI reached so far.  (Round 2 failed the call here: soak seed 20522, 67 faces in
+                    // resting contact with a large minimum separation.)
+                    if (p.max_iter < 0 && !d_per_query_toi && !d_sel && !c->scalar_f32 && walk_range) {
+                        walk_range(q0, len);
+                        n_cur = 0;
+                        break; // (fits stays true: the slice is done)
+                    }
                     throw SccdError { SCCD_E_NOMEM, "level-synchronous narrow phase: the live domains of one level exceed the memory budget" };
+                }
                 fits = false;
                 break;
             }
@@ -386,8 +399,27 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
         // (re)done in level order, bit-equal to the oracle's level-order restatement either way.
         const bool level_sync = !narrow_uses_walk_kernel(c, p, d_per_query_toi != nullptr);
         if (level_sync) {
-            if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi);
-            else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi);
+            // queries whose levels outgrow the memory budget are finished depth first (run_level_sync: only where the result
+            // cannot depend on the traversal): the TOI reached so far seeds the work-queue kernel, its counters start afresh
+            auto walk_range = [&](long long first, long long count) {
+                NarrowCounters hc;
+                SCCD_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof hc, hipMemcpyDeviceToHost, c->stream));
+                SCCD_HIP(hipStreamSynchronize(c->stream));
+                unsigned long long checks = hc.n_checks;
+                for (int k = 0; k < 8; k++) checks += hc.checks_part[k].n;
+                NarrowCounters* const h_up = reinterpret_cast<NarrowCounters*>(c->h_scalars.as<char>() + 12288);
+                std::memset(h_up, 0, sizeof(NarrowCounters));
+                h_up->toi_bits = hc.toi_bits;
+                h_up->n_checks = checks;
+                SCCD_HIP(hipMemcpyAsync(d_cnt, h_up, sizeof(NarrowCounters), hipMemcpyHostToDevice, c->stream));
+                SCCD_HIP(hipStreamSynchronize(c->stream)); // (the pinned source is reused by the next upload)
+                NarrowParams pr = p;
+                pr.pairs = p.pairs + first;
+                pr.n_pairs = count;
+                run_walk(c, pr, d_cnt, count, nullptr);
+            };
+            if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi, nullptr, 0, walk_range);
+            else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi, nullptr, 0, walk_range);
         } else {
             if (d_per_query_toi) { // every query starts at +inf (narrow_phase.cu:70)
                 hipLaunchKernelGGL(np_fill_u64_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
