@@ -794,6 +794,12 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     static const bool merged_env = !(std::getenv("SCCD_MERGED_SORT") && std::atoi(std::getenv("SCCD_MERGED_SORT")) == 0);
     const bool scan_build_env = std::getenv("SCCD_BUILD") && std::string(std::getenv("SCCD_BUILD")) == "scan";
     const bool want_merged = merged_env && B != nullptr && !scan_build_env;
+    // Multi-GPU, first attempt: the rank's window of cells is dealt out ON THE DEVICE (shard_window_k) and the fill reads it
+    // from there -- no host round trip between the histogram and the fill.  What the host would have decided from the
+    // histogram (coarsen the grid: too much replication; too few cells to deal out: shard by rows) is checked when the
+    // totals come back, on the same GLOBAL numbers, hence alike on every rank; then the build starts over the slow way.
+    ShardWindow* const d_win = reinterpret_cast<ShardWindow*>(bp->grid.as<char>() + 1024);
+    bool device_window_tried = false, device_window_redo = false;
     for (int shrink = 0;; shrink++) {
         launch_grid_setup(c, A->stats_head(), A->stats_part(), A->n_part, B ? B->stats_head() : nullptr,
                           B ? B->stats_part() : nullptr, B ? B->n_part : 0, n_total, axis, cf, shrink, gp,
@@ -802,7 +808,17 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
         // Multi-GPU: every rank takes a contiguous window of cells with an equal share of the
         // entries, and builds / sorts / sweeps only that window.  A pair is reported from exactly
         // one cell (owns_pair), hence by exactly one rank: no exchange of boxes or pairs.
-        if (c->shard_count > 1) {
+        static const bool device_window_env = !(std::getenv("SCCD_DEVICE_WINDOW") && std::atoi(std::getenv("SCCD_DEVICE_WINDOW")) == 0);
+        const bool device_window = c->shard_count > 1 && shrink == 0 && !device_window_tried && device_window_env && !scan_build_env;
+        if (device_window) {
+            device_window_tried = true;
+            uint32_t* d_hist = bp->grid.as<uint32_t>() + 1024; // bytes [4096, ...) of the grid block
+            SCCD_HIP(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * SCCD_MAX_CELLS, c->stream));
+            launch_cell_hist(c, A->raw.as<sccd_aabb>(), A->n, gp, SHARD_HIST_STRIDE, d_hist);
+            if (B) launch_cell_hist(c, B->raw.as<sccd_aabb>(), B->n, gp, SHARD_HIST_STRIDE, d_hist);
+            launch_shard_window(c, d_hist, gp, SHARD_HIST_STRIDE, c->shard_rank, c->shard_count, d_win);
+            bp->row_shard = false;
+        } else if (c->shard_count > 1) {
             uint32_t* d_hist = bp->grid.as<uint32_t>() + 1024; // bytes [4096, 8192) of the grid block
             SCCD_HIP(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * SCCD_MAX_CELLS, c->stream));
             launch_cell_hist(c, A->raw.as<sccd_aabb>(), A->n, gp, SHARD_HIST_STRIDE, d_hist);
@@ -835,10 +851,12 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                 bp->row_shard = true; // (almost) one cell: every rank sorts everything and takes a slice of the rows
             }
         }
+        ShardWindow hwin {};
         auto read_totals = [&](uint32_t (&total)[2], GridParams& hgp) {
             GridReadBack g;
             ReadBack rb(c);
             rb.add(&g, gp, sizeof g);
+            if (device_window) rb.add(&hwin, d_win, sizeof hwin);
             rb.sync();
             hgp = g.gp;
             total[0] = g.total[0];
@@ -855,6 +873,12 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
             // of the list instead of count, scan and fill.  Room for the entries: the replication
             // budget (single GPU) or the histogram estimate (cell window); an overflow is counted,
             // never written, and the pass repeated with exactly enough room.
+            // (a window dealt out on the device: its size is not known here -- an even share of the replication budget and
+            // a margin; the overflow check below makes up for a wrong guess)
+            if (device_window) {
+                const unsigned long long share = 3ull * (unsigned long long)std::max(A->n, B ? B->n : 0) / (unsigned long long)c->shard_count;
+                window_est = share + share / 4;
+            }
             unsigned long long cap = windowed_build ? window_est + window_est / 4 + 65536
                                                     : (unsigned long long)std::max<int64_t>(3 * (int64_t)std::max(A->n, B ? B->n : 0), (int64_t)std::max(A->n, B ? B->n : 0) + 4096);
             uint32_t total[2] = { 0, 0 };
@@ -876,26 +900,41 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                         bp->lb.key.ensure(sizeof(uint32_t) * ((size_t)cap + pad));
                         bp->lb.idx.ensure(sizeof(uint32_t) * ((size_t)cap + pad));
                     }
+                    const ShardWindow* const win = device_window ? d_win : nullptr;
                     if (want_merged) {
                         launch_cell_fill_append_two(c, A->raw.as<sccd_aabb>(), A->n, B->raw.as<sccd_aabb>(), B->n, gp, bp->cell_lo,
                                                     bp->cell_hi, d_total, (uint32_t)(2 * cap), bp->la.key.as<uint32_t>(),
-                                                    bp->la.idx.as<uint32_t>());
+                                                    bp->la.idx.as<uint32_t>(), win);
                     } else {
                         launch_cell_fill_append(c, A->raw.as<sccd_aabb>(), A->n, gp, bp->cell_lo, bp->cell_hi, d_total,
-                                                (uint32_t)cap, bp->la.key.as<uint32_t>(), bp->la.idx.as<uint32_t>(), false, d_place);
+                                                (uint32_t)cap, bp->la.key.as<uint32_t>(), bp->la.idx.as<uint32_t>(), false, d_place, win);
                         if (B)
                             launch_cell_fill_append(c, B->raw.as<sccd_aabb>(), B->n, gp, bp->cell_lo, bp->cell_hi, d_total + 1,
-                                                    (uint32_t)cap, bp->lb.key.as<uint32_t>(), bp->lb.idx.as<uint32_t>(), false);
+                                                    (uint32_t)cap, bp->lb.key.as<uint32_t>(), bp->lb.idx.as<uint32_t>(), false, nullptr, win);
                     }
                 }
                 {
                     ProfScope ps(c, SCCD_PROF_SORT);
                     read_totals(total, hgp);
                 }
+                if (device_window) { // what the host used to decide before the fill, now that the numbers are here
+                    bp->cell_lo = hwin.cell_lo;
+                    bp->cell_hi = hwin.cell_hi;
+                    device_window_redo = (can_shrink && hwin.total_est > (unsigned long long)std::max<int64_t>(3 * (int64_t)n_total, (int64_t)n_total + 4096))
+                        || hwin.n_cells < 4 * c->shard_count;
+                    if (device_window_redo) break;
+                }
                 const unsigned long long need = std::max<unsigned long long>(total[0], B ? total[1] : 0);
                 if (need <= cap) break;
                 if (!windowed_build && can_shrink) break; // over the replication budget: the grid gets coarser below
                 cap = need + 1024; // estimate too low (the sample missed a crowded cell): once more, with room
+            }
+            if (device_window_redo) { // the same grid again (shrink stays 0), the slow way: histogram on the host, then as before
+                device_window_redo = false;
+                bp->cell_lo = 0; // (the slow way decides the window -- or the row shard -- afresh)
+                bp->cell_hi = 1 << 30;
+                shrink--;
+                continue;
             }
             if (!windowed_build && can_shrink) {
                 auto over = [&](uint32_t t, int n) { return (int64_t)t > std::max<int64_t>(3 * (int64_t)n, (int64_t)n + 4096); };

@@ -461,11 +461,16 @@ __global__ void cell_hist_k(const sccd_aabb* __restrict__ raw, int n, const Grid
 // `capacity` are counted but not written (the host grows the buffers and runs the pass again).
 // place != nullptr: the entries go where a SHARED cursor says (both lists of a merged two-list sort fill one buffer, in any
 // order: the sort that follows separates them by the tag bit) while `cursor` only counts this list's entries.
+// d_win != nullptr: the cell window comes from device memory (shard_window_k wrote it: no host round trip in between)
 __device__ __forceinline__ void cell_fill_append_body(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp,
                                                       int cell_lo, int cell_hi, uint32_t* __restrict__ cursor, uint32_t capacity,
                                                       uint32_t* __restrict__ key, uint32_t* __restrict__ idx, int tagged,
-                                                      uint32_t* __restrict__ place, int block)
+                                                      uint32_t* __restrict__ place, int block, const ShardWindow* __restrict__ d_win = nullptr)
 {
+    if (d_win) {
+        cell_lo = d_win->cell_lo;
+        cell_hi = d_win->cell_hi;
+    }
     const int i = block * (int)blockDim.x + (int)threadIdx.x;
     const GridParams g = *gp;
     const uint32_t tag = (tagged && g.tag_bit >= 0) ? (1u << g.tag_bit) : 0u; // list B of a merged two-list sort
@@ -513,21 +518,86 @@ __device__ __forceinline__ void cell_fill_append_body(const sccd_aabb* __restric
 __global__ void cell_fill_append_k(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp,
                                    int cell_lo, int cell_hi, uint32_t* __restrict__ cursor, uint32_t capacity,
                                    uint32_t* __restrict__ key, uint32_t* __restrict__ idx, int tagged,
-                                   uint32_t* __restrict__ place)
+                                   uint32_t* __restrict__ place, const ShardWindow* __restrict__ d_win)
 {
-    cell_fill_append_body(raw, n, gp, cell_lo, cell_hi, cursor, capacity, key, idx, tagged, place, (int)blockIdx.x);
+    cell_fill_append_body(raw, n, gp, cell_lo, cell_hi, cursor, capacity, key, idx, tagged, place, (int)blockIdx.x, d_win);
 }
 // both lists of a merged two-list build in ONE launch (the first blocks_a blocks: list A): they fill the same buffers by the
 // same placement cursor and only count apart
 __global__ void cell_fill_append2_k(const sccd_aabb* __restrict__ raw_a, int na, const sccd_aabb* __restrict__ raw_b, int nb,
                                     int blocks_a, const GridParams* __restrict__ gp, int cell_lo, int cell_hi,
                                     uint32_t* __restrict__ cursors /* [0] A, [1] B, [2] placement */, uint32_t capacity,
-                                    uint32_t* __restrict__ key, uint32_t* __restrict__ idx)
+                                    uint32_t* __restrict__ key, uint32_t* __restrict__ idx, const ShardWindow* __restrict__ d_win)
 {
     if ((int)blockIdx.x < blocks_a)
-        cell_fill_append_body(raw_a, na, gp, cell_lo, cell_hi, cursors, capacity, key, idx, 0, cursors + 2, (int)blockIdx.x);
+        cell_fill_append_body(raw_a, na, gp, cell_lo, cell_hi, cursors, capacity, key, idx, 0, cursors + 2, (int)blockIdx.x, d_win);
     else
-        cell_fill_append_body(raw_b, nb, gp, cell_lo, cell_hi, cursors + 1, capacity, key, idx, 1, cursors + 2, (int)blockIdx.x - blocks_a);
+        cell_fill_append_body(raw_b, nb, gp, cell_lo, cell_hi, cursors + 1, capacity, key, idx, 1, cursors + 2,
+                              (int)blockIdx.x - blocks_a, d_win);
+}
+
+// Multi-GPU: this rank's window of cells from the sampled histogram, ON THE DEVICE (round 2 read the 64 KB histogram back
+// and dealt the cells out on the host: an 80 us round trip in every rank's build, and a rank's build is all latency).
+// The same rule as shard_bounds() (api.hip; mirrored in sccd/dist.py): window r starts at the first cell k whose midpoint in
+// running weight, prefix[k] + w[k] / 2, reaches total * r / parts -- that expression never decreases with k, so the first
+// such cell is found by bisection over the scanned histogram.  One block of 1024 threads, 16 cells each.
+__global__ __launch_bounds__(1024) void shard_window_k(const uint32_t* __restrict__ hist, const GridParams* __restrict__ gp, int stride,
+                                                       int rank, int parts, ShardWindow* __restrict__ out)
+{
+    static_assert(SCCD_MAX_CELLS == 16384, "shard_window_k: 1024 threads x 16 cells");
+    __shared__ uint32_t pre[SCCD_MAX_CELLS]; // exclusive prefix sums
+    __shared__ uint32_t wsum[16];
+    const int n = gp->n_cells;
+    const int t = threadIdx.x;
+    uint32_t w[16], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int k = t * 16 + i;
+        w[i] = k < n ? hist[k] : 0u;
+        sum += w[i];
+    }
+    const uint32_t incl = (uint32_t)wave_incl_scan((int)sum);
+    if (lane_id() == 63) wsum[t >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - sum;
+    for (int k = 0; k < (t >> 6); k++) base += wsum[k];
+    uint32_t total = 0;
+    for (int k = 0; k < 16; k++) total += wsum[k];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        pre[t * 16 + i] = base;
+        base += w[i];
+    }
+    __syncthreads();
+    __shared__ int bound[2];
+    if (t < 2) {
+        const int r = rank + t; // bounds[rank], bounds[rank + 1]
+        int at;
+        if (r <= 0) at = 0;
+        else if (r >= parts) at = n;
+        else {
+            const unsigned long long target = (unsigned long long)total * (unsigned long long)r / (unsigned long long)parts;
+            int lo = 0, hi = n; // first k with pre[k] + hist[k] / 2 >= target, else n
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if ((unsigned long long)pre[mid] + hist[mid] / 2u < target) lo = mid + 1;
+                else hi = mid;
+            }
+            at = lo;
+        }
+        bound[t] = at;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const int lo = bound[0], hi = max(bound[0], bound[1]);
+        out->cell_lo = lo;
+        out->cell_hi = hi;
+        out->n_cells = n;
+        out->pad = 0;
+        out->total_est = (unsigned long long)total * (unsigned long long)stride;
+        const uint32_t p_hi = hi < n ? pre[hi] : total, p_lo = lo < n ? pre[lo] : total;
+        out->window_est = (unsigned long long)(p_hi - p_lo) * (unsigned long long)stride;
+    }
 }
 
 // payload movement of thrust::sort_by_key (aabb.cu:107-109) as ONE gather after the index sort, fused with what
@@ -739,21 +809,28 @@ void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams
                        n, g, stride, hist);
     SCCD_HIP(hipGetLastError());
 }
+void launch_shard_window(sccd_ctx* c, const uint32_t* hist, const GridParams* g, int stride, int rank, int parts, ShardWindow* out)
+{
+    hipLaunchKernelGGL(shard_window_k, dim3(1), dim3(1024), 0, c->stream, hist, g, stride, rank, parts, out);
+    SCCD_HIP(hipGetLastError());
+}
 void launch_cell_fill_append(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
-                             uint32_t* cursor, uint32_t capacity, uint32_t* key, uint32_t* idx, bool tagged, uint32_t* place)
+                             uint32_t* cursor, uint32_t capacity, uint32_t* key, uint32_t* idx, bool tagged, uint32_t* place,
+                             const ShardWindow* d_win)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(cell_fill_append_k, dim3((n + 1023) / 1024), dim3(1024), 0, c->stream, raw, n, g, cell_lo, cell_hi,
-                       cursor, capacity, key, idx, tagged ? 1 : 0, place);
+                       cursor, capacity, key, idx, tagged ? 1 : 0, place, d_win);
     SCCD_HIP(hipGetLastError());
 }
 void launch_cell_fill_append_two(sccd_ctx* c, const sccd_aabb* raw_a, int na, const sccd_aabb* raw_b, int nb, const GridParams* g,
-                                 int cell_lo, int cell_hi, uint32_t* cursors, uint32_t capacity, uint32_t* key, uint32_t* idx)
+                                 int cell_lo, int cell_hi, uint32_t* cursors, uint32_t capacity, uint32_t* key, uint32_t* idx,
+                                 const ShardWindow* d_win)
 {
     const int blocks_a = (na + 1023) / 1024, blocks_b = (nb + 1023) / 1024;
     if (blocks_a + blocks_b == 0) return;
     hipLaunchKernelGGL(cell_fill_append2_k, dim3((unsigned)(blocks_a + blocks_b)), dim3(1024), 0, c->stream, raw_a, na, raw_b, nb,
-                       blocks_a, g, cell_lo, cell_hi, cursors, capacity, key, idx);
+                       blocks_a, g, cell_lo, cell_hi, cursors, capacity, key, idx, d_win);
     SCCD_HIP(hipGetLastError());
 }
 void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,

@@ -108,12 +108,22 @@ void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a,
                        const double* part_b, int n_part_b, int n_total, int axis, double cell_factor, int shrink,
                        GridParams* g, uint32_t* cursors, bool reserve_tag = false);
 void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int stride, uint32_t* hist);
+// a rank's window of cells, decided on the device (boxes.hip shard_window_k)
+struct ShardWindow {
+    int cell_lo, cell_hi; // this rank's cells
+    int n_cells, pad;
+    unsigned long long total_est;  // entries of the whole grid, estimated from the sampled histogram
+    unsigned long long window_est; // ... of this rank's window
+};
+void launch_shard_window(sccd_ctx* c, const uint32_t* hist, const GridParams* g, int stride, int rank, int parts, ShardWindow* out);
+// d_win != nullptr: the window is read from device memory (cell_lo / cell_hi are ignored)
 void launch_cell_fill_append(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
                              uint32_t* cursor, uint32_t capacity, uint32_t* key, uint32_t* idx, bool tagged = false,
-                             uint32_t* place = nullptr);
+                             uint32_t* place = nullptr, const ShardWindow* d_win = nullptr);
 // both lists of a merged two-list build in one launch: cursors[0] / [1] count list A's / B's entries, cursors[2] places both
 void launch_cell_fill_append_two(sccd_ctx* c, const sccd_aabb* raw_a, int na, const sccd_aabb* raw_b, int nb, const GridParams* g,
-                                 int cell_lo, int cell_hi, uint32_t* cursors, uint32_t capacity, uint32_t* key, uint32_t* idx);
+                                 int cell_lo, int cell_hi, uint32_t* cursors, uint32_t capacity, uint32_t* key, uint32_t* idx,
+                                 const ShardWindow* d_win = nullptr);
 void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
                        uint32_t* counts);
 void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
