@@ -31,14 +31,25 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 BYTES_PER_QUERY = 220.0       # narrow phase: pair 8 + element indices 12/16 + 24 coords + toi
 BYTES_SWEEP_PER_BOX = 64.0    # sweep: sorted box record, + 8 B per emitted pair
 BYTES_SORT_PER_KEY_PASS = 16  # one radix pass over (u32 key, u32 index): read 8 + write 8
-FLOP_PER_CHECK = 520.0        # one inclusion-function check = 8 corners x 57 FLOP + min/max/tests
-FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: FP64 vector peak
+FLOP_PER_CHECK = 520.0        # one inclusion-function check = 8 corners x 57 FLOP + min/max/tests (the REFERENCE's form)
+FLOP_PER_CHECK_EXECUTED = 156.0  # what np_walk_k executes per check: the min/max form of ti_inclusion_mm
+FP64_VALU_PEAK_TFLOPS = 78.6  # AMD's MI355X specification: 78.6 TFLOP/s FP64 vector (= 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz)
+BYTES_BROAD_PER_BOX = 548.0   # box build 124 + radix sort 204 + payload gather 128 + counts/scan 28 + sweep 64, + 8 B per pair
 
 
 def pmc_kernels(workload):
-    """per-kernel HBM bytes of profiles/r02_pmc_traffic_<workload>.json if that profile is of THIS build, else None"""
+    """per-kernel HBM bytes of profiles/r03_pmc_traffic_<workload>.json if that profile is of THIS build, else None"""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_%s.json" % workload)))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_%s.json" % workload)))
+        return tj["kernels"] if tj.get("lib_sha256") == lib_sha256() else None
+    except Exception:
+        return None
+
+
+def pmc_sq(workload):
+    """SQ counters per kernel of profiles/r03_pmc_sq_<workload>.json (tools/pmc_sq.sh) if taken on THIS build, else None"""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_sq_%s.json" % workload)))
         return tj["kernels"] if tj.get("lib_sha256") == lib_sha256() else None
     except Exception:
         return None
@@ -58,7 +69,7 @@ def lib_sha256():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cloth1m", choices=["cloth1m", "clothball10k", "boxes1m", "sort16m"])
     ap.add_argument("--cloth-n", type=int, default=708, help="cloth grid side for cloth1m (708 -> 999,698 tris)")
@@ -66,6 +77,8 @@ def parse():
     ap.add_argument("--sweep-algo", type=int, default=0, help="0 auto, 1 plain SAP, 2 filter/queue/confirm, 3 direct")
     ap.add_argument("--max-iter", type=int, default=-1, help="Tight-Inclusion check limit per query (the IPC Toolkit passes 10000000); -1: none")
     ap.add_argument("--limit-level-order", action="store_true", help="SCCD_OPT_LIMIT_LEVEL_ORDER: check limits on the level-synchronous kernels (round 2's default)")
+    ap.add_argument("--boxes-n", type=int, default=1_000_000, help="boxes1m: number of boxes (SURVEY 8d also asks for 16,000,000; extents shrink so that ~10 overlaps per box remain)")
+    ap.add_argument("--boxes-variant", default="iso", choices=["iso", "thin"], help="boxes1m: isotropic, or cloth-like (z extents x 0.01: SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="cloth side of the CPU sample (0 = auto)")
     return ap.parse_args()
@@ -199,9 +212,9 @@ def main():
         units = {  # class -> (algorithmic bytes per step, kernel name, name in the rocprofv3 summaries)
             "narrow_ee": (BYTES_PER_QUERY * q_ee, "np_walk_k<false> (edge-edge Tight-Inclusion)", "np_walk_k<false, %d, 0>" % args.arith),
             "narrow_vf": (BYTES_PER_QUERY * q_vf, "np_walk_k<true> (vertex-face Tight-Inclusion)", "np_walk_k<true, %d, 0>" % args.arith),
-            "sweep": (BYTES_SWEEP_PER_BOX * n_boxes + 8.0 * (q_vf + q_ee), "sweep_stq_k (3 launches per step)", "sweep_stq_k"),
+            "sweep": (BYTES_SWEEP_PER_BOX * n_boxes + 8.0 * (q_vf + q_ee), "sweep_band_k / sweep_band2_k (2 launches per step)", "sweep_band_k"),
             "sort": (BYTES_SORT_PER_KEY_PASS * 4 * n_boxes, "onesweep radix sort + scans", "os_pass_k"),
-            "boxes": (124.0 * n_boxes, "box build, cell count/fill, gather", "entry_gather_k"),
+            "boxes": (124.0 * n_boxes, "box build, cell fill, sorted records", "entry_record_k"),
             "ranges": (28.0 * n_boxes, "ranges_k", "ranges_k"),
         }
         ms_dom, launches = prof[dom]  # live, over the timed region
@@ -212,13 +225,13 @@ def main():
         # THIS build of the library: the JSON carries the hash of the libsccd_hip.so it profiled
         traffic, traffic_note = None, "no PMC profile of this workload"
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_cloth1m.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_cloth1m.json")))
             if args.workload == "cloth1m" and args.cloth_n == 708 and world == 1:
                 if tj.get("lib_sha256") == lib_sha256():
                     traffic = tj["kernels"][units[dom][2]]["hbm_bytes_per_launch_corrected"]
-                    traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build (profiles/r02_pmc_traffic_cloth1m.json)"
+                    traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build (profiles/r03_pmc_traffic_cloth1m.json)"
                 else:
-                    traffic_note = "profiles/r02_pmc_traffic_cloth1m.json was taken on another build of the library: dropped"
+                    traffic_note = "profiles/r03_pmc_traffic_cloth1m.json was taken on another build of the library: dropped"
         except Exception:
             pass
         checks = float(c_vf + c_ee)
@@ -226,10 +239,20 @@ def main():
         if dom.startswith("narrow"):
             dom_checks = float(c_ee if dom == "narrow_ee" else c_vf)
             achieved = dom_checks * FLOP_PER_CHECK / launches_per_step / (per_launch_ms * 1e-3) / 1e12 if ms_dom > 0 else 0.0
+            sq = pmc_sq("cloth1m") if (args.workload == "cloth1m" and args.cloth_n == 708 and world == 1) else None
+            valu_per_check = None
+            if sq and units[dom][2] in sq and sq[units[dom][2]].get("SQ_INSTS_VALU"):
+                valu_per_check = round(sq[units[dom][2]]["SQ_INSTS_VALU"] * launches_per_step / max(1.0, dom_checks), 3)
             roofline = {
                 "bound": "fp64_valu", "kernel": units[dom][1], "achieved": round(achieved, 3), "peak": FP64_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / FP64_VALU_PEAK_TFLOPS, 5), "traffic": traffic,
                 "flop_per_check": FLOP_PER_CHECK, "checks_per_launch": dom_checks / launches_per_step,
+                # `achieved` prices a check at the REFERENCE's 520 FLOP (the algorithmic unit).  The kernel executes
+                # the min/max form of the inclusion function, ~156 FP64 operations per check: what the vector ALU really does
+                "executed_flop_per_check": FLOP_PER_CHECK_EXECUTED,
+                "executed_tflops": round(achieved * FLOP_PER_CHECK_EXECUTED / FLOP_PER_CHECK, 3),
+                "executed_frac": round(achieved * FLOP_PER_CHECK_EXECUTED / FLOP_PER_CHECK / FP64_VALU_PEAK_TFLOPS, 5),
+                "valu_per_check": valu_per_check,  # wave-level VALU instructions per check (SQ_INSTS_VALU of this build's PMC profile), else null
                 "hbm": {"achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(hbm_achieved / HBM_PEAK_GBS, 5), "bytes_per_query": BYTES_PER_QUERY},
             }
@@ -240,10 +263,42 @@ def main():
             "traffic_note": traffic_note, "avg_launch_ms": round(per_launch_ms, 4), "launches": launches,
             "class_ms_per_step": {k: round(v[0] / n_prof, 4) for k, v in prof_all.items()},
             "class_ms_source": "%d untimed steps after the warm-up with events on every class (the timed region times %s only)" % (n_prof, dom),
-            "narrow_phase": {"checks_per_s": checks / max(1e-9, narrow_ms * 1e-3),
-                             "fp64_frac_vf_plus_ee": round(checks * FLOP_PER_CHECK / max(1e-9, narrow_ms * 1e-3) / (FP64_VALU_PEAK_TFLOPS * 1e12), 5),
-                             "ms_per_step": round(narrow_ms, 4)},
+            "class_ms_note": "each class's own device time; the classes of a step OVERLAP (two streams: the edge-edge build beside the vertex-face broad phase, the edge-edge sweep and narrow kernel beside the vertex-face narrow kernel): they sum to more than ms_per_step",
+            "narrow_phase": {"checks_per_step": checks, "launch_ms_sum": round(narrow_ms, 4),
+                             "note": "the two narrow launches overlap in the default configuration: launch_ms_sum is not their wall span (broad_phase.passes_apart has each launch alone)"},
         })
+        # ---- the passes apart (two untimed steps, SCCD_OPT_PASSES_APART): each class's own duration with nothing beside it,
+        # and the broad phase against SURVEY 8d's formula (548 B per box + 8 B per pair)
+        ctx.set_option(sccd.OPT_PASSES_APART, 1)
+        for _ in range(2):
+            step()
+        ctx.set_option(sccd.OPT_PROFILE, 1)
+        ctx.reset_profile()
+        for _ in range(n_prof):
+            step()
+        prof_apart = {k: v[0] / n_prof for k, v in ctx.profile().items()}
+        ctx.set_option(sccd.OPT_PROFILE, 0)
+        ctx.set_option(sccd.OPT_PASSES_APART, 0)
+        broad_ms = prof_apart["boxes"] + prof_apart["sort"] + prof_apart["ranges"] + prof_apart["sweep"]
+        broad_bytes = BYTES_BROAD_PER_BOX * n_boxes + 8.0 * (q_vf + q_ee)
+        broad = {"bytes_per_step": broad_bytes, "formula": "548 B x boxes + 8 B x pairs (SURVEY 8d)", "boxes": n_boxes,
+                 "ms_passes_apart": round(broad_ms, 4), "achieved": round(broad_bytes / max(1e-9, broad_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                 "peak": HBM_PEAK_GBS, "frac": round(broad_bytes / max(1e-9, broad_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                 "passes_apart": {k: round(v, 4) for k, v in prof_apart.items()}}
+        # ---- the reference ccd()'s real entry cost (ccd.cu:103-106 uploads the mesh inside the call): sccd_ccd from pageable host matrices
+        host_ms = None
+        if world == 1:
+            ctx.synchronize()
+            # (column-major already, like the Eigen matrices of a C++ caller: the binding passes the pointers through)
+            hV0, hV1 = np.asfortranarray(V0, dtype=np.float64), np.asfortranarray(V1, dtype=np.float64)
+            hE, hF = np.asfortranarray(E, dtype=np.int32), np.asfortranarray(F, dtype=np.int32)
+            sccd.ccd(hV0, hV1, hE, hF, 0.0, args.max_iter, 1e-6, True, ctx=ctx)
+            t_h = []
+            for _ in range(5):
+                th0 = time.perf_counter()
+                sccd.ccd(hV0, hV1, hE, hF, 0.0, args.max_iter, 1e-6, True, ctx=ctx)
+                t_h.append((time.perf_counter() - th0) * 1e3)
+            host_ms = round(min(t_h), 4)
         result = {
             "metric": "CCD queries/sec (broad+narrow)", "value": value, "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -252,7 +307,12 @@ def main():
                            checks_per_step=float(qq[1].item()), candidates_per_step=float(qq[2].item()),
                            parallelism=f"cell windows sharded over {world} GPU(s), one RCCL all-reduce(min) of the TOI per step",
                            rccl_ranks=rccl_ranks, backend=(backend if use_dist else "none")),
-            "min_toi_latency_ms": dt / args.steps * 1e3,
+            # the reference's ccd() takes host matrices and uploads them inside the call: ITS min-TOI latency is the host path
+            "min_toi_latency_ms": host_ms if host_ms is not None else dt / args.steps * 1e3,
+            "host_path_ms": host_ms,
+            "min_toi_latency_note": "sccd_ccd() from pageable host matrices, upload and packing inside the call (best of 5); ms_per_step is the same step on a device-resident mesh",
+            "max_iter": args.max_iter,
+            "broad_phase": broad,
             "roofline": roofline,
         }
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -271,8 +331,12 @@ def main():
 
 def bench_boxes(args, ctx, sccd, scenes, torch):
     """BASELINE configs[2]: 1M random AABBs, broad phase only."""
-    n = 1_000_000
-    boxes = scenes.random_boxes(n, seed=42, max_extent=0.027)
+    n = args.boxes_n
+    boxes = scenes.random_boxes(n, seed=42, max_extent=0.027 * (1_000_000 / n) ** (1.0 / 3.0))
+    if args.boxes_variant == "thin":  # cloth-like: boxes 100x thinner in z, centres unchanged
+        cz = (boxes["min"][:, 2] + boxes["max"][:, 2]) / 2
+        hz = (boxes["max"][:, 2] - boxes["min"][:, 2]) / 2 * 0.01
+        boxes["min"][:, 2], boxes["max"][:, 2] = cz - hz, cz + hz
     dboxes = sccd.DeviceAABBs(boxes, ctx)
     bp = sccd.BroadPhase(ctx)
 
@@ -295,15 +359,19 @@ def bench_boxes(args, ctx, sccd, scenes, torch):
     ms_sweep, launches = prof["sweep"]
     achieved = (BYTES_SWEEP_PER_BOX * n + 8.0 * pairs) * args.steps / (ms_sweep * 1e-3) / 1e9
     tk = pmc_kernels("boxes1m")  # HBM bytes per sweep launch from the PMC passes of this build (tools/pmc_traffic.sh boxes1m)
-    traffic = tk["sweep_stq_k"]["hbm_bytes_per_launch_corrected"] if tk and "sweep_stq_k" in tk else None
+    kname = next((k for k in (tk or {}) if k.startswith("sweep_band_k")), None)
+    traffic = tk[kname]["hbm_bytes_per_launch_corrected"] if kname else None
     cls = {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[0] > 0}
     return {
         "metric": "broad-phase boxes/sec", "value": n * args.steps / dt, "unit": "boxes/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "1M random AABBs, one list, sweep only (BASELINE configs[2])", "pairs": pairs,
+        "config": {"workload": "%d random AABBs (%s), one list, broad phase only (BASELINE configs[2])" % (n, args.boxes_variant), "pairs": pairs,
                    "candidates": bp.candidates()},
-        "roofline": {"bound": "hbm", "kernel": "sweep_stq_k", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        "broad_phase": {"bytes_per_step": BYTES_BROAD_PER_BOX * n + 8.0 * pairs, "formula": "548 B x boxes + 8 B x pairs (SURVEY 8d)",
+                        "achieved": round((BYTES_BROAD_PER_BOX * n + 8.0 * pairs) * args.steps / dt / 1e9, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                        "frac": round((BYTES_BROAD_PER_BOX * n + 8.0 * pairs) * args.steps / dt / 1e9 / HBM_PEAK_GBS, 5)},
+        "roofline": {"bound": "hbm", "kernel": "sweep_band_k", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "avg_launch_ms": round(ms_sweep / max(1, launches), 4), "class_ms_per_step": cls,
                      "candidate_tests_per_s": bp.candidates() * args.steps / (ms_sweep * 1e-3)},

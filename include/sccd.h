@@ -86,6 +86,8 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        cast to float first, boxes / tolerances / inclusion function / TOI are float arithmetic
                                        (values travel widened in the same double-typed interfaces); narrow phase on the
                                        level-synchronous kernels (bit-equal to the oracle's float twin on the GPU, tests/test_gpu_parity.py) */
+#define SCCD_OPT_PASSES_APART 13      /* ccd(): 1 = the vertex-face and the edge-edge pass one after the other on one stream (what
+                                       * SCCD_OVERLAP=0 does for the whole process): measurements of the passes' own durations */
 #define SCCD_OPT_LIMIT_LEVEL_ORDER 12 /* check limits (max_iter >= 0, root_finder.cu:287-305): 0 (default) the fast kernel runs
                                        * without the limit and the library proves that the limit would not have changed the
                                        * answer (one query redone in the reference's level order on the host), falling back to the

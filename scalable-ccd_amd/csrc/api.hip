@@ -129,6 +129,21 @@ void sccd_collect_profile(sccd_ctx* c)
     c->pending.clear();
 }
 
+// what the helper context ran (ccd(): the edge-edge lists, sweep and narrow kernel) belongs to this context's account
+static void merge_side_profile(sccd_ctx* c)
+{
+    sccd_collect_profile(c);
+    if (!c->side) return;
+    SCCD_HIP(hipStreamSynchronize(c->side->stream));
+    sccd_collect_profile(c->side);
+    for (int k = 0; k < SCCD_PROF_COUNT; k++) {
+        c->prof_ms[k] += c->side->prof_ms[k];
+        c->prof_launches[k] += c->side->prof_launches[k];
+        c->side->prof_ms[k] = 0;
+        c->side->prof_launches[k] = 0;
+    }
+}
+
 extern "C" {
 
 const char* sccd_version(void) { return "sccd-hip 0.1 (gfx950)"; }
@@ -232,6 +247,7 @@ int sccd_set_option(sccd_ctx* c, int opt, int64_t v)
     case SCCD_OPT_MEMORY_LIMIT_MB: c->memory_limit_mb = v; break;
     case SCCD_OPT_SCALAR: c->scalar_f32 = v ? 1 : 0; break;
     case SCCD_OPT_LIMIT_LEVEL_ORDER: c->limit_level_order = v ? 1 : 0; break;
+    case SCCD_OPT_PASSES_APART: c->passes_apart = v ? 1 : 0; break;
     default: c->err = "unknown option"; return SCCD_E_INVALID;
     }
     return SCCD_OK;
@@ -253,6 +269,7 @@ int64_t sccd_get_option(const sccd_ctx* c, int opt)
     case SCCD_OPT_MEMORY_LIMIT_MB: return c->memory_limit_mb;
     case SCCD_OPT_SCALAR: return c->scalar_f32;
     case SCCD_OPT_LIMIT_LEVEL_ORDER: return c->limit_level_order;
+    case SCCD_OPT_PASSES_APART: return c->passes_apart;
     default: return 0;
     }
 }
@@ -262,17 +279,7 @@ int sccd_get_profile(sccd_ctx* c, double ms[SCCD_PROF_COUNT], int64_t launches[S
     if (!c) return SCCD_E_INVALID;
     return guarded(c, [&] {
         SCCD_HIP(hipStreamSynchronize(c->stream));
-        sccd_collect_profile(c);
-        if (c->side) { // what the helper context ran belongs to this one's account
-            SCCD_HIP(hipStreamSynchronize(c->side->stream));
-            sccd_collect_profile(c->side);
-            for (int k = 0; k < SCCD_PROF_COUNT; k++) {
-                c->prof_ms[k] += c->side->prof_ms[k];
-                c->prof_launches[k] += c->side->prof_launches[k];
-                c->side->prof_ms[k] = 0;
-                c->side->prof_launches[k] = 0;
-            }
-        }
+        merge_side_profile(c);
         for (int k = 0; k < SCCD_PROF_COUNT; k++) {
             if (ms) ms[k] = c->prof_ms[k];
             if (launches) launches[k] = c->prof_launches[k];
@@ -1351,7 +1358,7 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
     }
     double before[SCCD_PROF_COUNT];
     if (st && c->profile == 1) {
-        sccd_collect_profile(c);
+        merge_side_profile(c);
         std::memcpy(before, c->prof_ms, sizeof before);
     }
     boxes_from_mesh(c, m, ms, pl, true, true, true); // inflation radius = min_distance (ccd.cu:112)
@@ -1364,7 +1371,7 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
     static const bool overlap_env = !(std::getenv("SCCD_OVERLAP") && std::atoi(std::getenv("SCCD_OVERLAP")) == 0);
     bool helper = false, presweep_done = false;
     static const bool presweep_env = !(std::getenv("SCCD_PRESWEEP") && std::atoi(std::getenv("SCCD_PRESWEEP")) == 0);
-    if (overlap_env && m->nE > 0) {
+    if (overlap_env && !c->passes_apart && m->nE > 0) {
         if (!c->side) {
             if (sccd_create(c->device, &c->side) != SCCD_OK) throw SccdError { SCCD_E_NOMEM, "ccd: cannot create the helper context" };
             SCCD_HIP(hipEventCreateWithFlags(&c->side_event, hipEventDisableTiming));
@@ -1539,7 +1546,7 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
         st->ms_total = msf;
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
-        sccd_collect_profile(c);
+        merge_side_profile(c); // (the edge-edge half of the step ran on the helper context)
         st->ms_boxes = c->prof_ms[SCCD_PROF_BOXES] - before[SCCD_PROF_BOXES];
         st->ms_sort = c->prof_ms[SCCD_PROF_SORT] - before[SCCD_PROF_SORT];
         st->ms_sweep = (c->prof_ms[SCCD_PROF_SWEEP] - before[SCCD_PROF_SWEEP])

@@ -103,6 +103,7 @@ struct sccd_ctx {
     int profile = 0;
     int scalar_f32 = 0; // SCCD_OPT_SCALAR: 1 = the reference's float build
     int sweep_blocks_per_cu = 0; // 0 = the sweep kernel's own choice (a full CU); ccd()'s helper context sweeps with half
+    int passes_apart = 0;      // SCCD_OPT_PASSES_APART
     int limit_level_order = 0; // SCCD_OPT_LIMIT_LEVEL_ORDER: 1 = every check limit on the level-synchronous kernels (cross-check)
     // narrow_counters_upload() already put {zeros, this TOI} into the narrow phase's counters (it rides ahead of
     // the sweep in ccd(), so that the narrow kernel can start right behind the sweep's read-back)

@@ -279,9 +279,10 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restri
             wtot[k][threadIdx.x] = 0;
             wrun[k][threadIdx.x] = 0;
         }
-        // request the next ticket
-        uint32_t t1_req = 0;
-        if (threadIdx.x == 0) t1_req = atomicAdd(ticket, 1u);
+        // request the next ticket (a launch with a block per tile has none to give: the broad phase's size, where the 400
+        // wasted atomics on the one ticket word were a third of the 7 us a pass spends queueing there)
+        uint32_t t1_req = (uint32_t)num_tiles;
+        if (threadIdx.x == 0 && (int)gridDim.x < num_tiles) t1_req = atomicAdd(ticket, 1u);
         wave_lds_fence();
         uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
         bool valid[RS_ITEMS];

@@ -37,6 +37,7 @@ OPT_ARITH, OPT_NARROW_ALGO, OPT_SWEEP_ALGO, OPT_SORT_AXIS = 1, 2, 3, 4
 OPT_SHARD_RANK, OPT_SHARD_COUNT, OPT_OVERLAP_CAPACITY, OPT_PROFILE, OPT_MAX_OVERLAP_CUTOFF = 5, 6, 7, 8, 9
 OPT_MEMORY_LIMIT_MB = 10
 OPT_SCALAR = 11  # 1: the reference's float build (SCALABLE_CCD_USE_DOUBLE=OFF)
+OPT_PASSES_APART = 13  # 1: ccd() runs its two passes one after the other (measurements)
 OPT_LIMIT_LEVEL_ORDER = 12  # 1: check limits always on the level-synchronous kernels; default: fast kernel + certificate (same result)
 PROF_NAMES = ["boxes", "sort", "ranges", "sweep", "narrow_vf", "narrow_ee"]
 
