@@ -111,11 +111,15 @@ public:
     T* data() { return m_data; }
     const T* data() const { return m_data; }
     void clear() { m_size = 0; }
+    /// keeps the first min(size(), n) elements, like thrust::device_vector::resize
     void resize(size_t n)
     {
         if (n > m_cap) {
+            T* grown = nullptr;
+            ctx().check(sccd_dev_alloc(ctx().get(), n * sizeof(T), reinterpret_cast<void**>(&grown)));
+            if (m_data && m_size) ctx().check(sccd_dev_copy(ctx().get(), grown, m_data, m_size * sizeof(T)));
             release();
-            ctx().check(sccd_dev_alloc(ctx().get(), n * sizeof(T), reinterpret_cast<void**>(&m_data)));
+            m_data = grown;
             m_cap = n;
             m_owned = true;
         }
@@ -298,7 +302,7 @@ public:
         if (!boxes) throw std::runtime_error("BroadPhase::build: boxes are null");
         m_a = boxes;
         m_b.reset();
-        apply_memory_handler();
+        const HandlerScope handler_scope(m_ctx, memory_handler.get());
         m_ctx->check(sccd_broad_phase_build(m_bp, boxes->get(), nullptr));
     }
     void build(const std::shared_ptr<DeviceAABBs> boxesA, const std::shared_ptr<DeviceAABBs> boxesB)
@@ -306,7 +310,7 @@ public:
         if (!boxesA || !boxesB) throw std::runtime_error("BroadPhase::build: boxes are null");
         m_a = boxesA;
         m_b = boxesB;
-        apply_memory_handler();
+        const HandlerScope handler_scope(m_ctx, memory_handler.get());
         m_ctx->check(sccd_broad_phase_build(m_bp, boxesA->get(), boxesB->get()));
     }
     /// One sweep step; the overlaps stay on the device, valid until the next call (broad_phase.cuh:41-44).
@@ -314,7 +318,7 @@ public:
     {
         const int32_t* p = nullptr;
         int64_t n = 0;
-        apply_memory_handler();
+        const HandlerScope handler_scope(m_ctx, memory_handler.get());
         m_ctx->check(sccd_broad_phase_detect_overlaps_partial(m_bp, &p, &n));
         d_overlaps.view(reinterpret_cast<const int2*>(p), (size_t)n, *m_ctx);
         if (memory_handler) memory_handler->real_count = (int)n;
@@ -324,7 +328,7 @@ public:
     {
         int32_t* p = nullptr;
         int64_t n = 0;
-        apply_memory_handler();
+        const HandlerScope handler_scope(m_ctx, memory_handler.get());
         m_ctx->check(sccd_broad_phase_detect_overlaps(m_bp, &p, &n));
         std::vector<std::pair<int, int>> out((size_t)n);
         for (int64_t i = 0; i < n; i++) out[(size_t)i] = { p[2 * i], p[2 * i + 1] };
@@ -341,13 +345,31 @@ public:
     int threads_per_block = 32; // accepted for source compatibility; the sweep kernel picks its own launch shape
 
 private:
-    void apply_memory_handler()
-    {
-        if (!memory_handler) return;
-        if (memory_handler->memory_limit_GB > 0) m_ctx->set_option(SCCD_OPT_MEMORY_LIMIT_MB, (int64_t)memory_handler->memory_limit_GB * 1024);
-        if (memory_handler->MAX_OVERLAP_CUTOFF > 0) m_ctx->set_option(SCCD_OPT_MAX_OVERLAP_CUTOFF, (int64_t)memory_handler->MAX_OVERLAP_CUTOFF);
-        if (memory_handler->MAX_OVERLAP_SIZE > 0) m_ctx->set_option(SCCD_OPT_OVERLAP_CAPACITY, (int64_t)memory_handler->MAX_OVERLAP_SIZE);
-    }
+    /// The handler belongs to THIS BroadPhase (broad_phase.cuh:76): its three settings apply for the duration of one call
+    /// and the context's own options come back afterwards (a shared context must not inherit one object's limits).
+    struct HandlerScope {
+        Context* c = nullptr;
+        int64_t saved[3] = { 0, 0, 0 };
+        HandlerScope(Context* ctx, const MemoryHandler* h) : c(h ? ctx : nullptr)
+        {
+            if (!c) return;
+            saved[0] = sccd_get_option(c->get(), SCCD_OPT_MEMORY_LIMIT_MB);
+            saved[1] = sccd_get_option(c->get(), SCCD_OPT_MAX_OVERLAP_CUTOFF);
+            saved[2] = sccd_get_option(c->get(), SCCD_OPT_OVERLAP_CAPACITY);
+            if (h->memory_limit_GB > 0) c->set_option(SCCD_OPT_MEMORY_LIMIT_MB, (int64_t)h->memory_limit_GB * 1024);
+            if (h->MAX_OVERLAP_CUTOFF > 0) c->set_option(SCCD_OPT_MAX_OVERLAP_CUTOFF, (int64_t)h->MAX_OVERLAP_CUTOFF);
+            if (h->MAX_OVERLAP_SIZE > 0) c->set_option(SCCD_OPT_OVERLAP_CAPACITY, (int64_t)h->MAX_OVERLAP_SIZE);
+        }
+        ~HandlerScope()
+        {
+            if (!c) return;
+            (void)sccd_set_option(c->get(), SCCD_OPT_MEMORY_LIMIT_MB, saved[0]);
+            (void)sccd_set_option(c->get(), SCCD_OPT_MAX_OVERLAP_CUTOFF, saved[1]);
+            (void)sccd_set_option(c->get(), SCCD_OPT_OVERLAP_CAPACITY, saved[2]);
+        }
+        HandlerScope(const HandlerScope&) = delete;
+        HandlerScope& operator=(const HandlerScope&) = delete;
+    };
     std::shared_ptr<MemoryHandler> memory_handler;
     Context* m_ctx;
     sccd_broad_phase* m_bp = nullptr;

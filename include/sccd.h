@@ -104,6 +104,7 @@ int sccd_dev_alloc(sccd_ctx* ctx, size_t bytes, void** d_ptr);
 int sccd_dev_free(sccd_ctx* ctx, void* d_ptr);
 int sccd_dev_upload(sccd_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int sccd_dev_download(sccd_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+int sccd_dev_copy(sccd_ctx* ctx, void* d_dst, const void* d_src, size_t bytes); /* device to device (thrust::device_vector::resize keeps its contents) */
 
 /* ------------------------------------------------------------------------------------------ */
 /* mesh  == the four DeviceMatrix objects of ccd() (src/scalable_ccd/cuda/ccd.cu:103-106)     */

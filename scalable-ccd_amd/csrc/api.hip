@@ -1700,6 +1700,15 @@ extern "C" int sccd_dev_upload(sccd_ctx* c, void* d_dst, const void* h_src, size
         SCCD_HIP(hipStreamSynchronize(c->stream));
     });
 }
+extern "C" int sccd_dev_copy(sccd_ctx* c, void* d_dst, const void* d_src, size_t bytes)
+{
+    if (!c || (bytes && (!d_dst || !d_src))) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        if (bytes == 0) return;
+        SCCD_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+    });
+}
 extern "C" int sccd_dev_download(sccd_ctx* c, void* h_dst, const void* d_src, size_t bytes)
 {
     if (!c || (bytes && (!h_dst || !d_src))) return SCCD_E_INVALID;
@@ -1758,7 +1767,10 @@ extern "C" int sccd_selftest_lds_gather(sccd_ctx* c, int n_waves, int n_active, 
     return guarded(c, [&] {
         SCCD_REQUIRE(n_waves >= 1 && n_waves <= 4096 && n_active >= 0 && n_active <= 64, "selftest: bad arguments");
         const int nrec = 5000, per_wave = 2 * 3 * 64 * 2 + 64 * 2;
-        n_waves = (n_waves + 1) / 2 * 2; // whole blocks
+        {
+            const int wpb = narrow_selftest_waves_per_block(); // whole blocks of the kernel's own shape
+            n_waves = (n_waves + wpb - 1) / wpb * wpb;
+        }
         std::vector<double> hV((size_t)nrec * 6);
         for (size_t i = 0; i < hV.size(); i++) hV[i] = (double)i + 0.5;
         std::vector<int> perm((size_t)n_waves * 64);

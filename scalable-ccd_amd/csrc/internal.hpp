@@ -233,4 +233,5 @@ bool narrow_uses_walk_kernel(const sccd_ctx* c, const NarrowParams& p, bool per_
 // ti_census.cpp (host): ONE query bisected alone in the reference's level order with the check limit
 double ti_census_level_order(const double v[8][3], int is_vf, int arith, double ms, double tol, int max_iter, int allow_zero_toi,
                              double toi_init, long long max_live, bool* gave_up);
+int narrow_selftest_waves_per_block(); // (np_walk_k's block shape: NW_WAVES)
 void narrow_selftest_lds_gather(sccd_ctx* c, const double* d_V, const int* d_perm, int n_waves, int n_active, double* d_out);

@@ -52,7 +52,7 @@ ABI_SYMBOLS = [
     "sccd_broad_phase_num_boxes", "sccd_broad_phase_candidates", "sccd_free", "sccd_narrow_phase", "sccd_ccd",
     "sccd_ccd_mesh", "sccd_ccd_mesh_prepare", "sccd_ccd_mesh_pass", "sccd_ipc_ccd_strategy", "sccd_get_profile", "sccd_reset_profile", "sccd_sort_pairs_u32",
     "sccd_shard_bounds", "sccd_boxes_variance_axis", "sccd_selftest_lds_gather",
-    "sccd_dev_alloc", "sccd_dev_free", "sccd_dev_upload", "sccd_dev_download", "sccd_ccd_collisions",
+    "sccd_dev_alloc", "sccd_dev_free", "sccd_dev_upload", "sccd_dev_download", "sccd_dev_copy", "sccd_ccd_collisions",
 ]
 
 

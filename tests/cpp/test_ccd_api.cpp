@@ -291,6 +291,30 @@ int main()
         bp2.clear();
         CHECK(bp2.num_boxes() == 0 && bp2.overlaps().size() == 0);
     }
+    {
+        // a MemoryHandler is per BroadPhase (broad_phase.cuh:76): its limits apply to that object's calls only -- the shared
+        // default context keeps its own options afterwards
+        Context& dc = Context::default_context();
+        const int64_t lim0 = sccd_get_option(dc.get(), SCCD_OPT_MEMORY_LIMIT_MB), cut0 = sccd_get_option(dc.get(), SCCD_OPT_MAX_OVERLAP_CUTOFF),
+                      cap0 = sccd_get_option(dc.get(), SCCD_OPT_OVERLAP_CAPACITY);
+        auto handler = std::make_shared<MemoryHandler>();
+        handler->memory_limit_GB = 1;
+        handler->MAX_OVERLAP_CUTOFF = 4096;
+        BroadPhase bp3(handler);
+        bp3.build(std::make_shared<DeviceAABBs>(edge_boxes));
+        std::vector<std::pair<int, int>> got = bp3.detect_overlaps(); // (in chunks of 4096 rows)
+        std::sort(got.begin(), got.end());
+        CHECK(got == ee_overlaps);
+        CHECK(sccd_get_option(dc.get(), SCCD_OPT_MEMORY_LIMIT_MB) == lim0 && sccd_get_option(dc.get(), SCCD_OPT_MAX_OVERLAP_CUTOFF) == cut0
+              && sccd_get_option(dc.get(), SCCD_OPT_OVERLAP_CAPACITY) == cap0);
+        // DeviceVector::resize keeps its contents like thrust::device_vector
+        std::vector<int> h(1000);
+        for (int i = 0; i < 1000; i++) h[(size_t)i] = 7 * i + 1;
+        DeviceVector<int> dv(h);
+        dv.resize(100000);
+        dv.resize(1000);
+        CHECK(dv.to_host() == h);
+    }
 
     threw = false;
     try {

@@ -34,11 +34,14 @@ for d in sorted(glob.glob("gpurun_out/pmcsq_*/")):
     agg=collections.defaultdict(lambda:[0.0,0])
     for r in csv.DictReader(open(fs[-1])):
         nm=r["Kernel_Name"]
-        if "np_walk_k" not in nm and "np_walk_k" not in nm and "sweep_stq_k" not in nm and "os_pass_k" not in nm: continue
+        if not any(k in nm for k in ("np_walk_k", "sweep_band", "os_pass_k", "entry_record", "cell_fill_append")): continue
         nm=nm.replace("(anonymous namespace)::","").split("(")[0].replace("void ","")
         agg[(nm,r["Counter_Name"])][0]+=float(r["Counter_Value"]); agg[(nm,r["Counter_Name"])][1]+=1
     for (k,c),(v,n) in agg.items(): out[k][c]=v/n
-json.dump(out, open("gpurun_out/pmc_sq_$W.json","w"), indent=1, sort_keys=True)
+import hashlib,os
+lib=os.environ.get("SCCD_LIB") or "scalable-ccd_amd/sccd/libsccd_hip.so"
+sha=hashlib.sha256(open(lib,"rb").read()).hexdigest()
+json.dump({"workload":"$W","lib_sha256":sha,"note":"rocprofv3 --pmc, one pass per counter group (tools/pmc_sq.sh); per-kernel averages over the launches of a 3-step bench run","kernels":out}, open("gpurun_out/pmc_sq_$W.json","w"), indent=1, sort_keys=True)
 for k,v in out.items():
     print(k)
     for c,x in sorted(v.items()): print("   %-26s %.4g"%(c,x))
