@@ -408,9 +408,9 @@ __device__ __forceinline__ void sweep_band_body(SweepLds* lds_s, unsigned long l
     bool have = false;           // (the window survives from tile to tile inside a chunk)
     int ahead = 0;               // segments [ahead_c0, + 32 * ahead) were asked for ahead and sit in `seg`
     unsigned ahead_c0 = 0;
-    SegRegs seg0, seg1;
+    SegRegs seg0, seg1, seg2, seg3;
     seg0.v0 = seg0.v1 = seg0.v2 = make_uint4(0u, 0u, 0u, 0u);
-    seg1 = seg0;
+    seg1 = seg2 = seg3 = seg0;
     while (tile < t_hi) {
         const int row = row_begin + tile * 64 + lane;
         const bool valid = row < row_end;
@@ -450,6 +450,14 @@ __device__ __forceinline__ void sweep_band_body(SweepLds* lds_s, unsigned long l
                     if (ahead >= 2 && from < need) {
                         st.write(seg1, from);
                         from += SW_SEG;
+                        if (ahead >= 3 && from < need) {
+                            st.write(seg2, from);
+                            from += SW_SEG;
+                            if (ahead >= 4 && from < need) {
+                                st.write(seg3, from);
+                                from += SW_SEG;
+                            }
+                        }
                     }
                 }
                 for (; from < need; from += SW_SEG) {
@@ -529,13 +537,37 @@ __device__ __forceinline__ void sweep_band_body(SweepLds* lds_s, unsigned long l
                     ahead = 1;
                     ahead_c0 = w_hi;
                     seg0 = st.load(ahead_c0);
-                } else if (next_follows && tile_next < t_hi) { // the tile's last block: the next tile starts 64 columns further on
-                    ahead = 1;
-                    ahead_c0 = w_hi;
-                    seg0 = st.load(ahead_c0);
-                    if (w_hi + (unsigned)SW_SEG < n_cols_up) {
+                }
+            }
+            if (__ballot(live) == 0 && tile_next < t_hi) {
+                // The tile's LAST block: ask for the NEXT tile's window now -- up to four segments, in registers while this
+                // block's candidates are queued and confirmed (a tile used to start with a bare wait for its first loads:
+                // at two waves per SIMD that wait was a third of the sweep).  Inside a chunk the window moves on and only
+                // what lies behind it is asked for.
+                const int row_n = row_begin + tile_next * 64 + lane;
+                const unsigned j_n = ONE ? (unsigned)row_n + 1u : nx.aux.w;
+                const unsigned base_n = wave_min_u32_dpp((row_n < row_end && j_n < (unsigned)n_cols) ? j_n : 0xFFFFFFFFu);
+                if (base_n != 0xFFFFFFFFu) {
+                    const unsigned nlo_n = base_n & ~(unsigned)(SW_SEG - 1);
+                    const unsigned need_n = min(n_cols_up, nlo_n + (unsigned)SW_WIN);
+                    const unsigned from_n = (next_follows && w_hi > nlo_n && w_lo <= nlo_n) ? w_hi : nlo_n;
+                    ahead_c0 = from_n;
+                    ahead = 0;
+                    if (from_n < need_n) {
+                        seg0 = st.load(from_n);
+                        ahead = 1;
+                    }
+                    if (from_n + 1u * SW_SEG < need_n) {
+                        seg1 = st.load(from_n + 1u * SW_SEG);
                         ahead = 2;
-                        seg1 = st.load(ahead_c0 + (unsigned)SW_SEG);
+                    }
+                    if (from_n + 2u * SW_SEG < need_n) {
+                        seg2 = st.load(from_n + 2u * SW_SEG);
+                        ahead = 3;
+                    }
+                    if (from_n + 3u * SW_SEG < need_n) {
+                        seg3 = st.load(from_n + 3u * SW_SEG);
+                        ahead = 4;
                     }
                 }
             }
@@ -579,10 +611,7 @@ __device__ __forceinline__ void sweep_band_body(SweepLds* lds_s, unsigned long l
             }
         }
         drain(me, my_cellpack); // (the rows leave the registers)
-        if (!next_follows) { // the next tile is somewhere else: its window starts from nothing
-            have = false;
-            ahead = 0;
-        }
+        if (!next_follows) have = false; // the next tile is somewhere else: its window starts from nothing (what was asked for ahead)
         tile = tile_next;
     }
     wave_lds_fence();
