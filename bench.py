@@ -280,6 +280,12 @@ def main():
         ctx.set_option(sccd.OPT_PROFILE, 0)
         ctx.set_option(sccd.OPT_PASSES_APART, 0)
         broad_ms = prof_apart["boxes"] + prof_apart["sort"] + prof_apart["ranges"] + prof_apart["sweep"]
+        # the slowest rank's device time per phase (passes apart): narrow-phase scaling is readable on its own
+        mx = torch.tensor([broad_ms, prof_apart["narrow_vf"] + prof_apart["narrow_ee"]], dtype=torch.float64, device=red_dev)
+        if use_dist:
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        rank_max = {"broad_ms": round(float(mx[0].item()), 4), "narrow_ms": round(float(mx[1].item()), 4),
+                    "note": "max over ranks of each rank's device time per phase, passes apart (two untimed steps)"}
         broad_bytes = BYTES_BROAD_PER_BOX * n_boxes + 8.0 * (q_vf + q_ee)
         broad = {"bytes_per_step": broad_bytes, "formula": "548 B x boxes + 8 B x pairs (SURVEY 8d)", "boxes": n_boxes,
                  "ms_passes_apart": round(broad_ms, 4), "achieved": round(broad_bytes / max(1e-9, broad_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
@@ -313,6 +319,7 @@ def main():
             "min_toi_latency_note": "sccd_ccd() from pageable host matrices, upload and packing inside the call (best of 5); ms_per_step is the same step on a device-resident mesh",
             "max_iter": args.max_iter,
             "broad_phase": broad,
+            "rank_max": rank_max,
             "roofline": roofline,
         }
         if rank == 0 and world == 1 and not args.no_cpu_baseline:

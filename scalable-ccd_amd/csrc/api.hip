@@ -493,8 +493,11 @@ extern "C" int sccd_boxes_create(sccd_ctx* c, const sccd_aabb* boxes, int n, int
 }
 
 // vertex boxes -> (edge, face) boxes, all on the device (ccd.cu:112-121 without the host trip)
+constexpr int LAZY_STATS_STRIDE = 8; // a lazy list's grid statistics look at every 8th element
+// lazy_ef: the edge and face lists are only DESCRIBED (multi-GPU ccd(): a rank builds the boxes of its window of cells, in
+// the fill pass -- internal.hpp sccd_boxes::lazy); their grid statistics come from a sample every rank takes alike
 static void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline* pl, bool want_v, bool want_e,
-                            bool want_f)
+                            bool want_f, bool lazy_ef = false)
 {
     (void)want_v;
     ProfScope ps(c, SCCD_PROF_BOXES);
@@ -521,6 +524,18 @@ static void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline*
         pl->fb.kind = BOX_FACE;
         pl->fb.raw.ensure(sizeof(sccd_aabb) * (size_t)std::max(m->nF, 1));
         begin_stats(pl->fb);
+    }
+    pl->eb.lazy = pl->fb.lazy = false;
+    if (lazy_ef) {
+        for (sccd_boxes* b : { want_e ? &pl->eb : nullptr, want_f ? &pl->fb : nullptr }) {
+            if (!b || b->n == 0) continue;
+            b->lazy = true;
+            b->lazy_vb = pl->vb.raw.as<sccd_aabb>();
+            b->lazy_elems = b == &pl->eb ? (const void*)m->E.as<int2>() : (const void*)m->F.as<int4>();
+            b->n_part = launch_elem_stats(c, b, LAZY_STATS_STRIDE, b->stats_head(), b->stats_part());
+            b->have_stats = true;
+        }
+        return;
     }
     if (want_e && want_f && m->nE > 0 && m->nF > 0) { // both in one launch
         launch_edge_face_boxes(c, pl->vb.raw.as<sccd_aabb>(), m->E.as<int2>(), m->nE, pl->eb.raw.as<sccd_aabb>(), pl->eb.stats_head(),
@@ -753,6 +768,18 @@ static void lists_finish_merged(sccd_ctx* c, const sccd_boxes* A, const sccd_box
     }
 }
 
+// a lazy list (internal.hpp) built in full after all: every path but the device-window fill reads the whole raw array
+static void materialise(sccd_ctx* c, const sccd_boxes* b)
+{
+    if (!b || !b->lazy) return;
+    sccd_boxes* m = const_cast<sccd_boxes*>(b); // (pipeline-owned: ccd_on_mesh made it lazy)
+    if (b->kind == BOX_EDGE)
+        launch_edge_boxes(c, b->lazy_vb, reinterpret_cast<const int2*>(b->lazy_elems), b->n, m->raw.as<sccd_aabb>());
+    else
+        launch_face_boxes(c, b->lazy_vb, reinterpret_cast<const int4*>(b->lazy_elems), b->n, m->raw.as<sccd_aabb>());
+    m->lazy = false;
+}
+
 static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes* B)
 {
     sccd_ctx* c = bp->ctx;
@@ -782,6 +809,15 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     };
     uint32_t* d_total = reinterpret_cast<uint32_t*>(bp->grid.as<char>() + 512 + offsetof(GridReadBack, total));
     static_assert(512 + sizeof(GridReadBack) <= 4096, "grid buffer layout");
+    {
+        // lazy lists live on the device-window path only
+        static const bool dw_env = !(std::getenv("SCCD_DEVICE_WINDOW") && std::atoi(std::getenv("SCCD_DEVICE_WINDOW")) == 0);
+        const bool scan_env = std::getenv("SCCD_BUILD") && std::string(std::getenv("SCCD_BUILD")) == "scan";
+        if (!(c->shard_count > 1 && dw_env && !scan_env && c->sort_axis >= 0)) {
+            materialise(c, A);
+            materialise(c, B);
+        }
+    }
     int axis = c->sort_axis;
     if (axis < 0) axis = pick_sort_axis(c, A->raw.as<sccd_aabb>(), A->n);
     {
@@ -821,15 +857,15 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
             device_window_tried = true;
             uint32_t* d_hist = bp->grid.as<uint32_t>() + 1024; // bytes [4096, ...) of the grid block
             SCCD_HIP(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * SCCD_MAX_CELLS, c->stream));
-            launch_cell_hist(c, A->raw.as<sccd_aabb>(), A->n, gp, SHARD_HIST_STRIDE, d_hist);
-            if (B) launch_cell_hist(c, B->raw.as<sccd_aabb>(), B->n, gp, SHARD_HIST_STRIDE, d_hist);
+            launch_cell_hist(c, A, gp, SHARD_HIST_STRIDE, d_hist);
+            if (B) launch_cell_hist(c, B, gp, SHARD_HIST_STRIDE, d_hist);
             launch_shard_window(c, d_hist, gp, SHARD_HIST_STRIDE, c->shard_rank, c->shard_count, d_win);
             bp->row_shard = false;
         } else if (c->shard_count > 1) {
             uint32_t* d_hist = bp->grid.as<uint32_t>() + 1024; // bytes [4096, 8192) of the grid block
             SCCD_HIP(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * SCCD_MAX_CELLS, c->stream));
-            launch_cell_hist(c, A->raw.as<sccd_aabb>(), A->n, gp, SHARD_HIST_STRIDE, d_hist);
-            if (B) launch_cell_hist(c, B->raw.as<sccd_aabb>(), B->n, gp, SHARD_HIST_STRIDE, d_hist);
+            launch_cell_hist(c, A, gp, SHARD_HIST_STRIDE, d_hist);
+            if (B) launch_cell_hist(c, B, gp, SHARD_HIST_STRIDE, d_hist);
             static thread_local std::vector<uint32_t> hist_v(SCCD_MAX_CELLS);
             uint32_t* hist = hist_v.data();
             GridParams hgp;
@@ -909,15 +945,14 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                     }
                     const ShardWindow* const win = device_window ? d_win : nullptr;
                     if (want_merged) {
-                        launch_cell_fill_append_two(c, A->raw.as<sccd_aabb>(), A->n, B->raw.as<sccd_aabb>(), B->n, gp, bp->cell_lo,
-                                                    bp->cell_hi, d_total, (uint32_t)(2 * cap), bp->la.key.as<uint32_t>(),
-                                                    bp->la.idx.as<uint32_t>(), win);
+                        launch_cell_fill_append_two(c, A, B, gp, bp->cell_lo, bp->cell_hi, d_total, (uint32_t)(2 * cap),
+                                                    bp->la.key.as<uint32_t>(), bp->la.idx.as<uint32_t>(), win);
                     } else {
-                        launch_cell_fill_append(c, A->raw.as<sccd_aabb>(), A->n, gp, bp->cell_lo, bp->cell_hi, d_total,
-                                                (uint32_t)cap, bp->la.key.as<uint32_t>(), bp->la.idx.as<uint32_t>(), false, d_place, win);
+                        launch_cell_fill_append(c, A, gp, bp->cell_lo, bp->cell_hi, d_total, (uint32_t)cap, bp->la.key.as<uint32_t>(),
+                                                bp->la.idx.as<uint32_t>(), false, d_place, win);
                         if (B)
-                            launch_cell_fill_append(c, B->raw.as<sccd_aabb>(), B->n, gp, bp->cell_lo, bp->cell_hi, d_total + 1,
-                                                    (uint32_t)cap, bp->lb.key.as<uint32_t>(), bp->lb.idx.as<uint32_t>(), false, nullptr, win);
+                            launch_cell_fill_append(c, B, gp, bp->cell_lo, bp->cell_hi, d_total + 1, (uint32_t)cap,
+                                                    bp->lb.key.as<uint32_t>(), bp->lb.idx.as<uint32_t>(), false, nullptr, win);
                     }
                 }
                 {
@@ -938,6 +973,8 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
             }
             if (device_window_redo) { // the same grid again (shrink stays 0), the slow way: histogram on the host, then as before
                 device_window_redo = false;
+                materialise(c, A); // (the slow way reads whole lists)
+                materialise(c, B);
                 bp->cell_lo = 0; // (the slow way decides the window -- or the row shard -- afresh)
                 bp->cell_hi = 1 << 30;
                 shrink--;
@@ -1361,7 +1398,10 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
         merge_side_profile(c);
         std::memcpy(before, c->prof_ms, sizeof before);
     }
-    boxes_from_mesh(c, m, ms, pl, true, true, true); // inflation radius = min_distance (ccd.cu:112)
+    // (a rank of a multi-GPU job builds the edge and face boxes of its window of cells only: see boxes_from_mesh)
+    static const bool lazy_env = !(std::getenv("SCCD_LAZY_BOXES") && std::atoi(std::getenv("SCCD_LAZY_BOXES")) == 0);
+    const bool lazy_ef = lazy_env && c->shard_count > 1 && c->sort_axis >= 0 && c->max_overlap_cutoff == 0;
+    boxes_from_mesh(c, m, ms, pl, true, true, true, lazy_ef); // inflation radius = min_distance (ccd.cu:112)
     double toi = 1; // ccd.cu:125
     // The edge-edge lists do not depend on the vertex-face pass: a helper context (own stream, scratch, pinned mirror)
     // builds them on a worker thread meanwhile.  Both builds are chains of short, latency-bound kernels with host

@@ -183,6 +183,46 @@ __device__ __forceinline__ BoxLoad load_box_geom(const sccd_aabb* b)
     return r;
 }
 
+// Where a list's boxes come from: the raw array (SRC 0), or -- multi-GPU: a rank needs the boxes of ITS window of cells only,
+// and writing all 3 M boxes of a mesh on every rank was the largest item of an 8-rank step -- computed on the spot from the
+// vertex boxes and the element's vertex indices (SRC 1 edges, SRC 2 faces: the arithmetic of edge_boxes_body /
+// face_boxes_body, hence the same bits), and stored to `out` only where the caller says so.
+struct BoxSrc {
+    const sccd_aabb* raw; // SRC 0
+    const sccd_aabb* vb;  // SRC 1, 2: the vertex boxes
+    const void* elems;    // int2[] edges / int4[] faces
+    sccd_aabb* out;       // where a computed box goes if it is kept (element order)
+};
+template <int SRC> __device__ __forceinline__ BoxLoad src_box(const BoxSrc& bs, int i, int4* ids)
+{
+    if (SRC == 0) return load_box_geom(bs.raw + i);
+    BoxLoad r;
+    if (SRC == 1) {
+        const int2 e = reinterpret_cast<const int2*>(bs.elems)[i];
+        const BoxLoad a = load_box_geom(bs.vb + e.x), b = load_box_geom(bs.vb + e.y);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            r.lo[k] = (b.lo[k] < a.lo[k]) ? b.lo[k] : a.lo[k];
+            r.hi[k] = (a.hi[k] < b.hi[k]) ? b.hi[k] : a.hi[k];
+        }
+        *ids = make_int4(e.x, e.y, -e.x - 1, i);
+    } else {
+        const int4 f = reinterpret_cast<const int4*>(bs.elems)[i];
+        const BoxLoad a = load_box_geom(bs.vb + f.x), b = load_box_geom(bs.vb + f.y), c = load_box_geom(bs.vb + f.z);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double l = (b.lo[k] < a.lo[k]) ? b.lo[k] : a.lo[k];
+            l = (c.lo[k] < l) ? c.lo[k] : l;
+            double h = (a.hi[k] < b.hi[k]) ? b.hi[k] : a.hi[k];
+            h = (h < c.hi[k]) ? c.hi[k] : h;
+            r.lo[k] = l;
+            r.hi[k] = h;
+        }
+        *ids = make_int4(f.x, f.y, f.z, i);
+    }
+    return r;
+}
+
 // AABB(a, b): component-wise min/max (aabb.cuh:18-29); ids aabb.cu:200-203
 __device__ __forceinline__ void edge_boxes_body(const sccd_aabb* __restrict__ vb, const int2* __restrict__ E, int nE,
                                                 sccd_aabb* __restrict__ out, GridStats* __restrict__ st, double* __restrict__ part,
@@ -261,6 +301,25 @@ __global__ void box_stats_k(const sccd_aabb* __restrict__ raw, int n, GridStats*
         const BoxLoad b = load_box_geom(raw + i);
         acc.add(b.lo, b.hi);
     }
+    acc.finish(st, part);
+}
+
+// Bounds and summed extents of an element list from every `stride`-th element, WITHOUT building the list (multi-GPU: a
+// rank builds the boxes of its window only; the grid needs one cell size everyone agrees on, and any cell size is correct --
+// the same sample on every rank gives the same grid).  The sums are scaled by the stride: what grid_setup_k divides by the
+// true number of boxes.
+template <int SRC>
+__global__ void elem_stats_k(BoxSrc bs, int n, int stride, GridStats* __restrict__ st, double* __restrict__ part)
+{
+    StatsAcc acc;
+    for (long long i = (long long)(blockIdx.x * blockDim.x + threadIdx.x) * stride; i < n;
+         i += (long long)gridDim.x * blockDim.x * stride) {
+        int4 ids;
+        const BoxLoad b = src_box<SRC>(bs, (int)i, &ids);
+        acc.add(b.lo, b.hi);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) acc.se[k] *= (double)stride;
     acc.finish(st, part);
 }
 
@@ -435,8 +494,8 @@ __global__ void cell_fill_k(const sccd_aabb* __restrict__ raw, int n, const Grid
 // Entries per cell, from every `stride`-th box (multi-GPU: the ranks take contiguous cell windows
 // of about equal entry counts; ANY partition of the cells is correct, so a sample is enough --
 // it only has to be the same sample on every rank).
-__global__ void cell_hist_k(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp, int stride,
-                            uint32_t* __restrict__ hist /*[n_cells]*/)
+template <int SRC>
+__global__ void cell_hist_k(BoxSrc bs, int n, const GridParams* __restrict__ gp, int stride, uint32_t* __restrict__ hist /*[n_cells]*/)
 {
     __shared__ uint32_t h[SCCD_MAX_CELLS];
     const GridParams g = *gp;
@@ -444,7 +503,8 @@ __global__ void cell_hist_k(const sccd_aabb* __restrict__ raw, int n, const Grid
     __syncthreads();
     for (long long i = (long long)(blockIdx.x * blockDim.x + threadIdx.x) * stride; i < n;
          i += (long long)gridDim.x * blockDim.x * stride) {
-        const CellSpan s = cell_span(g, load_box_geom(raw + i));
+        int4 ids;
+        const CellSpan s = cell_span(g, src_box<SRC>(bs, (int)i, &ids));
         for (int ca = s.a0; ca <= s.a1; ca++)
             for (int cb = s.b0; cb <= s.b1; cb++) atomicAdd(&h[ca * g.Sb + cb], 1u);
     }
@@ -464,7 +524,8 @@ __global__ void cell_hist_k(const sccd_aabb* __restrict__ raw, int n, const Grid
 constexpr int FILL_PER = 4;                // boxes per thread of the fill pass
 constexpr int FILL_BOXES = 1024 * FILL_PER; // ... per block of 1024 threads
 // d_win != nullptr: the cell window comes from device memory (shard_window_k wrote it: no host round trip in between)
-__device__ __forceinline__ void cell_fill_append_body(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp,
+template <int SRC>
+__device__ __forceinline__ void cell_fill_append_body(const BoxSrc& bs, int n, const GridParams* __restrict__ gp,
                                                       int cell_lo, int cell_hi, uint32_t* __restrict__ cursor, uint32_t capacity,
                                                       uint32_t* __restrict__ key, uint32_t* __restrict__ idx, int tagged,
                                                       uint32_t* __restrict__ place, int block, const ShardWindow* __restrict__ d_win = nullptr)
@@ -488,13 +549,16 @@ __device__ __forceinline__ void cell_fill_append_body(const sccd_aabb* __restric
         q[k] = 0;
         cnt[k] = 0;
         if (i < n) {
-            const BoxLoad b = load_box_geom(raw + i);
+            int4 ids = make_int4(0, 0, 0, 0);
+            const BoxLoad b = src_box<SRC>(bs, i, &ids);
             s[k] = cell_span(g, b);
             q[k] = grid_qx(g, b.lo[g.axis]);
             for (int ca = s[k].a0; ca <= s[k].a1; ca++) {
                 const int c0 = max(ca * g.Sb + s[k].b0, cell_lo), c1 = min(ca * g.Sb + s[k].b1, cell_hi - 1);
                 cnt[k] += c1 >= c0 ? (uint32_t)(c1 - c0 + 1) : 0u;
             }
+            // (a box computed here is kept where the window lists it: the record builder gathers it by element number)
+            if (SRC != 0 && cnt[k] > 0) store_box(bs.out + i, b.lo, b.hi, ids.x, ids.y, ids.z, ids.w);
         }
         mine += cnt[k];
     }
@@ -531,25 +595,26 @@ __device__ __forceinline__ void cell_fill_append_body(const sccd_aabb* __restric
     }
 }
 
-__global__ void cell_fill_append_k(const sccd_aabb* __restrict__ raw, int n, const GridParams* __restrict__ gp,
-                                   int cell_lo, int cell_hi, uint32_t* __restrict__ cursor, uint32_t capacity,
-                                   uint32_t* __restrict__ key, uint32_t* __restrict__ idx, int tagged,
-                                   uint32_t* __restrict__ place, const ShardWindow* __restrict__ d_win)
+template <int SRC>
+__global__ void cell_fill_append_k(BoxSrc bs, int n, const GridParams* __restrict__ gp, int cell_lo, int cell_hi,
+                                   uint32_t* __restrict__ cursor, uint32_t capacity, uint32_t* __restrict__ key,
+                                   uint32_t* __restrict__ idx, int tagged, uint32_t* __restrict__ place,
+                                   const ShardWindow* __restrict__ d_win)
 {
-    cell_fill_append_body(raw, n, gp, cell_lo, cell_hi, cursor, capacity, key, idx, tagged, place, (int)blockIdx.x, d_win);
+    cell_fill_append_body<SRC>(bs, n, gp, cell_lo, cell_hi, cursor, capacity, key, idx, tagged, place, (int)blockIdx.x, d_win);
 }
 // both lists of a merged two-list build in ONE launch (the first blocks_a blocks: list A): they fill the same buffers by the
 // same placement cursor and only count apart
-__global__ void cell_fill_append2_k(const sccd_aabb* __restrict__ raw_a, int na, const sccd_aabb* __restrict__ raw_b, int nb,
-                                    int blocks_a, const GridParams* __restrict__ gp, int cell_lo, int cell_hi,
-                                    uint32_t* __restrict__ cursors /* [0] A, [1] B, [2] placement */, uint32_t capacity,
+template <int SRC_A, int SRC_B>
+__global__ void cell_fill_append2_k(BoxSrc a, int na, BoxSrc b, int nb, int blocks_a, const GridParams* __restrict__ gp, int cell_lo,
+                                    int cell_hi, uint32_t* __restrict__ cursors /* [0] A, [1] B, [2] placement */, uint32_t capacity,
                                     uint32_t* __restrict__ key, uint32_t* __restrict__ idx, const ShardWindow* __restrict__ d_win)
 {
     if ((int)blockIdx.x < blocks_a)
-        cell_fill_append_body(raw_a, na, gp, cell_lo, cell_hi, cursors, capacity, key, idx, 0, cursors + 2, (int)blockIdx.x, d_win);
+        cell_fill_append_body<SRC_A>(a, na, gp, cell_lo, cell_hi, cursors, capacity, key, idx, 0, cursors + 2, (int)blockIdx.x, d_win);
     else
-        cell_fill_append_body(raw_b, nb, gp, cell_lo, cell_hi, cursors + 1, capacity, key, idx, 1, cursors + 2,
-                              (int)blockIdx.x - blocks_a, d_win);
+        cell_fill_append_body<SRC_B>(b, nb, gp, cell_lo, cell_hi, cursors + 1, capacity, key, idx, 1, cursors + 2,
+                                     (int)blockIdx.x - blocks_a, d_win);
 }
 
 // Multi-GPU: this rank's window of cells from the sampled histogram, ON THE DEVICE (round 2 read the 64 KB histogram back
@@ -817,36 +882,79 @@ void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a,
                        n_total, axis, cell_factor, shrink, g, cursors, max_cells, reserve_tag ? 1 : 0);
     SCCD_HIP(hipGetLastError());
 }
-void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int stride, uint32_t* hist)
+// the boxes of a list for the kernels above: the raw array, or (lazy lists) the recipe to compute them
+static BoxSrc box_src(const sccd_boxes* b)
 {
+    return BoxSrc { b->raw.as<sccd_aabb>(), b->lazy_vb, b->lazy_elems, b->raw.as<sccd_aabb>() };
+}
+static int src_kind(const sccd_boxes* b) { return b->lazy ? (b->kind == BOX_EDGE ? 1 : 2) : 0; }
+void launch_cell_hist(sccd_ctx* c, const sccd_boxes* b, const GridParams* g, int stride, uint32_t* hist)
+{
+    const int n = b->n;
     if (n == 0) return;
     // few blocks: each flushes up to 1024 bins with global atomics
-    hipLaunchKernelGGL(cell_hist_k, dim3(std::min(grid_for((n + stride - 1) / stride), 64)), dim3(TPB), 0, c->stream, raw,
-                       n, g, stride, hist);
+    const dim3 grid((unsigned)std::min(grid_for((n + stride - 1) / stride), 64)), block(TPB);
+    const BoxSrc bs = box_src(b);
+    switch (src_kind(b)) {
+    case 0: hipLaunchKernelGGL(cell_hist_k<0>, grid, block, 0, c->stream, bs, n, g, stride, hist); break;
+    case 1: hipLaunchKernelGGL(cell_hist_k<1>, grid, block, 0, c->stream, bs, n, g, stride, hist); break;
+    default: hipLaunchKernelGGL(cell_hist_k<2>, grid, block, 0, c->stream, bs, n, g, stride, hist); break;
+    }
     SCCD_HIP(hipGetLastError());
+}
+// statistics of a lazy list from every stride-th element; returns the number of block partials written
+int launch_elem_stats(sccd_ctx* c, const sccd_boxes* b, int stride, GridStats* st, double* part)
+{
+    const int n = b->n;
+    if (n == 0) return 0;
+    const int grid = std::min(grid_for((n + stride - 1) / stride), SCCD_STATS_BLOCKS);
+    const BoxSrc bs = box_src(b);
+    if (src_kind(b) == 1) hipLaunchKernelGGL(elem_stats_k<1>, dim3(grid), dim3(TPB), 0, c->stream, bs, n, stride, st, part);
+    else hipLaunchKernelGGL(elem_stats_k<2>, dim3(grid), dim3(TPB), 0, c->stream, bs, n, stride, st, part);
+    SCCD_HIP(hipGetLastError());
+    return grid;
 }
 void launch_shard_window(sccd_ctx* c, const uint32_t* hist, const GridParams* g, int stride, int rank, int parts, ShardWindow* out)
 {
     hipLaunchKernelGGL(shard_window_k, dim3(1), dim3(1024), 0, c->stream, hist, g, stride, rank, parts, out);
     SCCD_HIP(hipGetLastError());
 }
-void launch_cell_fill_append(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
+void launch_cell_fill_append(sccd_ctx* c, const sccd_boxes* b, const GridParams* g, int cell_lo, int cell_hi,
                              uint32_t* cursor, uint32_t capacity, uint32_t* key, uint32_t* idx, bool tagged, uint32_t* place,
                              const ShardWindow* d_win)
 {
+    const int n = b->n;
     if (n == 0) return;
-    hipLaunchKernelGGL(cell_fill_append_k, dim3((n + FILL_BOXES - 1) / FILL_BOXES), dim3(1024), 0, c->stream, raw, n, g, cell_lo, cell_hi,
-                       cursor, capacity, key, idx, tagged ? 1 : 0, place, d_win);
+    const dim3 grid((unsigned)((n + FILL_BOXES - 1) / FILL_BOXES)), block(1024);
+    const BoxSrc bs = box_src(b);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, block, 0, c->stream, bs, n, g, cell_lo, cell_hi, cursor, capacity, key, idx, tagged ? 1 : 0, place,
+                           d_win);
+    };
+    switch (src_kind(b)) {
+    case 0: go(cell_fill_append_k<0>); break;
+    case 1: go(cell_fill_append_k<1>); break;
+    default: go(cell_fill_append_k<2>); break;
+    }
     SCCD_HIP(hipGetLastError());
 }
-void launch_cell_fill_append_two(sccd_ctx* c, const sccd_aabb* raw_a, int na, const sccd_aabb* raw_b, int nb, const GridParams* g,
+void launch_cell_fill_append_two(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B, const GridParams* g,
                                  int cell_lo, int cell_hi, uint32_t* cursors, uint32_t capacity, uint32_t* key, uint32_t* idx,
                                  const ShardWindow* d_win)
 {
+    const int na = A->n, nb = B->n;
     const int blocks_a = (na + FILL_BOXES - 1) / FILL_BOXES, blocks_b = (nb + FILL_BOXES - 1) / FILL_BOXES;
     if (blocks_a + blocks_b == 0) return;
-    hipLaunchKernelGGL(cell_fill_append2_k, dim3((unsigned)(blocks_a + blocks_b)), dim3(1024), 0, c->stream, raw_a, na, raw_b, nb,
-                       blocks_a, g, cell_lo, cell_hi, cursors, capacity, key, idx, d_win);
+    const BoxSrc a = box_src(A), b = box_src(B);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(blocks_a + blocks_b)), dim3(1024), 0, c->stream, a, na, b, nb, blocks_a, g, cell_lo,
+                           cell_hi, cursors, capacity, key, idx, d_win);
+    };
+    // (list A of a two-list build is the vertices, always there; list B may be lazy faces)
+    SCCD_REQUIRE(src_kind(A) == 0, "broad phase: a lazy list A");
+    if (src_kind(B) == 0) go(cell_fill_append2_k<0, 0>);
+    else if (src_kind(B) == 2) go(cell_fill_append2_k<0, 2>);
+    else go(cell_fill_append2_k<0, 1>);
     SCCD_HIP(hipGetLastError());
 }
 void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,

@@ -37,6 +37,11 @@ struct sccd_boxes {
     int n = 0;
     int kind = BOX_UNKNOWN; // (uploaded boxes: unknown)
     DevBuf raw; // sccd_aabb[n]
+    // LAZY list (ccd() of a multi-GPU rank): `raw` is allocated but only the boxes of the rank's window of cells get written,
+    // by the fill pass, which computes every box from the vertex boxes and the element's vertex indices (boxes.hip BoxSrc)
+    bool lazy = false;
+    const sccd_aabb* lazy_vb = nullptr; // the vertex boxes
+    const void* lazy_elems = nullptr;   // int2[n] edges / int4[n] faces
     // bounds + extent partials of the list ({GridStats, pad to 128 B, double[n_part][3]}): written by the
     // box builders themselves (fused) or, for uploaded boxes, by box_stats_k on first use
     mutable DevBuf stats;
@@ -107,7 +112,8 @@ int launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st, do
 void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a, int n_part_a, const GridStats* st_b,
                        const double* part_b, int n_part_b, int n_total, int axis, double cell_factor, int shrink,
                        GridParams* g, uint32_t* cursors, bool reserve_tag = false);
-void launch_cell_hist(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int stride, uint32_t* hist);
+void launch_cell_hist(sccd_ctx* c, const sccd_boxes* b, const GridParams* g, int stride, uint32_t* hist);
+int launch_elem_stats(sccd_ctx* c, const sccd_boxes* b, int stride, GridStats* st, double* part);
 // a rank's window of cells, decided on the device (boxes.hip shard_window_k)
 struct ShardWindow {
     int cell_lo, cell_hi; // this rank's cells
@@ -117,11 +123,11 @@ struct ShardWindow {
 };
 void launch_shard_window(sccd_ctx* c, const uint32_t* hist, const GridParams* g, int stride, int rank, int parts, ShardWindow* out);
 // d_win != nullptr: the window is read from device memory (cell_lo / cell_hi are ignored)
-void launch_cell_fill_append(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,
+void launch_cell_fill_append(sccd_ctx* c, const sccd_boxes* b, const GridParams* g, int cell_lo, int cell_hi,
                              uint32_t* cursor, uint32_t capacity, uint32_t* key, uint32_t* idx, bool tagged = false,
                              uint32_t* place = nullptr, const ShardWindow* d_win = nullptr);
 // both lists of a merged two-list build in one launch: cursors[0] / [1] count list A's / B's entries, cursors[2] places both
-void launch_cell_fill_append_two(sccd_ctx* c, const sccd_aabb* raw_a, int na, const sccd_aabb* raw_b, int nb, const GridParams* g,
+void launch_cell_fill_append_two(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B, const GridParams* g,
                                  int cell_lo, int cell_hi, uint32_t* cursors, uint32_t capacity, uint32_t* key, uint32_t* idx,
                                  const ShardWindow* d_win = nullptr);
 void launch_cell_count(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams* g, int cell_lo, int cell_hi,

