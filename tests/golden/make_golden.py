@@ -69,6 +69,10 @@ if __name__ == "__main__":
     import orc
 
     G = {name: compute_case(orc, name) for name in CASES}
+    try:  # (the case that tells the arithmetic contracts apart is made by make_contract_case.py: keep it)
+        G["contract_split"] = json.load(open(os.path.join(HERE, "golden.json")))["contract_split"]
+    except Exception:
+        pass
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(G, f, indent=1, sort_keys=True)
     print(json.dumps(G, indent=1, sort_keys=True))

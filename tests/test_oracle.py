@@ -199,7 +199,7 @@ def test_golden_vectors(orc):
     from golden.make_golden import SLOW_CASES, compute_case
 
     for name, want in G.items():
-        if name in SLOW_CASES:
+        if name in SLOW_CASES or name == "contract_split":  # (its own test below: inputs and both answers are in the file)
             continue
         got = compute_case(orc, name)
         assert got == want, name
