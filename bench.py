@@ -365,7 +365,9 @@ def bench_boxes(args, ctx, sccd, scenes, torch):
     prof = ctx.profile()
     ms_sweep, launches = prof["sweep"]
     achieved = (BYTES_SWEEP_PER_BOX * n + 8.0 * pairs) * args.steps / (ms_sweep * 1e-3) / 1e9
-    tk = pmc_kernels("boxes1m")  # HBM bytes per sweep launch from the PMC passes of this build (tools/pmc_traffic.sh boxes1m)
+    # HBM bytes per sweep launch from the PMC passes of this build (tools/pmc_traffic.sh boxes1m): taken on the default
+    # 1M isotropic boxes, quoted for those only
+    tk = pmc_kernels("boxes1m") if (n == 1_000_000 and args.boxes_variant == "iso") else None
     kname = next((k for k in (tk or {}) if k.startswith("sweep_band_k")), None)
     traffic = tk[kname]["hbm_bytes_per_launch_corrected"] if kname else None
     cls = {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[0] > 0}
