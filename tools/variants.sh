@@ -8,7 +8,7 @@ CS=scalable-ccd_amd/csrc
 SRC=${VARIANT_SRC:-narrow}
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-inline-asm"
 mkdir -p scalable-ccd_amd/sccd/variants /tmp/variants
-OTHERS=""
+OTHERS="$CS/ti_census.o"
 for f in api boxes scan sort sweep narrow; do [ $f = $SRC ] || OTHERS="$OTHERS $CS/$f.o"; done
 for spec in "$@"; do
   name="${spec%%=*}"; defs="${spec#*=}"
