@@ -189,6 +189,8 @@ void sccd_destroy(sccd_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     delete static_cast<Pipeline*>(c->pipeline);
     c->pipeline = nullptr;
+    delete c->scratch_mesh;
+    c->scratch_mesh = nullptr;
     sccd_collect_profile(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->rb_event) (void)hipEventDestroy(c->rb_event);
@@ -338,13 +340,45 @@ static void mesh_set_vertices(sccd_mesh* m, const double* V0, const double* V1, 
     SCCD_HIP(hipStreamSynchronize(c->stream)); // borrowed inputs may go away after return
 }
 
-static void check_mesh_host(const double* V0, const double* V1, int nV, const int32_t* E, int nE, const int32_t* F, int nF);
-// Device-resident index matrices are validated on the device: an out-of-range vertex index would turn into wild
-// gathers in the box builders and the narrow phase (the reference asserts nothing and would fault).
-__global__ void mesh_index_check_k(const int32_t* __restrict__ idx, long long n, int nV, unsigned* __restrict__ bad)
+// (Re)fills a mesh from the caller's matrices.  Index matrices are validated on the device while they are packed
+// (pack_edges_k / pack_faces_k: an out-of-range vertex index would otherwise turn into wild gathers in the box builders
+// and the narrow phase -- the reference asserts nothing and would fault); the verdict comes back with the one
+// synchronisation this function ends with anyway (borrowed inputs may go away after return).
+static void mesh_fill(sccd_ctx* c, sccd_mesh* m, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
+                      const int32_t* F, int nF, int src_on_device)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && (idx[i] < 0 || idx[i] >= nV)) atomicOr(bad, 1u);
+    SCCD_REQUIRE(nV >= 0 && nE >= 0 && nF >= 0, "mesh: negative size");
+    SCCD_REQUIRE((nV == 0 || (V0 && V1)) && (nE == 0 || E) && (nF == 0 || F), "mesh: null matrix");
+    SCCD_REQUIRE(nV > 0 || (nE == 0 && nF == 0), "mesh: edge or face index out of range"); // (no vertex to index)
+    m->ctx = c;
+    m->nV = nV;
+    m->nE = nE;
+    m->nF = nF;
+    m->V.ensure(sizeof(double) * 6 * (size_t)std::max(nV, 1));
+    m->E.ensure(sizeof(int2) * (size_t)std::max(nE, 1));
+    m->F.ensure(sizeof(int4) * (size_t)std::max(nF, 1));
+    // staging: [the verdict word | raw E | raw F] (host sources)
+    c->tmp2.ensure(sizeof(int32_t) * (2 * (size_t)nE + 3 * (size_t)nF + 4));
+    unsigned* const d_bad = c->tmp2.as<unsigned>();
+    SCCD_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream));
+    const int32_t *dE = E, *dF = F;
+    if (!src_on_device) {
+        int32_t* t = c->tmp2.as<int32_t>() + 4;
+        copy_in(c, t, E, sizeof(int32_t) * 2 * (size_t)nE, 0);
+        copy_in(c, t + 2 * (size_t)nE, F, sizeof(int32_t) * 3 * (size_t)nF, 0);
+        dE = t;
+        dF = t + 2 * (size_t)nE;
+    }
+    launch_pack_edges(c, dE, nE, nV, m->E.as<int2>(), d_bad);
+    launch_pack_faces(c, dF, nF, nV, m->F.as<int4>(), d_bad);
+    unsigned bad = 0;
+    {
+        ReadBack rb(c);
+        rb.add(&bad, d_bad, sizeof bad);
+        mesh_set_vertices(m, V0, V1, src_on_device); // (ends with the synchronisation)
+        rb.sync();
+    }
+    SCCD_REQUIRE(bad == 0, "mesh: edge or face index out of range");
 }
 
 extern "C" int sccd_mesh_create(sccd_ctx* c, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
@@ -353,46 +387,21 @@ extern "C" int sccd_mesh_create(sccd_ctx* c, const double* V0, const double* V1,
     if (!c || !out) return SCCD_E_INVALID;
     *out = nullptr;
     return guarded(c, [&] {
-        SCCD_REQUIRE(nV >= 0 && nE >= 0 && nF >= 0, "mesh: negative size");
-        SCCD_REQUIRE((nV == 0 || (V0 && V1)) && (nE == 0 || E) && (nF == 0 || F), "mesh: null matrix");
-        if (!src_on_device) check_mesh_host(V0, V1, nV, E, nE, F, nF);
-        else if (nE + nF > 0) {
-            c->tmp2.ensure(sizeof(unsigned));
-            SCCD_HIP(hipMemsetAsync(c->tmp2.p, 0, sizeof(unsigned), c->stream));
-            if (nE > 0)
-                hipLaunchKernelGGL(mesh_index_check_k, dim3((unsigned)((2ll * nE + 255) / 256)), dim3(256), 0, c->stream, E,
-                                   2ll * nE, nV, c->tmp2.as<unsigned>());
-            if (nF > 0)
-                hipLaunchKernelGGL(mesh_index_check_k, dim3((unsigned)((3ll * nF + 255) / 256)), dim3(256), 0, c->stream, F,
-                                   3ll * nF, nV, c->tmp2.as<unsigned>());
-            SCCD_HIP(hipGetLastError());
-            unsigned bad = 0;
-            SCCD_HIP(hipMemcpyAsync(&bad, c->tmp2.p, sizeof bad, hipMemcpyDeviceToHost, c->stream));
-            SCCD_HIP(hipStreamSynchronize(c->stream));
-            SCCD_REQUIRE(bad == 0, "mesh: edge or face index out of range");
-        }
         std::unique_ptr<sccd_mesh> m(new sccd_mesh());
-        m->ctx = c;
-        m->nV = nV;
-        m->nE = nE;
-        m->nF = nF;
-        m->V.ensure(sizeof(double) * 6 * (size_t)std::max(nV, 1));
-        m->E.ensure(sizeof(int2) * (size_t)std::max(nE, 1));
-        m->F.ensure(sizeof(int4) * (size_t)std::max(nF, 1));
-        const int32_t *dE = E, *dF = F;
-        if (!src_on_device) {
-            c->tmp2.ensure(sizeof(int32_t) * (2 * (size_t)nE + 3 * (size_t)nF + 4));
-            int32_t* t = c->tmp2.as<int32_t>();
-            copy_in(c, t, E, sizeof(int32_t) * 2 * (size_t)nE, 0);
-            copy_in(c, t + 2 * (size_t)nE, F, sizeof(int32_t) * 3 * (size_t)nF, 0);
-            dE = t;
-            dF = t + 2 * (size_t)nE;
-        }
-        launch_pack_edges(c, dE, nE, m->E.as<int2>());
-        launch_pack_faces(c, dF, nF, m->F.as<int4>());
-        mesh_set_vertices(m.get(), V0, V1, src_on_device);
+        mesh_fill(c, m.get(), V0, V1, nV, E, nE, F, nF, src_on_device);
         *out = m.release();
     });
+}
+
+// The mesh behind the drivers that take HOST matrices (ccd(), ccd() with collisions, ipc_ccd_strategy()): owned by the
+// context and refilled call after call -- three allocations and three frees per call were 1 ms of a 5.6 ms ccd() on the
+// 1M-triangle cloth.
+static sccd_mesh* scratch_mesh_from_host(sccd_ctx* c, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
+                                         const int32_t* F, int nF)
+{
+    if (!c->scratch_mesh) c->scratch_mesh = new sccd_mesh();
+    mesh_fill(c, c->scratch_mesh, V0, V1, nV, E, nE, F, nF, 0);
+    return c->scratch_mesh;
 }
 
 extern "C" int sccd_mesh_update_vertices(sccd_mesh* m, const double* V0, const double* V1, int src_on_device)
@@ -444,21 +453,27 @@ static int build_elem_boxes(sccd_ctx* c, const sccd_aabb* vb, int nV, const int3
     return guarded(c, [&] {
         SCCD_REQUIRE(nV >= 0 && nM >= 0 && (nM == 0 || (vb && M && out)), "build_*_boxes: bad arguments");
         if (nM == 0) return;
-        for (size_t k = 0; k < (size_t)cols * (size_t)nM; k++)
-            SCCD_REQUIRE(M[k] >= 0 && M[k] < nV, "build_*_boxes: vertex index out of range");
+        SCCD_REQUIRE(nV > 0, "build_*_boxes: vertex index out of range");
         c->tmp0.ensure(sizeof(sccd_aabb) * (size_t)std::max(nV, 1));
-        c->tmp1.ensure(sizeof(int32_t) * (size_t)cols * (size_t)nM);
+        c->tmp1.ensure(sizeof(int32_t) * (size_t)cols * (size_t)nM + 16); // (+ the verdict word of the index check, at the end)
         c->tmp2.ensure(sizeof(int4) * (size_t)nM);
+        unsigned* const d_bad = reinterpret_cast<unsigned*>(c->tmp1.as<char>() + ((sizeof(int32_t) * (size_t)cols * (size_t)nM + 3) & ~(size_t)3));
+        SCCD_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream));
         c->np_scratch0.ensure(sizeof(sccd_aabb) * (size_t)nM);
         copy_in(c, c->tmp0.p, vb, sizeof(sccd_aabb) * (size_t)nV, 0);
         copy_in(c, c->tmp1.p, M, sizeof(int32_t) * (size_t)cols * (size_t)nM, 0);
         if (cols == 2) {
-            launch_pack_edges(c, c->tmp1.as<int32_t>(), nM, c->tmp2.as<int2>());
+            launch_pack_edges(c, c->tmp1.as<int32_t>(), nM, nV, c->tmp2.as<int2>(), d_bad);
             launch_edge_boxes(c, c->tmp0.as<sccd_aabb>(), c->tmp2.as<int2>(), nM, c->np_scratch0.as<sccd_aabb>());
         } else {
-            launch_pack_faces(c, c->tmp1.as<int32_t>(), nM, c->tmp2.as<int4>());
+            launch_pack_faces(c, c->tmp1.as<int32_t>(), nM, nV, c->tmp2.as<int4>(), d_bad);
             launch_face_boxes(c, c->tmp0.as<sccd_aabb>(), c->tmp2.as<int4>(), nM, c->np_scratch0.as<sccd_aabb>());
         }
+        // (indices are validated on the device while they are packed -- clamped, so the builders read nothing wild)
+        unsigned bad = 0;
+        SCCD_HIP(hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+        SCCD_REQUIRE(bad == 0, "build_*_boxes: vertex index out of range");
         SCCD_HIP(hipMemcpyAsync(out, c->np_scratch0.p, sizeof(sccd_aabb) * (size_t)nM, hipMemcpyDeviceToHost,
                                 c->stream));
         SCCD_HIP(hipStreamSynchronize(c->stream));
@@ -1629,14 +1644,6 @@ extern "C" int sccd_ccd_mesh_pass(sccd_ctx* c, const sccd_mesh* m, int is_vf, do
     });
 }
 
-static void check_mesh_host(const double* V0, const double* V1, int nV, const int32_t* E, int nE, const int32_t* F, int nF)
-{
-    SCCD_REQUIRE(nV >= 0 && nE >= 0 && nF >= 0, "ccd: negative size");
-    SCCD_REQUIRE((nV == 0 || (V0 && V1)) && (nE == 0 || E) && (nF == 0 || F), "ccd: null matrix");
-    for (size_t k = 0; k < 2 * (size_t)nE; k++) SCCD_REQUIRE(E[k] >= 0 && E[k] < nV, "ccd: edge index out of range");
-    for (size_t k = 0; k < 3 * (size_t)nF; k++) SCCD_REQUIRE(F[k] >= 0 && F[k] < nV, "ccd: face index out of range");
-}
-
 extern "C" int sccd_ccd(sccd_ctx* c, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
                         const int32_t* F, int nF, double ms, int max_iter, double tol, int allow_zero_toi,
                         int memory_limit_GB, double* toi)
@@ -1650,13 +1657,9 @@ extern "C" int sccd_ccd(sccd_ctx* c, const double* V0, const double* V1, int nV,
         ~Restore() { c->memory_limit_mb = v; }
     } restore { c, saved_limit };
     sccd_mesh* m = nullptr;
-    int rc = guarded(c, [&] { check_mesh_host(V0, V1, nV, E, nE, F, nF); });
+    const int rc = guarded(c, [&] { m = scratch_mesh_from_host(c, V0, V1, nV, E, nE, F, nF); });
     if (rc != SCCD_OK) return rc;
-    rc = sccd_mesh_create(c, V0, V1, nV, E, nE, F, nF, 0, &m);
-    if (rc != SCCD_OK) return rc;
-    rc = sccd_ccd_mesh(c, m, ms, max_iter, tol, allow_zero_toi, toi, nullptr);
-    sccd_mesh_destroy(m);
-    return rc;
+    return sccd_ccd_mesh(c, m, ms, max_iter, tol, allow_zero_toi, toi, nullptr);
 }
 
 // ccd() with the per-query collision list (ccd.cu:14-78 in a SCALABLE_CCD_TOI_PER_QUERY build): build, then alternate
@@ -1691,12 +1694,8 @@ extern "C" int sccd_ccd_collisions(sccd_ctx* c, const double* V0, const double* 
         int64_t v;
         ~Restore() { c->memory_limit_mb = v; }
     } restore { c, saved_limit };
-    sccd_mesh* m = nullptr;
-    int rc = guarded(c, [&] { check_mesh_host(V0, V1, nV, E, nE, F, nF); });
-    if (rc != SCCD_OK) return rc;
-    rc = sccd_mesh_create(c, V0, V1, nV, E, nE, F, nF, 0, &m);
-    if (rc != SCCD_OK) return rc;
-    rc = guarded(c, [&] {
+    return guarded(c, [&] {
+        sccd_mesh* const m = scratch_mesh_from_host(c, V0, V1, nV, E, nE, F, nF);
         Pipeline* pl = pipeline_of(c);
         boxes_from_mesh(c, m, ms, pl, true, true, true); // inflation radius = min_distance (ccd.cu:112)
         double t = 1;                                    // ccd.cu:125
@@ -1707,8 +1706,6 @@ extern "C" int sccd_ccd_collisions(sccd_ctx* c, const double* V0, const double* 
         *n_collisions = (int64_t)acc.size();
         *toi = t;
     });
-    sccd_mesh_destroy(m);
-    return rc;
 }
 
 extern "C" int sccd_dev_alloc(sccd_ctx* c, size_t bytes, void** d_ptr)
@@ -1783,12 +1780,8 @@ extern "C" int sccd_ipc_ccd_strategy(sccd_ctx* c, const double* V0, const double
                                      const int32_t* F, int nF, double ms, int max_iter, double tol, double* toi)
 {
     if (!c || !toi) return SCCD_E_INVALID;
-    sccd_mesh* m = nullptr;
-    int rc = guarded(c, [&] { check_mesh_host(V0, V1, nV, E, nE, F, nF); });
-    if (rc != SCCD_OK) return rc;
-    rc = sccd_mesh_create(c, V0, V1, nV, E, nE, F, nF, 0, &m);
-    if (rc != SCCD_OK) return rc;
-    rc = guarded(c, [&] {
+    return guarded(c, [&] {
+        sccd_mesh* const m = scratch_mesh_from_host(c, V0, V1, nV, E, nE, F, nF);
         Pipeline* pl = pipeline_of(c);
         boxes_from_mesh(c, m, ms, pl, true, true, true); // ipc_ccd_strategy.cu:123-125
         double earliest = 1.0;                           // :136
@@ -1796,8 +1789,6 @@ extern "C" int sccd_ipc_ccd_strategy(sccd_ctx* c, const double* V0, const double
         ipc_pass(c, m, pl, false, ms, max_iter, tol, &earliest);
         *toi = earliest;
     });
-    sccd_mesh_destroy(m);
-    return rc;
 }
 
 extern "C" int sccd_selftest_lds_gather(sccd_ctx* c, int n_waves, int n_active, int64_t* n_bad)

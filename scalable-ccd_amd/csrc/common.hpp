@@ -134,6 +134,7 @@ struct sccd_ctx {
     PinnedBuf h_scalars; // pinned mirror for async read-back
     DevBuf np_scratch0, np_scratch1, np_scratch2, np_scratch3, np_scratch4, np_scratch3_ovf;
     DevBuf tmp0, tmp1, tmp2;
+    struct sccd_mesh* scratch_mesh = nullptr; // the mesh behind the host-matrix drivers (api.hip: scratch_mesh_from_host)
     void* pipeline = nullptr; // cached pipeline objects (api.hip)
     hipEvent_t rb_event = nullptr; // ReadBack: polled, not waited for
     // ccd(): the edge-edge lists are built by a helper context (own stream, scratch and pinned mirror) on a worker

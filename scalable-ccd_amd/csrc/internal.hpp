@@ -93,8 +93,8 @@ struct sccd_broad_phase {
 // ------------------------------------------------------------------------------------------
 // boxes.hip
 void launch_pack_vertices(sccd_ctx* c, const double* dV0, const double* dV1, int nV, double* dV);
-void launch_pack_edges(sccd_ctx* c, const int32_t* dE, int nE, int2* out);
-void launch_pack_faces(sccd_ctx* c, const int32_t* dF, int nF, int4* out);
+void launch_pack_edges(sccd_ctx* c, const int32_t* dE, int nE, int nV, int2* out, unsigned* bad);
+void launch_pack_faces(sccd_ctx* c, const int32_t* dF, int nF, int nV, int4* out, unsigned* bad);
 // st / part may be null (no statistics); otherwise *st must be zeroed and the return value is the
 // number of block partials written
 int launch_vertex_boxes(sccd_ctx* c, const double* dV, int nV, double inflation, sccd_aabb* out, GridStats* st = nullptr,

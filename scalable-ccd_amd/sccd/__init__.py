@@ -221,10 +221,7 @@ class Mesh:
             if Fc.size and (Fc.ndim != 2 or Fc.shape[1] != 3):
                 raise RuntimeError("F must be k x 3")  # ccd.cu:98
             self.nV, self.nE, self.nF = V0c.shape[0], Ec.shape[0] if Ec.size else 0, Fc.shape[0] if Fc.size else 0
-            if self.nE and (Ec.min() < 0 or Ec.max() >= self.nV):
-                raise RuntimeError("edge index out of range")
-            if self.nF and (Fc.min() < 0 or Fc.max() >= self.nV):
-                raise RuntimeError("face index out of range")
+            # (vertex indices are validated by the library, on the device, while it packs E and F)
             self._keep = (V0c, V1c, Ec, Fc)
             args = (_ptr(V0c), _ptr(V1c), C.c_int(self.nV), _ptr(Ec), C.c_int(self.nE), _ptr(Fc), C.c_int(self.nF))
         self.ctx._check(lib().sccd_mesh_create(self.ctx._h, *args, C.c_int(int(on_device)), C.byref(self._h)))

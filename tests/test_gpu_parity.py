@@ -619,6 +619,28 @@ def test_ccd_argument_errors(sccd, ctx):
     bad[0, 0] = len(V0)
     with pytest.raises(RuntimeError):
         sccd.ccd(V0, V1, E, bad, ctx=ctx)
+    # vertex indices are validated on the device while E and F are packed (csrc/boxes.hip pack_*_k): every entry that
+    # takes index matrices refuses a bad one -- first, last, negative -- and the context works on afterwards
+    want = sccd.ccd(V0, V1, E, F, ctx=ctx)
+    for where, value in ((0, len(V0)), (-1, len(V0) + 7), (len(F) // 2, -1)):
+        badF, badE = F.copy(), E.copy()
+        badF[where, 2] = value
+        badE[where % len(E), 1] = value
+        for args in ((E, badF), (badE, F)):
+            with pytest.raises(RuntimeError, match="out of range"):
+                sccd.ccd(V0, V1, *args, ctx=ctx)
+            with pytest.raises(RuntimeError, match="out of range"):
+                sccd.Mesh(V0, V1, *args, ctx=ctx)
+            with pytest.raises(RuntimeError, match="out of range"):
+                sccd.ipc_ccd_strategy(V0, V1, *args, 0.0, -1, 1e-6, ctx=ctx)
+            with pytest.raises(RuntimeError, match="out of range"):
+                sccd.ccd(V0, V1, *args, ctx=ctx, want_collisions=True)
+        vb = sccd.build_vertex_boxes(V0, V1, 0.0, ctx)
+        with pytest.raises(RuntimeError, match="out of range"):
+            sccd.build_face_boxes(vb, badF, ctx)
+        with pytest.raises(RuntimeError, match="out of range"):
+            sccd.build_edge_boxes(vb, badE, ctx)
+        assert sccd.ccd(V0, V1, E, F, ctx=ctx) == want
     # nothing moves: the reference's EE tol[1] quirk (root_finder.cu:82-85) makes coplanar static
     # edges "collide" at t = 0; the restatement and the HIP path reproduce that
     from orc import ccd as oracle_ccd
