@@ -66,7 +66,11 @@ public:
         if (sccd_create(device, &m_ctx) != SCCD_OK)
             throw std::runtime_error(std::string("sccd_create: ") + sccd_last_error(nullptr));
     }
-    ~Context() { sccd_destroy(m_ctx); }
+    ~Context()
+    {
+        sccd_mesh_destroy(m_call_mesh);
+        sccd_destroy(m_ctx);
+    }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
     sccd_ctx* get() const { return m_ctx; }
@@ -80,9 +84,18 @@ public:
         static Context ctx(0);
         return ctx;
     }
+    /// The packed mesh behind narrow_phase() calls that hand over four DeviceMatrix (the reference's argument list): kept
+    /// by the context and refilled call after call -- no allocation per call.
+    sccd_mesh* call_mesh(const double* V0, const double* V1, int nV, const int32_t* E, int nE, const int32_t* F, int nF)
+    {
+        if (!m_call_mesh) check(sccd_mesh_create(m_ctx, V0, V1, nV, E, nE, F, nF, /*src_on_device=*/1, &m_call_mesh));
+        else check(sccd_mesh_assign(m_call_mesh, V0, V1, nV, E, nE, F, nF, /*src_on_device=*/1));
+        return m_call_mesh;
+    }
 
 private:
     sccd_ctx* m_ctx = nullptr;
+    sccd_mesh* m_call_mesh = nullptr;
 };
 
 /// Two packed ints, the element type of the overlap list (CUDA's int2 in the reference).
@@ -457,7 +470,7 @@ namespace detail {
             sccd_free(col);
         }
     }
-    struct MeshOfMatrices { // the library's packed mesh (sccd_mesh) of four device matrices, for one call
+    struct MeshOfMatrices { // the library's packed mesh (sccd_mesh) of four device matrices, for one call (owned by the context)
         sccd_mesh* m = nullptr;
         MeshOfMatrices(Context& ctx, const DeviceMatrix<Scalar>& V0, const DeviceMatrix<Scalar>& V1,
                        const DeviceMatrix<int>& E, const DeviceMatrix<int>& F)
@@ -465,10 +478,8 @@ namespace detail {
             if (V0.rows() != V1.rows() || (V0.rows() && (V0.cols() != 3 || V1.cols() != 3)) || (E.rows() && E.cols() != 2)
                 || (F.rows() && F.cols() != 3))
                 throw std::runtime_error("narrow_phase: V must be n x 3, E m x 2, F k x 3");
-            ctx.check(sccd_mesh_create(ctx.get(), V0.data(), V1.data(), (int)V0.rows(), E.data(), (int)E.rows(), F.data(),
-                                       (int)F.rows(), /*src_on_device=*/1, &m));
+            m = ctx.call_mesh(V0.data(), V1.data(), (int)V0.rows(), E.data(), (int)E.rows(), F.data(), (int)F.rows());
         }
-        ~MeshOfMatrices() { sccd_mesh_destroy(m); }
     };
 } // namespace detail
 

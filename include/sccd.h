@@ -113,6 +113,10 @@ int sccd_dev_copy(sccd_ctx* ctx, void* d_dst, const void* d_src, size_t bytes); 
 int sccd_mesh_create(sccd_ctx* ctx, const double* V0, const double* V1, int nV, const int32_t* E,
                      int nE, const int32_t* F, int nF, int src_on_device, sccd_mesh** out);
 int sccd_mesh_update_vertices(sccd_mesh* mesh, const double* V0, const double* V1, int src_on_device);
+/* all four matrices again, into the mesh's own buffers (grown where needed): what narrow_phase() with the reference's
+   argument list -- four DeviceMatrix per call, narrow_phase.cuh:30-46 -- does without allocating per call */
+int sccd_mesh_assign(sccd_mesh* mesh, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
+                     const int32_t* F, int nF, int src_on_device);
 void sccd_mesh_destroy(sccd_mesh* mesh);
 
 /* ------------------------------------------------------------------------------------------ */

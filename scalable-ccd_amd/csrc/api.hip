@@ -404,6 +404,13 @@ static sccd_mesh* scratch_mesh_from_host(sccd_ctx* c, const double* V0, const do
     return c->scratch_mesh;
 }
 
+extern "C" int sccd_mesh_assign(sccd_mesh* m, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
+                                const int32_t* F, int nF, int src_on_device)
+{
+    if (!m) return SCCD_E_INVALID;
+    return guarded(m->ctx, [&] { mesh_fill(m->ctx, m, V0, V1, nV, E, nE, F, nF, src_on_device); });
+}
+
 extern "C" int sccd_mesh_update_vertices(sccd_mesh* m, const double* V0, const double* V1, int src_on_device)
 {
     if (!m) return SCCD_E_INVALID;

@@ -44,7 +44,7 @@ PROF_NAMES = ["boxes", "sort", "ranges", "sweep", "narrow_vf", "narrow_ee"]
 # every symbol include/sccd.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     "sccd_create", "sccd_destroy", "sccd_last_error", "sccd_version", "sccd_set_stream", "sccd_synchronize",
-    "sccd_set_option", "sccd_get_option", "sccd_mesh_create", "sccd_mesh_update_vertices", "sccd_mesh_destroy",
+    "sccd_set_option", "sccd_get_option", "sccd_mesh_create", "sccd_mesh_update_vertices", "sccd_mesh_assign", "sccd_mesh_destroy",
     "sccd_build_vertex_boxes", "sccd_build_edge_boxes", "sccd_build_face_boxes", "sccd_boxes_create",
     "sccd_boxes_from_mesh", "sccd_boxes_size", "sccd_boxes_download", "sccd_boxes_destroy",
     "sccd_broad_phase_create", "sccd_broad_phase_destroy", "sccd_broad_phase_build",
