@@ -454,10 +454,12 @@ struct CellSpan {
 __device__ __forceinline__ CellSpan cell_span(const GridParams& g, const BoxLoad& b)
 {
     CellSpan s;
-    s.a0 = grid_cell_a(g, b.lo[g.aa]);
-    s.a1 = grid_cell_a(g, b.hi[g.aa]);
-    s.b0 = grid_cell_b(g, b.lo[g.ab]);
-    s.b1 = grid_cell_b(g, b.hi[g.ab]);
+    // (sel3d, not b.lo[g.aa]: an array indexed by a run-time value lives in scratch memory -- 56 bytes per thread of it,
+    // stored and re-read for every box, in the two-list fill until round 3)
+    s.a0 = grid_cell_a(g, sel3d(b.lo, g.aa));
+    s.a1 = grid_cell_a(g, sel3d(b.hi, g.aa));
+    s.b0 = grid_cell_b(g, sel3d(b.lo, g.ab));
+    s.b1 = grid_cell_b(g, sel3d(b.hi, g.ab));
     return s;
 }
 
@@ -492,7 +494,7 @@ __global__ void cell_fill_k(const sccd_aabb* __restrict__ raw, int n, const Grid
     const GridParams g = *gp;
     const BoxLoad b = load_box_geom(raw + i);
     const CellSpan s = cell_span(g, b);
-    const unsigned q = grid_qx(g, b.lo[g.axis]);
+    const unsigned q = grid_qx(g, sel3d(b.lo, g.axis));
     uint32_t at = offsets[i];
     for (int ca = s.a0; ca <= s.a1; ca++)
         for (int cb = s.b0; cb <= s.b1; cb++) {
@@ -565,7 +567,7 @@ __device__ __forceinline__ void cell_fill_append_body(const BoxSrc& bs, int n, c
             int4 ids = make_int4(0, 0, 0, 0);
             const BoxLoad b = src_box<SRC>(bs, i, &ids);
             s[k] = cell_span(g, b);
-            q[k] = grid_qx(g, b.lo[g.axis]);
+            q[k] = grid_qx(g, sel3d(b.lo, g.axis));
             for (int ca = s[k].a0; ca <= s[k].a1; ca++) {
                 const int c0 = max(ca * g.Sb + s[k].b0, cell_lo), c1 = min(ca * g.Sb + s[k].b1, cell_hi - 1);
                 cnt[k] += c1 >= c0 ? (uint32_t)(c1 - c0 + 1) : 0u;

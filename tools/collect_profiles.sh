@@ -10,6 +10,10 @@ for W in cloth1m boxes1m sort16m; do
   rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_$W --output-format csv -- python3 bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof/ks_$W.log 2>&1
   cp $(ls gpurun_out/prof/ks_$W/*/*kernel_stats.csv | tail -1) gpurun_out/prof/${R}_${W}_kernel_stats.csv
 done
+# (the default step overlaps two streams: each kernel's own duration, one kernel at a time on the chip, is in this trace)
+rm -rf gpurun_out/prof/ks_cloth1m_apart
+SCCD_OVERLAP=0 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_cloth1m_apart --output-format csv -- python3 bench.py --workload cloth1m --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof/ks_cloth1m_apart.log 2>&1
+cp $(ls gpurun_out/prof/ks_cloth1m_apart/*/*kernel_stats.csv | tail -1) gpurun_out/prof/${R}_cloth1m_passes_apart_kernel_stats.csv
 for W in cloth1m sort16m boxes1m; do
   bash tools/pmc_traffic.sh $W > gpurun_out/prof/pmc_traffic_$W.txt 2>&1
   cp gpurun_out/pmc_traffic_$W.json gpurun_out/prof/${R}_pmc_traffic_$W.json
