@@ -7,7 +7,7 @@ f=sorted(glob.glob("gpurun_out/kstats/*/*kernel_stats.csv"))[-1]
 rows=list(csv.DictReader(open(f)))
 tot=0
 for r in rows:
-    nm=r["Name"]; nm=nm[23:] if nm.startswith("(anon") else nm
+    nm=r["Name"].replace("(anonymous namespace)::","").replace("void ","")
     per=float(r["TotalDurationNs"])/6e6
     tot+=per
     print("%-28s calls/step %5.1f  ms/step %.4f  avg_us %.1f" % (nm[:28], int(r["Calls"])/6, per, float(r["AverageNs"])/1e3))
