@@ -18,6 +18,9 @@ print("|---|---|---|---|---|---|")
 for w in ("cloth1m", "boxes1m", "sort16m"):
     pj = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_{w}.json")
     ks = os.path.join(ROOT, "profiles", f"{tag}_{w}_kernel_stats.csv")
+    apart = os.path.join(ROOT, "profiles", f"{tag}_{w}_passes_apart_kernel_stats.csv")  # one kernel at a time on the chip
+    if os.path.exists(apart):
+        ks = apart
     if not (os.path.exists(pj) and os.path.exists(ks)):
         continue
     traffic = {short(k): v["hbm_bytes_per_launch_corrected"] for k, v in json.load(open(pj))["kernels"].items()}

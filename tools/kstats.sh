@@ -13,4 +13,4 @@ for r in rows:
     print("%-28s calls/step %5.1f  ms/step %.4f  avg_us %.1f" % (nm[:28], int(r["Calls"])/6, per, float(r["AverageNs"])/1e3))
 print("sum ms/step", round(tot,3))
 PY
-tail -1 gpurun_out/kstats.log | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('bench ms/step', d['ms_per_step'])"
+grep '^{"metric"' gpurun_out/kstats.log | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('bench ms/step', d['ms_per_step'])"
