@@ -29,6 +29,7 @@
 #include <string>
 #include <tuple>
 #include <utility>
+#include <algorithm>
 #include <vector>
 
 #if defined(__has_include)
@@ -431,6 +432,39 @@ inline void sort_and_sweep(std::vector<AABB> boxesA, std::vector<AABB> boxesB, i
         throw;
     }
     ctx.set_option(SCCD_OPT_SORT_AXIS, saved);
+}
+
+/// sort_along_axis() (broad_phase/sort_and_sweep.hpp:11, sort_and_sweep.cpp:126-141): orders host boxes by min[axis].  The device
+/// path sorts its own keys; this is for callers that use the reference's two-step form (sort, then sweep<>()).
+inline void sort_along_axis(const int axis, std::vector<AABB>& boxes)
+{
+    if (axis < 0 || axis > 2) throw std::runtime_error("sort_along_axis: axis must be 0, 1 or 2");
+    std::sort(boxes.begin(), boxes.end(), [axis](const AABB& a, const AABB& b) { return a.min[axis] < b.min[axis]; });
+}
+/// sweep<is_two_lists>() (sort_and_sweep.hpp:18-22, sort_and_sweep.cpp:143-195): the boxes of one list, or of two lists MERGED
+/// with the first list's element ids flipped to -id - 1 (sort_and_sweep.cpp:228-237); pairs come back as (min id, max id), or
+/// as (first-list id, second-list id) with the flip undone (:104-109); sort_axis in: the axis swept, out: the arg-max-variance
+/// axis of the box centres.  Served by the device path, which orders the boxes itself.
+template <bool is_two_lists>
+void sweep(std::vector<AABB>& boxes, int& sort_axis, std::vector<std::pair<int, int>>& overlaps,
+           Context& ctx = Context::default_context())
+{
+    overlaps.clear();
+    if (boxes.empty()) return;
+    if constexpr (!is_two_lists) {
+        sort_and_sweep(boxes, sort_axis, overlaps, ctx);
+    } else {
+        std::vector<AABB> first, second;
+        for (const AABB& box : boxes) {
+            if (box.element_id < 0) {
+                first.push_back(box);
+                first.back().element_id = -box.element_id - 1;
+            } else {
+                second.push_back(box);
+            }
+        }
+        sort_and_sweep(std::move(first), std::move(second), sort_axis, overlaps, ctx);
+    }
 }
 
 /// The four DeviceMatrix objects of ccd() (ccd.cu:103-106) as one device-resident mesh.

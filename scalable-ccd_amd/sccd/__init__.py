@@ -398,6 +398,25 @@ def sort_and_sweep(boxes, boxes_b=None, sort_axis=0, ctx=None):
     return pairs, ax.value
 
 
+def sort_along_axis(axis, boxes):
+    """sort_along_axis() of broad_phase/sort_and_sweep.hpp:11 (sort_and_sweep.cpp:126-141): the boxes ordered by min[axis]."""
+    if axis not in (0, 1, 2):
+        raise RuntimeError("sort_along_axis: axis must be 0, 1 or 2")
+    b = np.asarray(boxes)
+    return b[np.argsort(b["min"][:, axis], kind="stable")]
+
+
+def sweep(boxes, sort_axis=0, two_lists=False, ctx=None):
+    """sweep<is_two_lists>() of sort_and_sweep.hpp:18-22 (sort_and_sweep.cpp:143-195): one list, or two lists MERGED with the first
+    list's element ids flipped to -id - 1 (:228-237).  -> (pairs, next_sort_axis); served by the device path."""
+    b = np.asarray(boxes)
+    if not two_lists:
+        return sort_and_sweep(b, None, sort_axis, ctx)
+    first = b[b["element_id"] < 0].copy()
+    first["element_id"] = -first["element_id"] - 1
+    return sort_and_sweep(first, b[b["element_id"] >= 0], sort_axis, ctx)
+
+
 def narrow_phase(mesh, overlaps, is_vf, max_iter=-1, tol=1e-6, ms=0.0, allow_zero_toi=True, toi=1.0,
                  want_collisions=False, n=None):
     """narrow_phase<is_vf>() of narrow_phase.cuh:30-46.  overlaps: int32[n,2] host array, or a

@@ -223,6 +223,33 @@ int main()
         CHECK(sort_axis == want_axis);
     }
     {
+        // the reference's two-step form: sort_along_axis(), then sweep<is_two_lists>() on the sorted (and, for two lists,
+        // merged and id-flipped) boxes -- sort_and_sweep.cpp:126-141,143-195,221-240
+        int sort_axis = 0, want_axis = 0;
+        std::vector<AABB> sorted_e = edge_boxes;
+        sort_along_axis(sort_axis, sorted_e);
+        CHECK(std::is_sorted(sorted_e.begin(), sorted_e.end(), [](const AABB& a, const AABB& b) { return a.min[0] < b.min[0]; }));
+        std::vector<std::pair<int, int>> got;
+        sweep<false>(sorted_e, sort_axis, got);
+        std::sort(got.begin(), got.end());
+        CHECK(got == want_ee);
+        on = orc_sort_and_sweep(oeb.data(), nE, &want_axis, &op, 4);
+        orc_free(op);
+        CHECK(sort_axis == want_axis);
+        std::vector<AABB> a = vertex_boxes, b = face_boxes, merged(vertex_boxes.size() + face_boxes.size());
+        sort_along_axis(0, a);
+        sort_along_axis(0, b);
+        for (AABB& box : a) box.element_id = -box.element_id - 1;
+        std::merge(a.begin(), a.end(), b.begin(), b.end(), merged.begin(), [](const AABB& x, const AABB& y) { return x.min[0] < y.min[0]; });
+        sort_axis = want_axis = 0;
+        sweep<true>(merged, sort_axis, got);
+        std::sort(got.begin(), got.end());
+        CHECK(got == want_vf);
+        on = orc_sort_and_sweep_two_lists(ovb.data(), nV, ofb.data(), nF, &want_axis, &op, 4);
+        orc_free(op);
+        CHECK(sort_axis == want_axis);
+    }
+    {
         int sort_axis = 0;
         std::vector<std::pair<int, int>> got = { { 1, 2 } };
         sort_and_sweep(std::vector<AABB>(), sort_axis, got);

@@ -302,6 +302,20 @@ def test_cpu_entry_point_sort_and_sweep(sccd, ctx, orc, axis):
     assert ctx.get_option(sccd.OPT_SORT_AXIS) == 0  # the context's own setting is restored
     empty, ax = sccd.sort_and_sweep(b[:0], sort_axis=axis, ctx=ctx)
     assert len(empty) == 0 and ax == axis
+    # the reference's two-step form (sort_and_sweep.cpp:126-141,143-195,221-240): sort_along_axis, then sweep<> on the sorted
+    # boxes -- two lists merged, the first list's ids flipped to -id - 1
+    se = sccd.sort_along_axis(axis, eb)
+    assert np.all(np.diff(se["min"][:, axis]) >= 0)
+    want, want_axis, _ = orc.sort_and_sweep(eb, sort_axis=axis)
+    got, got_axis = sccd.sweep(se, axis, two_lists=False, ctx=ctx)
+    assert np.array_equal(_sorted(got), want) and got_axis == want_axis
+    fa = sccd.sort_along_axis(axis, vb).copy()
+    fa["element_id"] = -fa["element_id"] - 1
+    merged = np.concatenate([fa, sccd.sort_along_axis(axis, fb)])
+    merged = merged[np.argsort(merged["min"][:, axis], kind="stable")]
+    want, want_axis, _ = orc.sort_and_sweep(vb, fb, sort_axis=axis)
+    got, got_axis = sccd.sweep(merged, axis, two_lists=True, ctx=ctx)
+    assert np.array_equal(_sorted(got), want) and got_axis == want_axis
 
 
 def test_random_100k_matches_golden_hash(sccd, ctx):
