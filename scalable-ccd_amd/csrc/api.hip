@@ -344,8 +344,9 @@ static void mesh_set_vertices(sccd_mesh* m, const double* V0, const double* V1, 
 // (pack_edges_k / pack_faces_k: an out-of-range vertex index would otherwise turn into wild gathers in the box builders
 // and the narrow phase -- the reference asserts nothing and would fault); the verdict comes back with the one
 // synchronisation this function ends with anyway (borrowed inputs may go away after return).
+constexpr size_t MESH_VERDICT_MIRROR = 11264; // the deferred verdict's slot in the pinned mirror (common.hpp: h_scalars)
 static void mesh_fill(sccd_ctx* c, sccd_mesh* m, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
-                      const int32_t* F, int nF, int src_on_device)
+                      const int32_t* F, int nF, int src_on_device, bool defer_verdict = false)
 {
     SCCD_REQUIRE(nV >= 0 && nE >= 0 && nF >= 0, "mesh: negative size");
     SCCD_REQUIRE((nV == 0 || (V0 && V1)) && (nE == 0 || E) && (nF == 0 || F), "mesh: null matrix");
@@ -360,24 +361,47 @@ static void mesh_fill(sccd_ctx* c, sccd_mesh* m, const double* V0, const double*
     // staging: [the verdict word | raw E | raw F] (host sources)
     c->tmp2.ensure(sizeof(int32_t) * (2 * (size_t)nE + 3 * (size_t)nF + 4));
     unsigned* const d_bad = c->tmp2.as<unsigned>();
-    SCCD_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream));
     const int32_t *dE = E, *dF = F;
+    const double *d0 = V0, *d1 = V1;
     if (!src_on_device) {
+        // the four uploads back to back (a copy from pageable memory blocks the host: anything issued between two of them
+        // -- the pack kernels used to be -- costs the link 15-50 us of idle time), then everything that works on them
+        const size_t nb = sizeof(double) * 3 * (size_t)nV;
+        c->tmp0.ensure(nb);
+        c->tmp1.ensure(nb);
         int32_t* t = c->tmp2.as<int32_t>() + 4;
+        copy_in(c, c->tmp0.p, V0, nb, 0);
+        copy_in(c, c->tmp1.p, V1, nb, 0);
         copy_in(c, t, E, sizeof(int32_t) * 2 * (size_t)nE, 0);
         copy_in(c, t + 2 * (size_t)nE, F, sizeof(int32_t) * 3 * (size_t)nF, 0);
         dE = t;
         dF = t + 2 * (size_t)nE;
+        d0 = c->tmp0.as<double>();
+        d1 = c->tmp1.as<double>();
     }
+    SCCD_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream));
+    launch_pack_vertices(c, d0, d1, nV, m->V.as<double>());
     launch_pack_edges(c, dE, nE, nV, m->E.as<int2>(), d_bad);
     launch_pack_faces(c, dF, nF, nV, m->F.as<int4>(), d_bad);
+    if (defer_verdict) {
+        // ccd() from host matrices: the step is enqueued right behind the packing, and the verdict is looked at when the call
+        // has synchronised anyway (mesh_deferred_verdict; the clamped indices keep the step harmless meanwhile)
+        SCCD_HIP(hipMemcpyAsync(c->h_scalars.as<char>() + MESH_VERDICT_MIRROR, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        return;
+    }
     unsigned bad = 0;
     {
-        ReadBack rb(c);
+        ReadBack rb(c); // (also the synchronisation this function owes its caller: borrowed inputs may go away after return)
         rb.add(&bad, d_bad, sizeof bad);
-        mesh_set_vertices(m, V0, V1, src_on_device); // (ends with the synchronisation)
         rb.sync();
     }
+    SCCD_REQUIRE(bad == 0, "mesh: edge or face index out of range");
+}
+static void mesh_deferred_verdict(sccd_ctx* c)
+{
+    SCCD_HIP(hipStreamSynchronize(c->stream));
+    unsigned bad = 0;
+    std::memcpy(&bad, c->h_scalars.as<char>() + MESH_VERDICT_MIRROR, sizeof bad);
     SCCD_REQUIRE(bad == 0, "mesh: edge or face index out of range");
 }
 
@@ -397,10 +421,10 @@ extern "C" int sccd_mesh_create(sccd_ctx* c, const double* V0, const double* V1,
 // context and refilled call after call -- three allocations and three frees per call were 1 ms of a 5.6 ms ccd() on the
 // 1M-triangle cloth.
 static sccd_mesh* scratch_mesh_from_host(sccd_ctx* c, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
-                                         const int32_t* F, int nF)
+                                         const int32_t* F, int nF, bool defer_verdict = false)
 {
     if (!c->scratch_mesh) c->scratch_mesh = new sccd_mesh();
-    mesh_fill(c, c->scratch_mesh, V0, V1, nV, E, nE, F, nF, 0);
+    mesh_fill(c, c->scratch_mesh, V0, V1, nV, E, nE, F, nF, 0, defer_verdict);
     return c->scratch_mesh;
 }
 
@@ -1664,9 +1688,11 @@ extern "C" int sccd_ccd(sccd_ctx* c, const double* V0, const double* V1, int nV,
         ~Restore() { c->memory_limit_mb = v; }
     } restore { c, saved_limit };
     sccd_mesh* m = nullptr;
-    const int rc = guarded(c, [&] { m = scratch_mesh_from_host(c, V0, V1, nV, E, nE, F, nF); });
+    int rc = guarded(c, [&] { m = scratch_mesh_from_host(c, V0, V1, nV, E, nE, F, nF, /*defer_verdict=*/true); });
     if (rc != SCCD_OK) return rc;
-    return sccd_ccd_mesh(c, m, ms, max_iter, tol, allow_zero_toi, toi, nullptr);
+    rc = sccd_ccd_mesh(c, m, ms, max_iter, tol, allow_zero_toi, toi, nullptr);
+    const int rc_mesh = guarded(c, [&] { mesh_deferred_verdict(c); }); // (an index out of range outranks whatever the step made of it)
+    return rc_mesh != SCCD_OK ? rc_mesh : rc;
 }
 
 // ccd() with the per-query collision list (ccd.cu:14-78 in a SCALABLE_CCD_TOI_PER_QUERY build): build, then alternate
