@@ -890,9 +890,10 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     ShardWindow* const d_win = reinterpret_cast<ShardWindow*>(bp->grid.as<char>() + 1024);
     bool device_window_tried = false, device_window_redo = false;
     for (int shrink = 0;; shrink++) {
+        // (a sharded build: the sampled cell histogram behind the grid block is zeroed by the same launch)
         launch_grid_setup(c, A->stats_head(), A->stats_part(), A->n_part, B ? B->stats_head() : nullptr,
                           B ? B->stats_part() : nullptr, B ? B->n_part : 0, n_total, axis, cf, shrink, gp,
-                          d_total, want_merged);
+                          d_total, want_merged, c->shard_count > 1 ? bp->grid.as<uint32_t>() + 1024 : nullptr);
         const bool can_shrink = shrink < 10;
         // Multi-GPU: every rank takes a contiguous window of cells with an equal share of the
         // entries, and builds / sorts / sweeps only that window.  A pair is reported from exactly
@@ -901,17 +902,13 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
         const bool device_window = c->shard_count > 1 && shrink == 0 && !device_window_tried && device_window_env && !scan_build_env;
         if (device_window) {
             device_window_tried = true;
-            uint32_t* d_hist = bp->grid.as<uint32_t>() + 1024; // bytes [4096, ...) of the grid block
-            SCCD_HIP(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * SCCD_MAX_CELLS, c->stream));
-            launch_cell_hist(c, A, gp, SHARD_HIST_STRIDE, d_hist);
-            if (B) launch_cell_hist(c, B, gp, SHARD_HIST_STRIDE, d_hist);
+            uint32_t* d_hist = bp->grid.as<uint32_t>() + 1024; // bytes [4096, ...) of the grid block (zeroed by grid_setup_k)
+            launch_cell_hist(c, A, B, gp, SHARD_HIST_STRIDE, d_hist);
             launch_shard_window(c, d_hist, gp, SHARD_HIST_STRIDE, c->shard_rank, c->shard_count, d_win);
             bp->row_shard = false;
         } else if (c->shard_count > 1) {
-            uint32_t* d_hist = bp->grid.as<uint32_t>() + 1024; // bytes [4096, 8192) of the grid block
-            SCCD_HIP(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * SCCD_MAX_CELLS, c->stream));
-            launch_cell_hist(c, A, gp, SHARD_HIST_STRIDE, d_hist);
-            if (B) launch_cell_hist(c, B, gp, SHARD_HIST_STRIDE, d_hist);
+            uint32_t* d_hist = bp->grid.as<uint32_t>() + 1024; // bytes [4096, ...) of the grid block (zeroed by grid_setup_k)
+            launch_cell_hist(c, A, B, gp, SHARD_HIST_STRIDE, d_hist);
             static thread_local std::vector<uint32_t> hist_v(SCCD_MAX_CELLS);
             uint32_t* hist = hist_v.data();
             GridParams hgp;

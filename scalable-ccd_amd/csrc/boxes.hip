@@ -341,9 +341,11 @@ __global__ __launch_bounds__(SCCD_STATS_BLOCKS) void grid_setup_k(const GridStat
                              const GridStats* __restrict__ st_b, const double* __restrict__ part_b, int n_part_b,
                              int n_total, int axis, double cell_factor, int shrink, GridParams* __restrict__ g,
                              uint32_t* __restrict__ cursors /* the two list cursors of the fill pass: zeroed here */,
-                             int max_cells, int reserve_tag)
+                             int max_cells, int reserve_tag, uint32_t* __restrict__ zero_hist /* [SCCD_MAX_CELLS] or null */)
 {
     if (threadIdx.x < 3) cursors[threadIdx.x] = 0u; // the two list totals and the placement cursor of a merged two-list fill
+    if (zero_hist) // (multi-GPU: the sampled cell histogram the next launch adds to -- a memset of its own was a launch more)
+        for (int k = threadIdx.x; k < SCCD_MAX_CELLS; k += SCCD_STATS_BLOCKS) zero_hist[k] = 0u;
     // Bounds and summed extents of both lists from the builders' block partials: thread j takes partial j of list A and of
     // list B (18 loads in flight, ONE memory round trip -- the kernel is on the critical path of every build and used to
     // make 72 of them in a row), then a tree in LDS that adds in a FIXED order: the same bits on every run and every rank
@@ -509,23 +511,42 @@ __global__ void cell_fill_k(const sccd_aabb* __restrict__ raw, int n, const Grid
 // Entries per cell, from every `stride`-th box (multi-GPU: the ranks take contiguous cell windows
 // of about equal entry counts; ANY partition of the cells is correct, so a sample is enough --
 // it only has to be the same sample on every rank).
+// A block takes a CONTIGUOUS run of the samples (elements that follow each other in a mesh lie in a few cells: the flush at
+// the end adds only the bins the block touched) and there are enough blocks for one sample per thread: round 2's 64 blocks
+// with samples strided over the grid walked eight dependent gathers per thread -- 23-27 us of an 8-rank step's 530.
 template <int SRC>
-__global__ void cell_hist_k(BoxSrc bs, int n, const GridParams* __restrict__ gp, int stride, uint32_t* __restrict__ hist /*[n_cells]*/)
+__device__ __forceinline__ void cell_hist_body(uint32_t* h, const BoxSrc& bs, int n, const GridParams& g, int stride,
+                                               uint32_t* __restrict__ hist, int block, int n_blocks)
 {
-    __shared__ uint32_t h[SCCD_MAX_CELLS];
-    const GridParams g = *gp;
     for (int k = threadIdx.x; k < g.n_cells; k += blockDim.x) h[k] = 0;
     __syncthreads();
-    for (long long i = (long long)(blockIdx.x * blockDim.x + threadIdx.x) * stride; i < n;
-         i += (long long)gridDim.x * blockDim.x * stride) {
+    const long long n_s = ((long long)n + stride - 1) / stride;
+    const long long per = (n_s + n_blocks - 1) / n_blocks;
+    const long long s0 = (long long)block * per, s1 = s0 + per < n_s ? s0 + per : n_s;
+    for (long long sm = s0 + threadIdx.x; sm < s1; sm += blockDim.x) {
         int4 ids;
-        const CellSpan s = cell_span(g, src_box<SRC>(bs, (int)i, &ids));
+        const CellSpan s = cell_span(g, src_box<SRC>(bs, (int)(sm * stride), &ids));
         for (int ca = s.a0; ca <= s.a1; ca++)
             for (int cb = s.b0; cb <= s.b1; cb++) atomicAdd(&h[ca * g.Sb + cb], 1u);
     }
     __syncthreads();
     for (int k = threadIdx.x; k < g.n_cells; k += blockDim.x)
         if (h[k]) atomicAdd(&hist[k], h[k]);
+}
+template <int SRC>
+__global__ void cell_hist_k(BoxSrc bs, int n, const GridParams* __restrict__ gp, int stride, uint32_t* __restrict__ hist /*[n_cells]*/)
+{
+    __shared__ uint32_t h[SCCD_MAX_CELLS];
+    cell_hist_body<SRC>(h, bs, n, *gp, stride, hist, (int)blockIdx.x, (int)gridDim.x);
+}
+// both lists of a two-list build in one launch (the first blocks_a blocks: list A)
+template <int SRC_A, int SRC_B>
+__global__ void cell_hist2_k(BoxSrc a, int na, BoxSrc b, int nb, int blocks_a, const GridParams* __restrict__ gp, int stride,
+                             uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t h[SCCD_MAX_CELLS];
+    if ((int)blockIdx.x < blocks_a) cell_hist_body<SRC_A>(h, a, na, *gp, stride, hist, (int)blockIdx.x, blocks_a);
+    else cell_hist_body<SRC_B>(h, b, nb, *gp, stride, hist, (int)blockIdx.x - blocks_a, (int)gridDim.x - blocks_a);
 }
 
 // Count + fill in ONE pass for a cell window (multi-GPU): a block of 1024 threads adds up the
@@ -888,13 +909,13 @@ int launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st, do
 }
 void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a, int n_part_a, const GridStats* st_b,
                        const double* part_b, int n_part_b, int n_total, int axis, double cell_factor, int shrink,
-                       GridParams* g, uint32_t* cursors, bool reserve_tag)
+                       GridParams* g, uint32_t* cursors, bool reserve_tag, uint32_t* zero_hist)
 {
     // SCCD_MAX_CELLS_ENV: experiments with coarser grids (<= SCCD_MAX_CELLS)
     const char* mc = std::getenv("SCCD_MAX_CELLS");
     const int max_cells = mc ? std::max(1, std::min(SCCD_MAX_CELLS, std::atoi(mc))) : SCCD_DEFAULT_CELLS;
     hipLaunchKernelGGL(grid_setup_k, dim3(1), dim3(SCCD_STATS_BLOCKS), 0, c->stream, st_a, part_a, n_part_a, st_b, part_b, n_part_b,
-                       n_total, axis, cell_factor, shrink, g, cursors, max_cells, reserve_tag ? 1 : 0);
+                       n_total, axis, cell_factor, shrink, g, cursors, max_cells, reserve_tag ? 1 : 0, zero_hist);
     SCCD_HIP(hipGetLastError());
 }
 // the boxes of a list for the kernels above: the raw array, or (lazy lists) the recipe to compute them
@@ -903,17 +924,36 @@ static BoxSrc box_src(const sccd_boxes* b)
     return BoxSrc { b->raw.as<sccd_aabb>(), b->lazy_vb, b->lazy_elems, b->raw.as<sccd_aabb>() };
 }
 static int src_kind(const sccd_boxes* b) { return b->lazy ? (b->kind == BOX_EDGE ? 1 : 2) : 0; }
-void launch_cell_hist(sccd_ctx* c, const sccd_boxes* b, const GridParams* g, int stride, uint32_t* hist)
+static int hist_blocks_for(int n, int stride)
 {
-    const int n = b->n;
-    if (n == 0) return;
-    // few blocks: each flushes up to 1024 bins with global atomics
-    const dim3 grid((unsigned)std::min(grid_for((n + stride - 1) / stride), 64)), block(TPB);
-    const BoxSrc bs = box_src(b);
-    switch (src_kind(b)) {
-    case 0: hipLaunchKernelGGL(cell_hist_k<0>, grid, block, 0, c->stream, bs, n, g, stride, hist); break;
-    case 1: hipLaunchKernelGGL(cell_hist_k<1>, grid, block, 0, c->stream, bs, n, g, stride, hist); break;
-    default: hipLaunchKernelGGL(cell_hist_k<2>, grid, block, 0, c->stream, bs, n, g, stride, hist); break;
+    return n > 0 ? std::max(1, std::min(grid_for((n + stride - 1) / stride), 512)) : 0; // (64 KB of LDS each: two per CU)
+}
+// the sampled cell histogram of one list, or of both lists of a two-list build in one launch (B may be null)
+void launch_cell_hist(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B, const GridParams* g, int stride, uint32_t* hist)
+{
+    const int na = A->n, nb = B ? B->n : 0;
+    const int blocks_a = hist_blocks_for(na, stride), blocks_b = hist_blocks_for(nb, stride);
+    if (blocks_a + blocks_b == 0) return;
+    const BoxSrc a = box_src(A), b = B ? box_src(B) : box_src(A);
+    const dim3 block(TPB);
+    if (blocks_b == 0 || blocks_a == 0) {
+        const sccd_boxes* L = blocks_a ? A : B;
+        const BoxSrc bs = blocks_a ? a : b;
+        const dim3 grid((unsigned)(blocks_a + blocks_b));
+        switch (src_kind(L)) {
+        case 0: hipLaunchKernelGGL(cell_hist_k<0>, grid, block, 0, c->stream, bs, L->n, g, stride, hist); break;
+        case 1: hipLaunchKernelGGL(cell_hist_k<1>, grid, block, 0, c->stream, bs, L->n, g, stride, hist); break;
+        default: hipLaunchKernelGGL(cell_hist_k<2>, grid, block, 0, c->stream, bs, L->n, g, stride, hist); break;
+        }
+    } else {
+        auto go = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3((unsigned)(blocks_a + blocks_b)), block, 0, c->stream, a, na, b, nb, blocks_a, g, stride, hist);
+        };
+        // (list A of a two-list build is the vertices, always there; list B may be lazy faces or edges)
+        SCCD_REQUIRE(src_kind(A) == 0, "broad phase: a lazy list A");
+        if (src_kind(B) == 0) go(cell_hist2_k<0, 0>);
+        else if (src_kind(B) == 2) go(cell_hist2_k<0, 2>);
+        else go(cell_hist2_k<0, 1>);
     }
     SCCD_HIP(hipGetLastError());
 }

@@ -111,8 +111,8 @@ void launch_edge_face_boxes(sccd_ctx* c, const sccd_aabb* vb, const int2* E, int
 int launch_box_stats(sccd_ctx* c, const sccd_aabb* raw, int n, GridStats* st, double* part);
 void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a, int n_part_a, const GridStats* st_b,
                        const double* part_b, int n_part_b, int n_total, int axis, double cell_factor, int shrink,
-                       GridParams* g, uint32_t* cursors, bool reserve_tag = false);
-void launch_cell_hist(sccd_ctx* c, const sccd_boxes* b, const GridParams* g, int stride, uint32_t* hist);
+                       GridParams* g, uint32_t* cursors, bool reserve_tag = false, uint32_t* zero_hist = nullptr);
+void launch_cell_hist(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B /* or null */, const GridParams* g, int stride, uint32_t* hist);
 int launch_elem_stats(sccd_ctx* c, const sccd_boxes* b, int stride, GridStats* st, double* part);
 // a rank's window of cells, decided on the device (boxes.hip shard_window_k)
 struct ShardWindow {
