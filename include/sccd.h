@@ -109,7 +109,9 @@ int sccd_dev_copy(sccd_ctx* ctx, void* d_dst, const void* d_src, size_t bytes); 
 /* ------------------------------------------------------------------------------------------ */
 /* mesh  == the four DeviceMatrix objects of ccd() (src/scalable_ccd/cuda/ccd.cu:103-106)     */
 
-/* src_on_device: 0 = host pointers, 1 = device pointers (same column-major layout). */
+/* src_on_device: 0 = host pointers, 1 = device pointers (same column-major layout).
+   Vertex indices of E and F are validated on the device while the matrices are packed: an index outside [0, nV) makes the
+   call fail with SCCD_E_INVALID ("index out of range"; the reference asserts nothing and would fault). */
 int sccd_mesh_create(sccd_ctx* ctx, const double* V0, const double* V1, int nV, const int32_t* E,
                      int nE, const int32_t* F, int nF, int src_on_device, sccd_mesh** out);
 int sccd_mesh_update_vertices(sccd_mesh* mesh, const double* V0, const double* V1, int src_on_device);
@@ -193,7 +195,9 @@ typedef struct sccd_stats {
 } sccd_stats;
 
 /* ccd(V0,V1,E,F,min_distance,max_iterations,tolerance,allow_zero_toi,memory_limit_GB):
- * src/scalable_ccd/cuda/ccd.cuh:26-38 / ccd.cu:80-146.  Host matrices in, earliest TOI out. */
+ * src/scalable_ccd/cuda/ccd.cuh:26-38 / ccd.cu:80-146.  Host matrices in, earliest TOI out.
+ * (The matrices go into a mesh the context owns and refills call after call; an index out of range is reported when the
+ *  call ends -- the step has then run on indices clamped to 0, and its result is discarded.) */
 int sccd_ccd(sccd_ctx* ctx, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
              const int32_t* F, int nF, double min_distance, int max_iterations, double tolerance,
              int allow_zero_toi, int memory_limit_GB, double* toi);
