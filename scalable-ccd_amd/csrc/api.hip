@@ -731,8 +731,9 @@ static void list_count(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, i
 // `filled`: key / idx already hold the entries (the one-pass append of the sharded build).  Sorts the list's (key, box
 // index) pairs; the records follow once BOTH lists of a build are sorted (a row's first column is looked up among the
 // other list's keys).
+// d_n_real (speculative build): `total` is the padded number of pairs that is sorted, the real count sits in device memory
 static void list_sort(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, int cell_lo, int cell_hi, uint32_t total,
-                      int key_bits, SortedList* L, bool filled = false)
+                      int key_bits, SortedList* L, bool filled = false, const uint32_t* d_n_real = nullptr)
 {
     const int n = b->n;
     L->m = 0;
@@ -751,7 +752,7 @@ static void list_sort(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, in
         ProfScope ps(c, SCCD_PROF_SORT);
         c->sort_tmp_keys.ensure(sizeof(uint32_t) * (m + pad));
         c->sort_tmp_vals.ensure(sizeof(uint32_t) * (m + pad));
-        if (radix_sort_pairs_u32(c, L->key.as<uint32_t>(), L->idx.as<uint32_t>(), (int64_t)m, key_bits)) {
+        if (radix_sort_pairs_u32(c, L->key.as<uint32_t>(), L->idx.as<uint32_t>(), (int64_t)m, key_bits, d_n_real)) {
             // odd number of passes: the sorted pairs sit in the ping-pong buffers -- swap, no copy
             std::swap(L->key.p, c->sort_tmp_keys.p);
             std::swap(L->key.cap, c->sort_tmp_keys.cap);
@@ -762,14 +763,15 @@ static void list_sort(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, in
 }
 // the sorted records of the lists of a build whose (key, index) pairs are sorted, each list in its own arrays
 static void lists_records(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B, const GridParams* gp, SortedList* LA,
-                          SortedList* LB)
+                          SortedList* LB, const uint32_t* d_tot = nullptr, int expect_bits = 0)
 {
     ProfScope ps(c, SCCD_PROF_BOXES);
     if (!B) {
         launch_entry_records(c, A->raw.as<sccd_aabb>(), LA->key.as<uint32_t>(), LA->idx.as<uint32_t>(), LA->m, gp, 0, nullptr,
-                             0, false, false, LA);
+                             0, false, false, LA, d_tot, expect_bits);
         return;
     }
+    SCCD_REQUIRE(!d_tot, "broad phase: device-side counts serve the one-list and the merged two-list build");
     if (LA->m == 0 || LB->m == 0) return;
     launch_entry_records_two(c, A->raw.as<sccd_aabb>(), LA->key.as<uint32_t>(), LA->idx.as<uint32_t>(), LA->m,
                              B->raw.as<sccd_aabb>(), LB->key.as<uint32_t>(), LB->idx.as<uint32_t>(), LB->m, /*b_tagged=*/false, gp, LA, LB);
@@ -783,8 +785,10 @@ static void lists_records(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B,
 // the result is list A followed by list B.
 // list A keeps the merged key array (its first total_a entries); list B gets its keys back without the tag from the
 // gather.  Lists that were filled by the one-pass append only (entries already in key / idx).
+// d_tot (speculative build): total_a / total_b are BOUNDS -- their sum is sorted, padded behind the real pairs -- and the
+// real counts {A, B, A + B} sit in device memory
 static void lists_finish_merged(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B, const GridParams* gp, uint32_t total_a,
-                                uint32_t total_b, int key_bits, SortedList* LA, SortedList* LB)
+                                uint32_t total_b, int key_bits, SortedList* LA, SortedList* LB, const uint32_t* d_tot = nullptr)
 {
     const size_t ma = total_a, mb = total_b, m = ma + mb, pad = SCCD_LIST_PAD;
     SCCD_REQUIRE(m < (1u << 31), "broad phase: too many cell entries");
@@ -796,7 +800,7 @@ static void lists_finish_merged(sccd_ctx* c, const sccd_boxes* A, const sccd_box
         ProfScope ps(c, SCCD_PROF_SORT);
         c->sort_tmp_keys.ensure(sizeof(uint32_t) * (m + pad));
         c->sort_tmp_vals.ensure(sizeof(uint32_t) * (m + pad));
-        if (radix_sort_pairs_u32(c, LA->key.as<uint32_t>(), LA->idx.as<uint32_t>(), (int64_t)m, key_bits)) {
+        if (radix_sort_pairs_u32(c, LA->key.as<uint32_t>(), LA->idx.as<uint32_t>(), (int64_t)m, key_bits, d_tot ? d_tot + 2 : nullptr)) {
             std::swap(LA->key.p, c->sort_tmp_keys.p);
             std::swap(LA->key.cap, c->sort_tmp_keys.cap);
             std::swap(LA->idx.p, c->sort_tmp_vals.p);
@@ -810,7 +814,7 @@ static void lists_finish_merged(sccd_ctx* c, const sccd_boxes* A, const sccd_box
         const uint32_t* keys = LA->key.as<uint32_t>();
         const uint32_t* idx = LA->idx.as<uint32_t>();
         launch_entry_records_two(c, A->raw.as<sccd_aabb>(), keys, idx, (int)ma, B->raw.as<sccd_aabb>(), keys + ma, idx + ma, (int)mb,
-                                 /*b_tagged=*/true, gp, LA, LB);
+                                 /*b_tagged=*/true, gp, LA, LB, d_tot, key_bits);
     }
 }
 
@@ -826,6 +830,20 @@ static void materialise(sccd_ctx* c, const sccd_boxes* b)
     m->lazy = false;
 }
 
+// the grid parameters and, right behind them, the two list totals of a build: ONE copy brings both back (two copies in a row
+// cost a 12 us bubble between them)
+struct GridReadBack {
+    GridParams gp;
+    uint32_t total[2];
+    uint32_t place; // (device only: the shared placement cursor of a merged two-list fill)
+};
+static bool speculate_env()
+{
+    static const bool on = !(std::getenv("SCCD_SPECULATE") && std::atoi(std::getenv("SCCD_SPECULATE")) == 0);
+    return on;
+}
+static bool over_budget(uint32_t t, int n) { return (int64_t)t > std::max<int64_t>(3 * (int64_t)n, (int64_t)n + 4096); }
+
 static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes* B)
 {
     sccd_ctx* c = bp->ctx;
@@ -838,6 +856,7 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     bp->candidates = 0;
     bp->candidates_done = 0;
     bp->la.m = bp->lb.m = 0;
+    bp->speculative = false;
     bp->la.kind = A->kind;
     bp->lb.kind = B ? B->kind : BOX_UNKNOWN;
     bp->total_rows = 0;
@@ -848,11 +867,6 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     GridParams* gp = reinterpret_cast<GridParams*>(bp->grid.as<char>() + 512);
     // the two list totals sit right behind the grid parameters: ONE copy brings both back (two copies in a
     // row cost a 12 us bubble between them)
-    struct GridReadBack {
-        GridParams gp;
-        uint32_t total[2];
-        uint32_t place; // (device only: the shared placement cursor of a merged two-list fill)
-    };
     uint32_t* d_total = reinterpret_cast<uint32_t*>(bp->grid.as<char>() + 512 + offsetof(GridReadBack, total));
     static_assert(512 + sizeof(GridReadBack) <= 4096, "grid buffer layout");
     {
@@ -998,6 +1012,34 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                                                     bp->lb.key.as<uint32_t>(), bp->lb.idx.as<uint32_t>(), false, nullptr, win);
                     }
                 }
+                // THE SPECULATIVE BUILD (internal.hpp sccd_broad_phase::guess): the same lists were built before -- sort,
+                // records and (bp_detect_partial) the sweep are enqueued right away for that build's counts plus a margin;
+                // the kernels read the real counts on the device and the host checks them when the sweep's counters come back.
+                {
+                    const sccd_broad_phase::Guess& gs = bp->guess;
+                    const bool one_or_merged = !B || want_merged;
+                    if (speculate_env() && gs.valid && fill_round == 0 && shrink == 0 && one_or_merged && (device_window || (!windowed_build && c->shard_count == 1))
+                        && gs.n_a == A->n && gs.n_b == (B ? B->n : 0) && gs.axis == axis && gs.cell_factor == cf && c->max_overlap_cutoff == 0
+                        && c->sweep_algo != 1 && !(std::getenv("SCCD_SORT") && std::string(std::getenv("SCCD_SORT")) == "classic")) {
+                        const uint32_t ba = gs.total[0] + std::max<uint32_t>(4096u, gs.total[0] / 32u);
+                        const uint32_t bb = B ? gs.total[1] + std::max<uint32_t>(4096u, gs.total[1] / 32u) : 0u;
+                        if (gs.total[0] > 0 && (!B || gs.total[1] > 0) && (unsigned long long)ba + bb <= (want_merged ? 2 : 1) * cap) {
+                            bp->spec_bound[0] = ba;
+                            bp->spec_bound[1] = bb;
+                            bp->spec_sorted = ba + bb;
+                            bp->spec_cap = (uint32_t)cap;
+                            bp->spec_window = device_window;
+                            if (want_merged) {
+                                lists_finish_merged(c, A, B, gp, ba, bb, gs.key_bits, &bp->la, &bp->lb, d_total);
+                            } else {
+                                list_sort(c, A, gp, bp->cell_lo, bp->cell_hi, ba, gs.key_bits, &bp->la, true, d_total);
+                                lists_records(c, A, nullptr, gp, &bp->la, &bp->lb, d_total, gs.key_bits);
+                            }
+                            bp->speculative = true;
+                            break;
+                        }
+                    }
+                }
                 {
                     ProfScope ps(c, SCCD_PROF_SORT);
                     read_totals(total, hgp);
@@ -1014,6 +1056,7 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                 if (!windowed_build && can_shrink) break; // over the replication budget: the grid gets coarser below
                 cap = need + 1024; // estimate too low (the sample missed a crowded cell): once more, with room
             }
+            if (bp->speculative) break; // (everything is enqueued; bp_detect_partial checks the guess)
             if (device_window_redo) { // the same grid again (shrink stays 0), the slow way: histogram on the host, then as before
                 device_window_redo = false;
                 materialise(c, A); // (the slow way reads whole lists)
@@ -1024,8 +1067,19 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                 continue;
             }
             if (!windowed_build && can_shrink) {
-                auto over = [&](uint32_t t, int n) { return (int64_t)t > std::max<int64_t>(3 * (int64_t)n, (int64_t)n + 4096); };
-                if (over(total[0], A->n) || (B && over(total[1], B->n))) continue;
+                if (over_budget(total[0], A->n) || (B && over_budget(total[1], B->n))) continue;
+            }
+            if (shrink == 0 && (!windowed_build || device_window)) { // what the next build of these lists may expect
+                bp->guess.valid = true;
+                bp->guess.n_a = A->n;
+                bp->guess.n_b = B ? B->n : 0;
+                bp->guess.axis = axis;
+                bp->guess.cell_factor = cf;
+                bp->guess.key_bits = hgp.key_bits;
+                bp->guess.total[0] = total[0];
+                bp->guess.total[1] = B ? total[1] : 0;
+            } else {
+                bp->guess.valid = false;
             }
             if (want_merged) {
                 // (a side without entries in this rank's cells: no pair can come of it -- sort_and_sweep.cpp:221-223)
@@ -1153,19 +1207,62 @@ static void bp_detect_partial(sccd_broad_phase* bp, int phase = 0)
         SCCD_HIP(hipMemsetAsync(d_cnt, 0, sizeof(SweepCounters), c->stream)); // pairs and candidate tests of THIS attempt
         {
             ProfScope ps(c, SCCD_PROF_SWEEP);
+            // (a speculative build: the lists' sizes are bounds, the kernels take the real counts from device memory)
+            const uint32_t* const d_tot = bp->speculative
+                ? reinterpret_cast<const uint32_t*>(bp->grid.as<char>() + 512 + offsetof(GridReadBack, total)) : nullptr;
             if (!B) {
-                launch_sweep(c, A, A, gp, a_lo, a_hi, EMIT_ONE_LIST, bp->overlaps.as<int2>(), bp->capacity, d_cnt);
+                launch_sweep(c, A, A, gp, a_lo, a_hi, EMIT_ONE_LIST, bp->overlaps.as<int2>(), bp->capacity, d_cnt, d_tot, d_tot, bp->guess.key_bits);
             } else {
-                launch_sweep_two(c, A, B, gp, a_lo, a_hi, b_lo, b_hi, bp->overlaps.as<int2>(), bp->capacity, d_cnt);
+                launch_sweep_two(c, A, B, gp, a_lo, a_hi, b_lo, b_hi, bp->overlaps.as<int2>(), bp->capacity, d_cnt, d_tot, bp->guess.key_bits);
             }
         }
         if (phase == 1) return;
     launched:
         SweepCounters h;
+        GridReadBack built; // (speculative build: the grid and the entry counts it really had)
+        ShardWindow hwin {}; // (... of a rank of a multi-GPU job: the cell window it was dealt on the device)
         {
             ReadBack rb(c);
             rb.add(&h, d_cnt, sizeof h);
+            if (bp->speculative) rb.add(&built, bp->grid.as<char>() + 512, sizeof built);
+            if (bp->speculative && bp->spec_window) rb.add(&hwin, bp->grid.as<char>() + 1024, sizeof hwin);
             rb.sync();
+        }
+        if (bp->speculative) {
+            // did the guess hold?  Everything the slow build would have looked at between the fill and the sort:
+            const sccd_broad_phase::Guess& gs = bp->guess;
+            const bool two = bp->B != nullptr;
+            const uint32_t ta = built.total[0], tb = two ? built.total[1] : 0u;
+            const bool ok = built.gp.key_bits == gs.key_bits                                   // the sort ran the right passes
+                && ta > 0 && (!two || tb > 0)                                                  // (an empty side ends the build early)
+                && ta <= bp->spec_bound[0] && tb <= bp->spec_bound[1]                          // records and sweep saw every entry
+                && (unsigned long long)ta + tb <= bp->spec_sorted                              // ... and so did the sort
+                && std::max(ta, tb) <= bp->spec_cap                                            // the fill dropped nothing
+                && (bp->spec_window                                                            // no coarser grid was due
+                        ? !(hwin.total_est > (unsigned long long)std::max<int64_t>(3 * (int64_t)(bp->A->n + (two ? bp->B->n : 0)),
+                                                                                   (int64_t)(bp->A->n + (two ? bp->B->n : 0)) + 4096))
+                            && hwin.n_cells >= 4 * c->shard_count                               // ... nor a split by rows
+                        : !over_budget(ta, bp->A->n) && !(two && over_budget(tb, bp->B->n)));
+            if (!ok) {
+                // build again, the slow way (the guess is gone: bp_build waits for the counts), and sweep that
+                bp->guess.valid = false;
+                const int64_t done = bp->candidates_done;
+                bp_build(bp, bp->A, bp->B);
+                bp->candidates_done = done;
+                bp_detect_partial(bp, 0);
+                return;
+            }
+            bp->speculative = false;
+            if (bp->spec_window) {
+                bp->cell_lo = hwin.cell_lo;
+                bp->cell_hi = hwin.cell_hi;
+            }
+            bp->la.m = (int)ta;
+            bp->lb.m = (int)tb;
+            bp->total_rows = (int64_t)ta + tb;
+            chunk_hi = bp->total_rows; // (a speculative build is swept in one chunk: bp_build)
+            bp->guess.total[0] = ta;   // (the next build's guess follows the scene)
+            bp->guess.total[1] = tb;
         }
         {
             unsigned long long cs = 0;

@@ -787,16 +787,38 @@ __device__ __forceinline__ void entry_record_body(const RecordArgs& a, const Gri
     recs[(size_t)REC_AUX * pstride + e] = make_uint4(k_e, kmax, lowcell, start);
 }
 template <int MODE>
-__global__ __launch_bounds__(ER_THREADS) void entry_record_k(RecordArgs a, const GridParams* __restrict__ gp)
+__global__ __launch_bounds__(ER_THREADS) void entry_record_k(RecordArgs a, const GridParams* __restrict__ gp, const uint32_t* __restrict__ d_tot,
+                                                             int expect_bits)
 {
+    // d_tot (may be null): the list's entry count in DEVICE memory -- a build whose records are made before the host knows
+    // the count (api.hip: the speculative build) launches for the count it expects; the real one is taken from here
     __shared__ unsigned s_win[2];
+    if (d_tot) { // (a count beyond the bound the launch was sized for is a failed guess: nothing is done here, the host finds out)
+        // (so is another key width than the sort was run for: the pairs are not in order then)
+        if (d_tot[0] > (uint32_t)a.m || gp->key_bits != expect_bits) return;
+        a.m = (int)d_tot[0];
+    }
+    if ((long long)blockIdx.x * ER_THREADS >= a.m) return;
     entry_record_body<MODE>(a, gp, s_win, (int)blockIdx.x);
 }
 // both lists of a two-list build in ONE launch (the first blocks_a blocks: list A's rows; two launches in a row sat on the
 // critical path of every vertex-face pass)
-__global__ __launch_bounds__(ER_THREADS) void entry_record2_k(RecordArgs a, RecordArgs b, int blocks_a, const GridParams* __restrict__ gp)
+__global__ __launch_bounds__(ER_THREADS) void entry_record2_k(RecordArgs a, RecordArgs b, int blocks_a, const GridParams* __restrict__ gp,
+                                                              const uint32_t* __restrict__ d_tot, int expect_bits)
 {
     __shared__ unsigned s_win[2];
+    if (d_tot) { // device-side counts (entry_record_k): ONE merged, sorted array -- list A's pairs, then list B's
+        if (d_tot[0] > (uint32_t)a.m || d_tot[1] > (uint32_t)b.m || gp->key_bits != expect_bits) return; // (a failed guess: entry_record_k)
+        const int ma = (int)d_tot[0], mb = (int)d_tot[1];
+        a.m = b.n_other = ma;
+        b.m = a.n_other = mb;
+        b.key = a.key + ma;
+        b.idx = a.idx + ma;
+        a.other = b.key;
+        b.other = a.key;
+        blocks_a = (ma + ER_THREADS - 1) / ER_THREADS;
+        if ((int)blockIdx.x >= blocks_a + (mb + ER_THREADS - 1) / ER_THREADS) return;
+    }
     if ((int)blockIdx.x < blocks_a) entry_record_body<1>(a, gp, s_win, (int)blockIdx.x);
     else entry_record_body<2>(b, gp, s_win, (int)blockIdx.x - blocks_a);
 }
@@ -1038,26 +1060,29 @@ static RecordArgs record_args(const sccd_aabb* raw, const uint32_t* key, const u
 }
 void launch_entry_records(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,
                           const GridParams* g, int mode, const uint32_t* other, int n_other, bool own_tagged,
-                          bool other_tagged, SortedList* out)
+                          bool other_tagged, SortedList* out, const uint32_t* d_tot, int expect_bits)
 {
+    // (d_tot != null: m is the bound the launch is sized for, the real count is read on the device)
     if (m == 0) return;
+    SCCD_REQUIRE(!(d_tot && mode != 0), "broad phase: device-side counts serve the one-list and the merged two-list records");
     const RecordArgs a = record_args(raw, key, idx, m, other, n_other, own_tagged, other_tagged, out);
     const dim3 grid((unsigned)((m + ER_THREADS - 1) / ER_THREADS)), block(ER_THREADS);
-    if (mode == 0) hipLaunchKernelGGL(entry_record_k<0>, grid, block, 0, c->stream, a, g);
-    else if (mode == 1) hipLaunchKernelGGL(entry_record_k<1>, grid, block, 0, c->stream, a, g);
-    else hipLaunchKernelGGL(entry_record_k<2>, grid, block, 0, c->stream, a, g);
+    if (mode == 0) hipLaunchKernelGGL(entry_record_k<0>, grid, block, 0, c->stream, a, g, d_tot, expect_bits);
+    else if (mode == 1) hipLaunchKernelGGL(entry_record_k<1>, grid, block, 0, c->stream, a, g, d_tot, expect_bits);
+    else hipLaunchKernelGGL(entry_record_k<2>, grid, block, 0, c->stream, a, g, d_tot, expect_bits);
     SCCD_HIP(hipGetLastError());
 }
 // the records of both lists of a two-list build in one launch (list A's rows look their first column up among keys_b, ...)
 void launch_entry_records_two(sccd_ctx* c, const sccd_aabb* raw_a, const uint32_t* key_a, const uint32_t* idx_a, int ma,
                               const sccd_aabb* raw_b, const uint32_t* key_b, const uint32_t* idx_b, int mb, bool b_tagged,
-                              const GridParams* g, SortedList* out_a, SortedList* out_b)
+                              const GridParams* g, SortedList* out_a, SortedList* out_b, const uint32_t* d_tot, int expect_bits)
 {
     if (ma == 0 || mb == 0) return;
     const RecordArgs a = record_args(raw_a, key_a, idx_a, ma, key_b, mb, false, b_tagged, out_a);
     const RecordArgs b = record_args(raw_b, key_b, idx_b, mb, key_a, ma, b_tagged, false, out_b);
     const int blocks_a = (ma + ER_THREADS - 1) / ER_THREADS, blocks_b = (mb + ER_THREADS - 1) / ER_THREADS;
-    hipLaunchKernelGGL(entry_record2_k, dim3((unsigned)(blocks_a + blocks_b)), dim3(ER_THREADS), 0, c->stream, a, b, blocks_a, g);
+    // (device-side counts: one block more than the bounds need -- the split between the lists moves with the real counts)
+    hipLaunchKernelGGL(entry_record2_k, dim3((unsigned)(blocks_a + blocks_b + (d_tot ? 1 : 0))), dim3(ER_THREADS), 0, c->stream, a, b, blocks_a, g, d_tot, expect_bits);
     SCCD_HIP(hipGetLastError());
 }
 

@@ -88,6 +88,20 @@ struct sccd_broad_phase {
     int64_t candidates_done = 0; // ... of the chunks before the current one
     int cell_lo = 0, cell_hi = 1 << 30; // this rank's window of cells (multi-GPU shard)
     bool row_shard = false;             // too few cells to shard by: split the rows instead
+    // The SPECULATIVE build (api.hip bp_build): sort, records and sweep are enqueued right behind the fill, for the entry
+    // counts and the key width of the previous build of the same lists plus a margin; the kernels take the real counts from
+    // device memory; the host looks at them when the sweep's counters come back and builds again, the slow way, if the guess
+    // did not hold.  (Round 2 waited for the counts between the fill and the sort: 25-30 us of every build chain.)
+    struct Guess {
+        bool valid = false;
+        int n_a = 0, n_b = 0, axis = 0, key_bits = 0;
+        double cell_factor = 0;
+        uint32_t total[2] = { 0, 0 };
+    } guess;
+    bool speculative = false;              // la.m / lb.m are BOUNDS until bp_detect_partial has checked the guess
+    bool spec_window = false;              // ... of a rank's cell window, dealt out on the device
+    uint32_t spec_bound[2] = { 0, 0 };     // what the records were sized for
+    uint32_t spec_sorted = 0, spec_cap = 0; // pairs sorted (padded); room of the entry buffers per list
 };
 
 // ------------------------------------------------------------------------------------------
@@ -140,11 +154,11 @@ void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams
 // both lists of a two-list build in one launch (b_tagged: list B's keys carry the list tag of a merged sort)
 void launch_entry_records_two(sccd_ctx* c, const sccd_aabb* raw_a, const uint32_t* key_a, const uint32_t* idx_a, int ma,
                               const sccd_aabb* raw_b, const uint32_t* key_b, const uint32_t* idx_b, int mb, bool b_tagged,
-                              const GridParams* g, SortedList* out_a, SortedList* out_b);
+                              const GridParams* g, SortedList* out_a, SortedList* out_b, const uint32_t* d_tot = nullptr, int expect_bits = 0);
 // own_tagged / other_tagged: this list's / the column list's keys carry the list tag of a merged sort
 void launch_entry_records(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,
                           const GridParams* g, int mode, const uint32_t* other, int n_other, bool own_tagged,
-                          bool other_tagged, SortedList* out);
+                          bool other_tagged, SortedList* out, const uint32_t* d_tot = nullptr, int expect_bits = 0);
 
 // scan.hip
 void exclusive_scan_u32(sccd_ctx* c, const uint32_t* in, uint32_t* out, int n, uint32_t* d_total);
@@ -152,7 +166,8 @@ void exclusive_scan_u32(sccd_ctx* c, const uint32_t* in, uint32_t* out, int n, u
 int pick_sort_axis(sccd_ctx* c, const sccd_aabb* raw, int n, const sccd_aabb* raw_b = nullptr, int n_b = 0);
 
 // sort.hip: in-place LSD radix sort of (key, value) pairs by key, ascending, stable
-bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n, int key_bits = 32);
+// d_n_real (device, may be null): only the first *d_n_real of the n pairs are there, the rest sort as key 0xFFFFFFFF (behind them)
+bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n, int key_bits = 32, const uint32_t* d_n_real = nullptr);
 
 // sweep.hip
 enum SweepEmit { EMIT_ONE_LIST = 0, EMIT_ROWS_A = 1, EMIT_ROWS_B = 2 };
@@ -168,10 +183,11 @@ struct SweepCounters { // lives in device memory (ctx->scalars)
 static_assert(sizeof(SweepCounters) == 512, "SweepCounters: keep the size a multiple of 256 bytes");
 // rows [row_begin, row_end) of `rows` against the columns of `cols` (rows == cols: one list)
 void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, const GridParams* gp, int row_begin,
-                  int row_end, int emit, int2* out, int64_t capacity, SweepCounters* d_cnt);
+                  int row_end, int emit, int2* out, int64_t capacity, SweepCounters* d_cnt, const uint32_t* d_m_rows = nullptr,
+                  const uint32_t* d_m_cols = nullptr, int expect_bits = 0); // (device-side entry counts and the key width they were sorted by: sweep_band_k)
 // both classes of a two-list sweep: rows [a_begin, a_end) of A against B and rows [b_begin, b_end) of B against A
 void launch_sweep_two(sccd_ctx* c, const SortedList* A, const SortedList* B, const GridParams* gp, int a_begin, int a_end,
-                      int b_begin, int b_end, int2* out, int64_t capacity, SweepCounters* d_cnt);
+                      int b_begin, int b_end, int2* out, int64_t capacity, SweepCounters* d_cnt, const uint32_t* d_tot = nullptr, int expect_bits = 0);
 
 // narrow.hip
 struct NarrowParams {

@@ -137,9 +137,14 @@ __device__ __forceinline__ void hist_add(uint32_t (*h)[256], uint32_t k, bool va
     }
 }
 
+// d_n_real (may be null): the first *d_n_real of the n keys are there; the rest count as 0xFFFFFFFF -- a build that is sorted
+// before the host knows its entry count sorts a padded number of keys (api.hip: the speculative build), and the padding must
+// end up behind the keys, whatever the buffers hold there.
 __global__ __launch_bounds__(HS_THREADS) void os_hist_k(const uint32_t* __restrict__ keys, long long n, uint32_t* __restrict__ partial,
-                                                        uint4* __restrict__ zero, long long zero_n, int passes)
+                                                        uint4* __restrict__ zero, long long zero_n, int passes,
+                                                        const uint32_t* __restrict__ d_n_real)
 {
+    const long long n_real = d_n_real ? min((long long)*d_n_real, n) : n;
     // every word the passes poll (tickets + look-back status) is zeroed here, not by memsets
     for (long long i = (long long)blockIdx.x * HS_THREADS + threadIdx.x; i < zero_n; i += (long long)gridDim.x * HS_THREADS)
         zero[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -161,14 +166,15 @@ __global__ __launch_bounds__(HS_THREADS) void os_hist_k(const uint32_t* __restri
             cnt4[r] = 0;
             k4[r] = make_uint4(0u, 0u, 0u, 0u);
             if (q < quads) {
-                if (i + 3 < n) {
+                if (i + 3 < n_real) {
                     k4[r] = *reinterpret_cast<const uint4*>(keys + i);
                     cnt4[r] = 4;
-                } else {
-                    k4[r].x = keys[i];
-                    cnt4[r] = 1;
-                    if (i + 1 < n) { k4[r].y = keys[i + 1]; cnt4[r] = 2; }
-                    if (i + 2 < n) { k4[r].z = keys[i + 2]; cnt4[r] = 3; }
+                } else { // the end of the keys, or of the padded run behind them
+                    k4[r] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                    if (i < n_real) k4[r].x = keys[i];
+                    if (i + 1 < n_real) k4[r].y = keys[i + 1];
+                    if (i + 2 < n_real) k4[r].z = keys[i + 2];
+                    cnt4[r] = (int)min(4ll, n - i);
                 }
             }
         }
@@ -244,8 +250,10 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restri
                                                         uint32_t* __restrict__ keys_out,
                                                         uint32_t* __restrict__ vals_out, long long n, int shift,
                                                         int num_tiles, const uint32_t* __restrict__ bases,
-                                                        uint32_t* status, uint32_t* ticket, int dbg)
+                                                        uint32_t* status, uint32_t* ticket, int dbg,
+                                                        const uint32_t* __restrict__ d_n_real /* os_hist_k; first pass only */)
 {
+    const long long n_load = d_n_real ? min((long long)*d_n_real, n) : n; // keys beyond it are loaded as 0xFFFFFFFF
     __shared__ uint32_t wtot[RS_WAVES][256]; // per-wave digit totals -> offset of the wave inside the digit's run
     __shared__ uint32_t wrun[RS_WAVES][256]; // running per-wave counters of the ranking
     __shared__ uint32_t dig_excl[256];       // exclusive offset of the digit inside the tile
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restri
     __syncthreads();
     uint32_t t0 = s_tk[0];
     TileRegs pre;
-    if ((int)t0 < num_tiles) tile_load(pre, keys_in, vals_in, (long long)t0 * RS_TILE + (long long)w * RS_WAVE_SPAN, lane, n);
+    if ((int)t0 < num_tiles) tile_load(pre, keys_in, vals_in, (long long)t0 * RS_TILE + (long long)w * RS_WAVE_SPAN, lane, n_load);
 
     while ((int)t0 < num_tiles) {
         const uint32_t tile = t0;
@@ -338,7 +346,7 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restri
         __syncthreads(); // dig_gbase scratch consumed before it is overwritten below
         // the next tile's loads (consumed at the top of the next round)
         const uint32_t t1 = s_tk[1];
-        if ((int)t1 < num_tiles) tile_load(pre, keys_in, vals_in, (long long)t1 * RS_TILE + (long long)w * RS_WAVE_SPAN, lane, n);
+        if ((int)t1 < num_tiles) tile_load(pre, keys_in, vals_in, (long long)t1 * RS_TILE + (long long)w * RS_WAVE_SPAN, lane, n_load);
         // 3. decoupled look-back, thread d = digit d, eight predecessor tiles probed per round
         {
             const int d = threadIdx.x;
@@ -458,7 +466,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_k(const uint32_t* __res
 
 // Sorts by the low `key_bits` bits (a multiple of 8).  Returns true when the result ended in the
 // context's ping-pong buffers (odd number of passes) instead of (keys, vals).
-bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n, int key_bits)
+bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n, int key_bits, const uint32_t* d_n_real)
 {
     if (n <= 1) return false;
     const int passes = std::max(1, std::min(4, (key_bits + 7) / 8));
@@ -474,6 +482,7 @@ bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
         const char* e = std::getenv("SCCD_SORT");
         return e && std::strcmp(e, "classic") == 0;
     }();
+    SCCD_REQUIRE(!(classic && d_n_real), "radix sort: the classic sort takes an exact count");
     if (classic) {
         c->sort_hist.ensure(sizeof(uint32_t) * 256 * (size_t)num_tiles);
         uint32_t* counts = c->sort_hist.as<uint32_t>();
@@ -508,13 +517,13 @@ bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
     uint32_t* status = reinterpret_cast<uint32_t*>(base + off_status);
     // every polled word (tickets and status, contiguous) is zeroed by os_hist_k before the passes
     hipLaunchKernelGGL(os_hist_k, dim3(hist_blocks), dim3(HS_THREADS), 0, c->stream, k_in, (long long)n, partial,
-                       reinterpret_cast<uint4*>(base), (long long)((512 + status_bytes) / 16), passes);
+                       reinterpret_cast<uint4*>(base), (long long)((512 + status_bytes) / 16), passes, d_n_real);
     hipLaunchKernelGGL(os_bases_k, dim3(4), dim3(1024), 0, c->stream, partial, hist_blocks, bases);
     for (int pass = 0; pass < passes; pass++) {
         static const int pass_blocks = std::getenv("SCCD_SORT_BLOCKS") ? std::atoi(std::getenv("SCCD_SORT_BLOCKS")) : 3;
         hipLaunchKernelGGL(os_pass_k, dim3(std::min(num_tiles, c->num_cus * pass_blocks)), dim3(RS_THREADS), 0, c->stream, k_in,
                            v_in, k_out, v_out, (long long)n, 8 * pass, num_tiles, bases + 256 * pass,
-                           status + (size_t)pass * num_tiles * 256, tickets + pass * 32, dbg);
+                           status + (size_t)pass * num_tiles * 256, tickets + pass * 32, dbg, pass == 0 ? d_n_real : nullptr);
         std::swap(k_in, k_out);
         std::swap(v_in, v_out);
     }

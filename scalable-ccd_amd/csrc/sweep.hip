@@ -628,10 +628,19 @@ template <bool ONE, int KIND>
 __global__ __launch_bounds__(SW_THREADS, 2) void sweep_band_k(SweepRecs R, int row_begin, int row_end, SweepRecs C, int n_cols,
                                                               const GridParams* __restrict__ gp, int emit, int chunk,
                                                               int2* __restrict__ out, long long capacity,
-                                                              SweepCounters* __restrict__ cnt, int diag)
+                                                              SweepCounters* __restrict__ cnt, int diag,
+                                                              const uint32_t* __restrict__ d_m_rows, const uint32_t* __restrict__ d_m_cols,
+                                                              int expect_bits)
 {
+    // d_m_rows / d_m_cols (may be null): the lists' entry counts in DEVICE memory -- a sweep enqueued before the host knows
+    // them (api.hip: the speculative build) is launched for the counts it expects and takes the real ones from here
     __shared__ SweepLds lds_s[SW_WAVES];
     __shared__ unsigned long long blk_scratch[3 * SW_WAVES];
+    // (a count beyond what the record arrays were sized for is a failed guess: nothing is swept, the host finds out)
+    // (so is another key width than the lists were sorted by: their records were never made)
+    if ((d_m_rows && *d_m_rows > (uint32_t)row_end) || (d_m_cols && *d_m_cols > (uint32_t)n_cols) || (d_m_rows && gp->key_bits != expect_bits)) return;
+    if (d_m_rows) row_end = min(row_end, (int)*d_m_rows);
+    if (d_m_cols) n_cols = (int)*d_m_cols;
     sweep_band_body<ONE, KIND>(lds_s, blk_scratch, R, row_begin, row_end, C, n_cols, gp, emit, chunk, out, capacity, cnt, diag,
                                blockIdx.x, gridDim.x);
 }
@@ -644,10 +653,18 @@ template <int KIND_A, int KIND_B>
 __global__ __launch_bounds__(SW_THREADS, 2) void sweep_band2_k(SweepRecs A, int a_begin, int a_end, int n_a, SweepRecs B, int b_begin,
                                                                int b_end, int n_b, const GridParams* __restrict__ gp, int chunk_a,
                                                                int chunk_b, int2* __restrict__ out, long long capacity,
-                                                               SweepCounters* __restrict__ cnt, int diag)
+                                                               SweepCounters* __restrict__ cnt, int diag,
+                                                               const uint32_t* __restrict__ d_tot /* [A, B] or null: sweep_band_k */, int expect_bits)
 {
     __shared__ SweepLds lds_s[SW_WAVES];
     __shared__ unsigned long long blk_scratch[3 * SW_WAVES];
+    if (d_tot) {
+        if (d_tot[0] > (uint32_t)n_a || d_tot[1] > (uint32_t)n_b || gp->key_bits != expect_bits) return; // (a failed guess: sweep_band_k)
+        n_a = (int)d_tot[0];
+        n_b = (int)d_tot[1];
+        a_end = min(a_end, n_a);
+        b_end = min(b_end, n_b);
+    }
     sweep_band_body<false, KIND_A>(lds_s, blk_scratch, A, a_begin, a_end, B, n_b, gp, EMIT_ROWS_A, chunk_a, out, capacity, cnt, diag,
                                    blockIdx.x, gridDim.x);
     __syncthreads(); // (the scratch words of the class's last flush)
@@ -697,9 +714,11 @@ __global__ void sweep_sap_k(SweepRecs R, int row_begin, int row_end, SweepRecs C
 } // namespace
 
 void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, const GridParams* gp, int row_begin,
-                  int row_end, int emit, int2* out, int64_t capacity, SweepCounters* d_cnt)
+                  int row_end, int emit, int2* out, int64_t capacity, SweepCounters* d_cnt, const uint32_t* d_m_rows,
+                  const uint32_t* d_m_cols, int expect_bits)
 {
     if (row_end <= row_begin || cols->m == 0) return;
+    SCCD_REQUIRE(!(d_m_rows && c->sweep_algo == 1), "sweep: the plain sweep takes exact counts");
     const bool one = rows == cols;
     const SweepRecs R = sweep_recs(rows), C = sweep_recs(cols);
     if (c->sweep_algo == 1) {
@@ -731,7 +750,7 @@ void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, c
         auto go = [&](auto kernel) {
             static const int diag = std::getenv("SCCD_SWEEP_DIAG") ? std::atoi(std::getenv("SCCD_SWEEP_DIAG")) : 0;
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(SW_THREADS), 0, c->stream, R, row_begin, row_end, C, cols->m, gp, emit,
-                               chunk, out, (long long)capacity, d_cnt, diag);
+                               chunk, out, (long long)capacity, d_cnt, diag, d_m_rows, d_m_cols, expect_bits);
         };
         if (kind == 1) go(sweep_band_k<true, 1>);
         else if (kind == 2) go(sweep_band_k<false, 2>);
@@ -744,13 +763,13 @@ void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, c
 
 // Both classes of a two-list sweep (rows A x columns B, rows B x columns A) in one launch.
 void launch_sweep_two(sccd_ctx* c, const SortedList* A, const SortedList* B, const GridParams* gp, int a_begin, int a_end,
-                      int b_begin, int b_end, int2* out, int64_t capacity, SweepCounters* d_cnt)
+                      int b_begin, int b_end, int2* out, int64_t capacity, SweepCounters* d_cnt, const uint32_t* d_tot, int expect_bits)
 {
     const int tiles_a = std::max(0, (a_end - a_begin + 63) / 64), tiles_b = std::max(0, (b_end - b_begin + 63) / 64);
     static const bool fuse_env = !(std::getenv("SCCD_SWEEP_FUSE") && std::atoi(std::getenv("SCCD_SWEEP_FUSE")) == 0);
     if (c->sweep_algo == 1 || !fuse_env || tiles_a == 0 || tiles_b == 0 || A->m == 0 || B->m == 0) {
-        launch_sweep(c, A, B, gp, a_begin, a_end, EMIT_ROWS_A, out, capacity, d_cnt);
-        launch_sweep(c, B, A, gp, b_begin, b_end, EMIT_ROWS_B, out, capacity, d_cnt);
+        launch_sweep(c, A, B, gp, a_begin, a_end, EMIT_ROWS_A, out, capacity, d_cnt, d_tot, d_tot ? d_tot + 1 : nullptr, expect_bits);
+        launch_sweep(c, B, A, gp, b_begin, b_end, EMIT_ROWS_B, out, capacity, d_cnt, d_tot ? d_tot + 1 : nullptr, d_tot, expect_bits);
         return;
     }
     static const int per_cu_env = std::getenv("SCCD_SWEEP_BLOCKS") ? std::atoi(std::getenv("SCCD_SWEEP_BLOCKS")) : 2;
@@ -764,7 +783,7 @@ void launch_sweep_two(sccd_ctx* c, const SortedList* A, const SortedList* B, con
     const SweepRecs RA = sweep_recs(A), RB = sweep_recs(B);
     auto go = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(SW_THREADS), 0, c->stream, RA, a_begin, a_end, A->m, RB, b_begin, b_end, B->m, gp,
-                           1, 1, out, (long long)capacity, d_cnt, diag);
+                           1, 1, out, (long long)capacity, d_cnt, diag, d_tot, expect_bits);
     };
     if (vf) go(sweep_band2_k<2, 3>);
     else go(sweep_band2_k<0, 0>);

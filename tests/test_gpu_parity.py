@@ -318,6 +318,40 @@ def test_cpu_entry_point_sort_and_sweep(sccd, ctx, orc, axis):
     assert np.array_equal(_sorted(got), want) and got_axis == want_axis
 
 
+@pytest.mark.parametrize("two_lists", [False, True])
+def test_speculative_builds_follow_the_scene_and_survive_a_wrong_guess(sccd, ctx, orc, two_lists):
+    """The second build of the same number of boxes on a BroadPhase is enqueued on the FIRST build's entry counts (sort, records
+    and sweep right behind the fill, real counts read on the device: csrc/api.hip bp_build).  Boxes that barely change keep the
+    guess; boxes that grow past its margin, or change the grid's key width, must fall back to the exact build -- the pair set
+    is the oracle's every time."""
+    n = 30_000
+    bp = sccd.BroadPhase(ctx)
+
+    def scene(seed, ext, jitter=0.0):
+        a = scenes.random_boxes(n, seed=seed, max_extent=ext)
+        if jitter:
+            rng = np.random.default_rng(seed + 1)
+            d = rng.uniform(-jitter, jitter, (n, 3))
+            a["min"] += d
+            a["max"] += d
+        if not two_lists:
+            return a, None
+        b = scenes.random_boxes(n // 2, seed=seed + 100, max_extent=ext)
+        return a, b
+
+    steps = [(5, 0.02, 0.0), (5, 0.02, 1e-4), (5, 0.02, 2e-4),  # the guess holds (a moving scene)
+             (5, 0.05, 0.0),                                     # many more entries: past the margin
+             (6, 0.004, 0.0), (6, 0.004, 1e-5),                  # far fewer, another grid
+             (5, 0.02, 0.0)]
+    for seed, ext, jitter in steps:
+        a, b = scene(seed, ext, jitter)
+        bp.build(sccd.DeviceAABBs(a, ctx), sccd.DeviceAABBs(b, ctx) if b is not None else None)
+        got = _sorted(bp.detect_overlaps())
+        want = orc.sort_and_sweep(a, b)[0] if b is not None else orc.sort_and_sweep(a)[0]
+        assert np.array_equal(got, want), (seed, ext, jitter, len(got), len(want))
+        assert bp.is_complete()
+
+
 def test_random_100k_matches_golden_hash(sccd, ctx):
     G = json.load(open(GOLDEN))["random_100k"]
     b = scenes.random_boxes(100_000, seed=42, max_extent=0.027)
@@ -954,6 +988,34 @@ def test_full_size_sharded_passes_reduce_to_the_same_toi(sccd, ctx, cloth1m):
         ctx.set_option(sccd.OPT_SHARD_RANK, 0)
     assert n_pairs == G["n_vf"] + G["n_ee"]
     assert toi == float.fromhex(G["toi_strict"])
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_repeated_steps_on_one_mesh_build_speculatively_and_agree(sccd, ctx, orc, world):
+    """A simulation calls ccd() step after step on one mesh: from the second step on the broad phase is enqueued on the previous
+    step's entry counts (csrc/api.hip bp_build, the speculative build) -- also a rank's cell window of a multi-GPU job.  Moving
+    the vertices a little keeps the guess, moving them a lot breaks it; every step's TOI and pair count are the oracle's."""
+    V0, V1, E, F = scenes.folded_cloth(60, seed=3)
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    rng = np.random.default_rng(11)
+    try:
+        for step, amp in enumerate([0.0, 1e-5, 1e-5, 3e-2, 1e-5, 0.0, 2e-3, 2e-3, 8e-2, 1e-4, 1e-4, 0.0]):
+            W0 = V0 + rng.uniform(-amp, amp, V0.shape)
+            W1 = V1 + rng.uniform(-amp, amp, V1.shape)
+            mesh.update_vertices(W0, W1)
+            want, nvf, nee = orc.ccd(W0, W1, E, F, nthreads=8)
+            tois, pairs = [], 0
+            for r in range(world):
+                ctx.set_option(sccd.OPT_SHARD_COUNT, world)
+                ctx.set_option(sccd.OPT_SHARD_RANK, r)
+                t, st = sccd.ccd_mesh(mesh, want_stats=True)
+                tois.append(t)
+                pairs += st["n_vf_pairs"] + st["n_ee_pairs"]
+            assert min(tois) == want, (step, amp, tois, want)
+            assert pairs == nvf + nee, (step, amp, pairs, nvf + nee)
+    finally:
+        ctx.set_option(sccd.OPT_SHARD_COUNT, 1)
+        ctx.set_option(sccd.OPT_SHARD_RANK, 0)
 
 
 def test_ccd_with_collisions(sccd, ctx, orc):
