@@ -49,6 +49,18 @@ def pytest_configure(config):
         config.option.timeout_method = "thread"
 
 
+def pytest_collection_modifyitems(config, items):
+    """SCCD_TEST_ORDER=reverse | shuffle:<seed>: the tests in another order -- the GPU tests share one context, and what a test
+    leaves there (buffer sizes, a BroadPhase's guess of its next build) must not matter to the next."""
+    order = os.environ.get("SCCD_TEST_ORDER", "")
+    if order == "reverse":
+        items.reverse()
+    elif order.startswith("shuffle:"):
+        import random
+
+        random.Random(int(order.split(":", 1)[1])).shuffle(items)
+
+
 @pytest.fixture(scope="session")
 def orc():
     """The CPU oracle (oracle/sccd_oracle.c) -- the checker, never the product."""
