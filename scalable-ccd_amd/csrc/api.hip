@@ -863,12 +863,11 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     // two lists with an empty side produce nothing (sort_and_sweep.cpp:221-223)
     if (A->n == 0 || (B && B->n == 0)) return;
 
-    bp->grid.ensure(4096 + sizeof(uint32_t) * SCCD_MAX_CELLS); // (unused) | params @512 | cell histogram @4096
+    // the grid block: (unused) | params + the lists' totals @512 (GridReadBack) | a rank's cell window @1024 | cell histogram @4096
+    bp->grid.ensure(4096 + sizeof(uint32_t) * SCCD_MAX_CELLS);
     GridParams* gp = reinterpret_cast<GridParams*>(bp->grid.as<char>() + 512);
-    // the two list totals sit right behind the grid parameters: ONE copy brings both back (two copies in a
-    // row cost a 12 us bubble between them)
     uint32_t* d_total = reinterpret_cast<uint32_t*>(bp->grid.as<char>() + 512 + offsetof(GridReadBack, total));
-    static_assert(512 + sizeof(GridReadBack) <= 4096, "grid buffer layout");
+    static_assert(512 + sizeof(GridReadBack) <= 1024 && 1024 + sizeof(ShardWindow) <= 4096, "grid buffer layout");
     {
         // lazy lists live on the device-window path only
         static const bool dw_env = !(std::getenv("SCCD_DEVICE_WINDOW") && std::atoi(std::getenv("SCCD_DEVICE_WINDOW")) == 0);
@@ -1166,7 +1165,6 @@ static void bp_detect_partial(sccd_broad_phase* bp, int phase = 0)
     int64_t chunk_hi = std::min(bp->cursor + cutoff, bp->total_rows);
 
     SweepCounters* d_cnt = c->scalars.as<SweepCounters>();
-    if (phase == 3) return; // (round 2 computed candidate ranges ahead of the sweep here; the sweep finds a row's columns itself now)
     // SCCD_OPT_SWEEP_ALGO: 0 / 2 / 3 the band sweep (window staging -> skewed filter -> queue -> confirm), 1 plain SAP cross-check.
     // Capacity sizing (MemoryHandler, memory_handler.cpp:11-79): the overlap list may use half of
     // the memory limit (SCCD_OPT_MEMORY_LIMIT_MB / ccd()'s memory_limit_GB; default: whatever
@@ -1584,7 +1582,6 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
             SCCD_HIP(hipSetDevice(device));
             SCCD_HIP(hipStreamWaitEvent(sc->stream, ev, 0));
             bp_build(bp_ee, eb, nullptr);
-            if (presweep_env) bp_detect_partial(bp_ee, 3); // the candidate ranges too (a 25 us kernel that must not queue behind the narrow phase)
         });
         helper = true;
     }
