@@ -1151,11 +1151,59 @@ static void shard_rows(sccd_ctx* c, bool row_shard, int lo, int hi, int* out_lo,
 // phase 0: the whole step.  phase 1: enqueue the first attempt only (ranges + sweep), no read-back -- ccd() starts the
 // edge-edge sweep this way beside the vertex-face narrow phase; phase 2: finish what phase 1 started (read the counters
 // back, rerun on overflow as usual).
+// A speculative build (bp_build) against what it really had -- the grid and the lists' entry counts (and a rank's cell window)
+// as read back from the device: did the guess hold?  Everything the slow build looks at between the fill and the sort.  On
+// success the lists' sizes become the real ones and the next build's guess follows the scene; on failure the guess is dropped
+// (the caller builds again, the slow way).
+static bool speculation_settle(sccd_broad_phase* bp, const GridReadBack& built, const ShardWindow& hwin)
+{
+    const sccd_broad_phase::Guess& gs = bp->guess;
+    const bool two = bp->B != nullptr;
+    const uint32_t ta = built.total[0], tb = two ? built.total[1] : 0u;
+    const int64_t n_total = (int64_t)bp->A->n + (two ? bp->B->n : 0);
+    const bool ok = built.gp.key_bits == gs.key_bits                  // the sort ran the right passes
+        && ta > 0 && (!two || tb > 0)                                 // (an empty side ends a build early)
+        && ta <= bp->spec_bound[0] && tb <= bp->spec_bound[1]         // records and sweep saw every entry
+        && (unsigned long long)ta + tb <= bp->spec_sorted             // ... and so did the sort
+        && std::max(ta, tb) <= bp->spec_cap                           // the fill dropped nothing
+        && (bp->spec_window                                           // no coarser grid was due, nor a split by rows
+                ? !(hwin.total_est > (unsigned long long)std::max<int64_t>(3 * n_total, n_total + 4096)) && hwin.n_cells >= 4 * bp->ctx->shard_count
+                : !over_budget(ta, bp->A->n) && !(two && over_budget(tb, bp->B->n)));
+    bp->speculative = false;
+    if (!ok) {
+        bp->guess.valid = false;
+        return false;
+    }
+    if (bp->spec_window) {
+        bp->cell_lo = hwin.cell_lo;
+        bp->cell_hi = hwin.cell_hi;
+    }
+    bp->la.m = (int)ta;
+    bp->lb.m = (int)tb;
+    bp->total_rows = (int64_t)ta + tb;
+    bp->guess.total[0] = ta;
+    bp->guess.total[1] = tb;
+    return true;
+}
+
 static void bp_detect_partial(sccd_broad_phase* bp, int phase = 0)
 {
     sccd_ctx* c = bp->ctx;
     if (!bp->built) throw SccdError { SCCD_E_NOT_BUILT, "Must initialize build broad phase before detecting overlaps!" };
     bp->n_overlaps = 0;
+    if (bp->speculative && phase != 2 && (c->max_overlap_cutoff > 0 || c->sweep_algo == 1)) {
+        // the options were changed between build and sweep to ones a speculative sweep does not serve (chunks of rows, the
+        // plain sweep): read what was built now, and go on with real sizes -- or build again
+        GridReadBack built;
+        ShardWindow hwin {};
+        {
+            ReadBack rb(c);
+            rb.add(&built, bp->grid.as<char>() + 512, sizeof built);
+            if (bp->spec_window) rb.add(&hwin, bp->grid.as<char>() + 1024, sizeof hwin);
+            rb.sync();
+        }
+        if (!speculation_settle(bp, built, hwin)) bp_build(bp, bp->A, bp->B);
+    }
     if (bp->cursor >= bp->total_rows) return;
     const SortedList* A = &bp->la;
     const SortedList* B = bp->B ? &bp->lb : nullptr;
@@ -1227,40 +1275,15 @@ static void bp_detect_partial(sccd_broad_phase* bp, int phase = 0)
             rb.sync();
         }
         if (bp->speculative) {
-            // did the guess hold?  Everything the slow build would have looked at between the fill and the sort:
-            const sccd_broad_phase::Guess& gs = bp->guess;
-            const bool two = bp->B != nullptr;
-            const uint32_t ta = built.total[0], tb = two ? built.total[1] : 0u;
-            const bool ok = built.gp.key_bits == gs.key_bits                                   // the sort ran the right passes
-                && ta > 0 && (!two || tb > 0)                                                  // (an empty side ends the build early)
-                && ta <= bp->spec_bound[0] && tb <= bp->spec_bound[1]                          // records and sweep saw every entry
-                && (unsigned long long)ta + tb <= bp->spec_sorted                              // ... and so did the sort
-                && std::max(ta, tb) <= bp->spec_cap                                            // the fill dropped nothing
-                && (bp->spec_window                                                            // no coarser grid was due
-                        ? !(hwin.total_est > (unsigned long long)std::max<int64_t>(3 * (int64_t)(bp->A->n + (two ? bp->B->n : 0)),
-                                                                                   (int64_t)(bp->A->n + (two ? bp->B->n : 0)) + 4096))
-                            && hwin.n_cells >= 4 * c->shard_count                               // ... nor a split by rows
-                        : !over_budget(ta, bp->A->n) && !(two && over_budget(tb, bp->B->n)));
-            if (!ok) {
+            if (!speculation_settle(bp, built, hwin)) {
                 // build again, the slow way (the guess is gone: bp_build waits for the counts), and sweep that
-                bp->guess.valid = false;
                 const int64_t done = bp->candidates_done;
                 bp_build(bp, bp->A, bp->B);
                 bp->candidates_done = done;
                 bp_detect_partial(bp, 0);
                 return;
             }
-            bp->speculative = false;
-            if (bp->spec_window) {
-                bp->cell_lo = hwin.cell_lo;
-                bp->cell_hi = hwin.cell_hi;
-            }
-            bp->la.m = (int)ta;
-            bp->lb.m = (int)tb;
-            bp->total_rows = (int64_t)ta + tb;
             chunk_hi = bp->total_rows; // (a speculative build is swept in one chunk: bp_build)
-            bp->guess.total[0] = ta;   // (the next build's guess follows the scene)
-            bp->guess.total[1] = tb;
         }
         {
             unsigned long long cs = 0;

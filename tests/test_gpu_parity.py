@@ -350,6 +350,18 @@ def test_speculative_builds_follow_the_scene_and_survive_a_wrong_guess(sccd, ctx
         want = orc.sort_and_sweep(a, b)[0] if b is not None else orc.sort_and_sweep(a)[0]
         assert np.array_equal(got, want), (seed, ext, jitter, len(got), len(want))
         assert bp.is_complete()
+    # options changed BETWEEN a (speculative) build and its sweep to ones a speculative sweep does not serve: the plain
+    # sweep, rows in chunks -- the build is settled first (csrc/api.hip bp_detect_partial)
+    a, b = scene(5, 0.02, 3e-4)
+    want = orc.sort_and_sweep(a, b)[0] if b is not None else orc.sort_and_sweep(a)[0]
+    da, db = sccd.DeviceAABBs(a, ctx), (sccd.DeviceAABBs(b, ctx) if b is not None else None)
+    for option, value in ((sccd.OPT_SWEEP_ALGO, 1), (sccd.OPT_MAX_OVERLAP_CUTOFF, 7000)):
+        bp.build(da, db)
+        ctx.set_option(option, value)
+        try:
+            assert np.array_equal(_sorted(bp.detect_overlaps()), want), option
+        finally:
+            ctx.set_option(option, 0)
 
 
 def test_random_100k_matches_golden_hash(sccd, ctx):
