@@ -788,7 +788,8 @@ static void lists_records(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B,
 // d_tot (speculative build): total_a / total_b are BOUNDS -- their sum is sorted, padded behind the real pairs -- and the
 // real counts {A, B, A + B} sit in device memory
 static void lists_finish_merged(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B, const GridParams* gp, uint32_t total_a,
-                                uint32_t total_b, int key_bits, SortedList* LA, SortedList* LB, const uint32_t* d_tot = nullptr)
+                                uint32_t total_b, int key_bits, SortedList* LA, SortedList* LB, const uint32_t* d_tot = nullptr,
+                                const uint32_t* d_extq = nullptr)
 {
     const size_t ma = total_a, mb = total_b, m = ma + mb, pad = SCCD_LIST_PAD;
     SCCD_REQUIRE(m < (1u << 31), "broad phase: too many cell entries");
@@ -814,7 +815,7 @@ static void lists_finish_merged(sccd_ctx* c, const sccd_boxes* A, const sccd_box
         const uint32_t* keys = LA->key.as<uint32_t>();
         const uint32_t* idx = LA->idx.as<uint32_t>();
         launch_entry_records_two(c, A->raw.as<sccd_aabb>(), keys, idx, (int)ma, B->raw.as<sccd_aabb>(), keys + ma, idx + ma, (int)mb,
-                                 /*b_tagged=*/true, gp, LA, LB, d_tot, key_bits);
+                                 /*b_tagged=*/true, gp, LA, LB, d_tot, key_bits, d_extq);
     }
 }
 
@@ -836,7 +837,13 @@ struct GridReadBack {
     GridParams gp;
     uint32_t total[2];
     uint32_t place; // (device only: the shared placement cursor of a merged two-list fill)
+    uint32_t ext_q; // (device only: list A's largest extent along the sort axis, quantised -- the one-class two-list sweep)
 };
+static bool one_class_env()
+{
+    static const bool on = !(std::getenv("SCCD_ONE_CLASS") && std::atoi(std::getenv("SCCD_ONE_CLASS")) == 0);
+    return on;
+}
 static bool speculate_env()
 {
     static const bool on = !(std::getenv("SCCD_SPECULATE") && std::atoi(std::getenv("SCCD_SPECULATE")) == 0);
@@ -857,6 +864,7 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     bp->candidates_done = 0;
     bp->la.m = bp->lb.m = 0;
     bp->speculative = false;
+    bp->one_class = false;
     bp->la.kind = A->kind;
     bp->lb.kind = B ? B->kind : BOX_UNKNOWN;
     bp->total_rows = 0;
@@ -896,6 +904,10 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
     static const bool merged_env = !(std::getenv("SCCD_MERGED_SORT") && std::atoi(std::getenv("SCCD_MERGED_SORT")) == 0);
     const bool scan_build_env = std::getenv("SCCD_BUILD") && std::string(std::getenv("SCCD_BUILD")) == "scan";
     const bool want_merged = merged_env && B != nullptr && !scan_build_env;
+    // ONE sweep class for vertices x faces: every pair is found from the FACE's row, whose window reaches back over the
+    // vertices that start before it (entry_record_body) -- a vertex box is a point's path: tiny along the sort axis -- instead
+    // of a second class with the vertices as rows: each list is read once, not twice (SCCD_ONE_CLASS=0: two classes)
+    const bool one_class = one_class_env() && want_merged && A->kind == BOX_VERTEX && B->kind == BOX_FACE && c->sweep_algo != 1;
     // Multi-GPU, first attempt: the rank's window of cells is dealt out ON THE DEVICE (shard_window_k) and the fill reads it
     // from there -- no host round trip between the histogram and the fill.  What the host would have decided from the
     // histogram (coarsen the grid: too much replication; too few cells to deal out: shard by rows) is checked when the
@@ -985,7 +997,7 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
             for (int fill_round = 0;; fill_round++) {
                 SCCD_REQUIRE(cap < (1ull << 31), "broad phase: too many cell entries");
                 const size_t pad = 64;
-                if (fill_round > 0) SCCD_HIP(hipMemsetAsync(d_total, 0, 3 * sizeof(uint32_t), c->stream)); // (grid_setup_k zeroed them for round 0)
+                if (fill_round > 0) SCCD_HIP(hipMemsetAsync(d_total, 0, 4 * sizeof(uint32_t), c->stream)); // (grid_setup_k zeroed them for round 0)
                 {
                     ProfScope ps(c, SCCD_PROF_BOXES);
                     // (merged sort: list A's buffers also take list B's entries behind its own)
@@ -1029,7 +1041,8 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
                             bp->spec_cap = (uint32_t)cap;
                             bp->spec_window = device_window;
                             if (want_merged) {
-                                lists_finish_merged(c, A, B, gp, ba, bb, gs.key_bits, &bp->la, &bp->lb, d_total);
+                                bp->one_class = one_class;
+                                lists_finish_merged(c, A, B, gp, ba, bb, gs.key_bits, &bp->la, &bp->lb, d_total, one_class ? d_total + 3 : nullptr);
                             } else {
                                 list_sort(c, A, gp, bp->cell_lo, bp->cell_hi, ba, gs.key_bits, &bp->la, true, d_total);
                                 lists_records(c, A, nullptr, gp, &bp->la, &bp->lb, d_total, gs.key_bits);
@@ -1082,7 +1095,9 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
             }
             if (want_merged) {
                 // (a side without entries in this rank's cells: no pair can come of it -- sort_and_sweep.cpp:221-223)
-                if (total[0] > 0 && total[1] > 0) lists_finish_merged(c, A, B, gp, total[0], total[1], hgp.key_bits, &bp->la, &bp->lb);
+                bp->one_class = one_class;
+                if (total[0] > 0 && total[1] > 0)
+                    lists_finish_merged(c, A, B, gp, total[0], total[1], hgp.key_bits, &bp->la, &bp->lb, nullptr, one_class ? d_total + 3 : nullptr);
                 else bp->la.m = bp->lb.m = 0;
             } else {
                 list_sort(c, A, gp, bp->cell_lo, bp->cell_hi, total[0], hgp.key_bits, &bp->la, true);
@@ -1258,6 +1273,9 @@ static void bp_detect_partial(sccd_broad_phase* bp, int phase = 0)
                 ? reinterpret_cast<const uint32_t*>(bp->grid.as<char>() + 512 + offsetof(GridReadBack, total)) : nullptr;
             if (!B) {
                 launch_sweep(c, A, A, gp, a_lo, a_hi, EMIT_ONE_LIST, bp->overlaps.as<int2>(), bp->capacity, d_cnt, d_tot, d_tot, bp->guess.key_bits);
+            } else if (bp->one_class) { // (list B's rows only: their windows reach back -- bp_build)
+                launch_sweep(c, B, A, gp, b_lo, b_hi, EMIT_ROWS_B, bp->overlaps.as<int2>(), bp->capacity, d_cnt, d_tot ? d_tot + 1 : nullptr,
+                             d_tot, bp->guess.key_bits);
             } else {
                 launch_sweep_two(c, A, B, gp, a_lo, a_hi, b_lo, b_hi, bp->overlaps.as<int2>(), bp->capacity, d_cnt, d_tot, bp->guess.key_bits);
             }

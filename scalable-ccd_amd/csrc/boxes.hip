@@ -343,7 +343,7 @@ __global__ __launch_bounds__(SCCD_STATS_BLOCKS) void grid_setup_k(const GridStat
                              uint32_t* __restrict__ cursors /* the two list cursors of the fill pass: zeroed here */,
                              int max_cells, int reserve_tag, uint32_t* __restrict__ zero_hist /* [SCCD_MAX_CELLS] or null */)
 {
-    if (threadIdx.x < 3) cursors[threadIdx.x] = 0u; // the two list totals and the placement cursor of a merged two-list fill
+    if (threadIdx.x < 4) cursors[threadIdx.x] = 0u; // the two list totals, the placement cursor of a merged two-list fill, list A's extent
     if (zero_hist) // (multi-GPU: the sampled cell histogram the next launch adds to -- a memset of its own was a launch more)
         for (int k = threadIdx.x; k < SCCD_MAX_CELLS; k += SCCD_STATS_BLOCKS) zero_hist[k] = 0u;
     // Bounds and summed extents of both lists from the builders' block partials: thread j takes partial j of list A and of
@@ -564,8 +564,11 @@ template <int SRC>
 __device__ __forceinline__ void cell_fill_append_body(const BoxSrc& bs, int n, const GridParams* __restrict__ gp,
                                                       int cell_lo, int cell_hi, uint32_t* __restrict__ cursor, uint32_t capacity,
                                                       uint32_t* __restrict__ key, uint32_t* __restrict__ idx, int tagged,
-                                                      uint32_t* __restrict__ place, int block, const ShardWindow* __restrict__ d_win = nullptr)
+                                                      uint32_t* __restrict__ place, int block, const ShardWindow* __restrict__ d_win = nullptr,
+                                                      uint32_t* __restrict__ extq_out = nullptr)
 {
+    // extq_out (may be null): receives the list's largest extent along the sort axis in QUANTISED units, max over the boxes of
+    // xq(hi) - xq(lo) -- what a one-class two-list sweep extends a row's window backwards by (entry_record_body)
     if (d_win) {
         cell_lo = d_win->cell_lo;
         cell_hi = d_win->cell_hi;
@@ -577,7 +580,7 @@ __device__ __forceinline__ void cell_fill_append_body(const BoxSrc& bs, int n, c
     const uint32_t tag = (tagged && g.tag_bit >= 0) ? (1u << g.tag_bit) : 0u; // list B of a merged two-list sort
     CellSpan s[FILL_PER];
     unsigned q[FILL_PER];
-    uint32_t cnt[FILL_PER], mine = 0;
+    uint32_t cnt[FILL_PER], mine = 0, extq = 0;
 #pragma unroll
     for (int k = 0; k < FILL_PER; k++) {
         const int i = block * FILL_BOXES + k * (int)blockDim.x + (int)threadIdx.x;
@@ -589,6 +592,7 @@ __device__ __forceinline__ void cell_fill_append_body(const BoxSrc& bs, int n, c
             const BoxLoad b = src_box<SRC>(bs, i, &ids);
             s[k] = cell_span(g, b);
             q[k] = grid_qx(g, sel3d(b.lo, g.axis));
+            if (extq_out) extq = max(extq, grid_qx(g, sel3d(b.hi, g.axis)) - q[k]);
             for (int ca = s[k].a0; ca <= s[k].a1; ca++) {
                 const int c0 = max(ca * g.Sb + s[k].b0, cell_lo), c1 = min(ca * g.Sb + s[k].b1, cell_hi - 1);
                 cnt[k] += c1 >= c0 ? (uint32_t)(c1 - c0 + 1) : 0u;
@@ -600,11 +604,20 @@ __device__ __forceinline__ void cell_fill_append_body(const BoxSrc& bs, int n, c
     }
     const uint32_t incl = (uint32_t)wave_incl_scan((int)mine);
     const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-    __shared__ uint32_t wave_tot[16], wave_base[16];
+    __shared__ uint32_t wave_tot[16], wave_base[16], wave_ext[16];
     const int w = threadIdx.x >> 6;
     if (lane_id() == 63) wave_tot[w] = total;
+    if (extq_out) {
+        const uint32_t wmax = wave_max_u32_dpp(extq);
+        if (lane_id() == 0) wave_ext[w] = wmax;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (extq_out) {
+            uint32_t m = 0;
+            for (int k = 0; k < (int)(blockDim.x >> 6); k++) m = max(m, wave_ext[k]);
+            if (m) atomicMax(extq_out, m);
+        }
         uint32_t sum = 0;
         for (int k = 0; k < (int)(blockDim.x >> 6); k++) {
             wave_base[k] = sum;
@@ -643,11 +656,12 @@ __global__ void cell_fill_append_k(BoxSrc bs, int n, const GridParams* __restric
 // same placement cursor and only count apart
 template <int SRC_A, int SRC_B>
 __global__ void cell_fill_append2_k(BoxSrc a, int na, BoxSrc b, int nb, int blocks_a, const GridParams* __restrict__ gp, int cell_lo,
-                                    int cell_hi, uint32_t* __restrict__ cursors /* [0] A, [1] B, [2] placement */, uint32_t capacity,
+                                    int cell_hi, uint32_t* __restrict__ cursors /* [0] A, [1] B, [2] placement, [3] list A's extent (quantised) */, uint32_t capacity,
                                     uint32_t* __restrict__ key, uint32_t* __restrict__ idx, const ShardWindow* __restrict__ d_win)
 {
     if ((int)blockIdx.x < blocks_a)
-        cell_fill_append_body<SRC_A>(a, na, gp, cell_lo, cell_hi, cursors, capacity, key, idx, 0, cursors + 2, (int)blockIdx.x, d_win);
+        cell_fill_append_body<SRC_A>(a, na, gp, cell_lo, cell_hi, cursors, capacity, key, idx, 0, cursors + 2, (int)blockIdx.x, d_win,
+                                     cursors + 3);
     else
         cell_fill_append_body<SRC_B>(b, nb, gp, cell_lo, cell_hi, cursors + 1, capacity, key, idx, 1, cursors + 2,
                                      (int)blockIdx.x - blocks_a, d_win);
@@ -740,7 +754,8 @@ struct RecordArgs { // one list's share of a record launch
     uint32_t pstride;
 };
 template <int MODE>
-__device__ __forceinline__ void entry_record_body(const RecordArgs& a, const GridParams* __restrict__ gp, unsigned* s_win, int block)
+__device__ __forceinline__ void entry_record_body(const RecordArgs& a, const GridParams* __restrict__ gp, unsigned* s_win, int block,
+                                                  uint32_t ext_q = 0xFFFFFFFFu)
 {
     const sccd_aabb* __restrict__ raw = a.raw;
     const uint32_t* __restrict__ key = a.key;
@@ -756,19 +771,35 @@ __device__ __forceinline__ void entry_record_body(const RecordArgs& a, const Gri
     const uint32_t own_strip = own_tagged ? tag : 0u, other_or = other_tagged ? tag : 0u;
     const uint32_t k_e = valid ? (key[e] & ~own_strip) : 0u;
     uint32_t start = (uint32_t)e + 1u;
-    if (MODE != 0) {
+    if (MODE == 1 && ext_q == 0xFFFFFFFEu) {
+        start = 0u; // (list A of a one-class sweep: its entries are columns only, no row of it is ever swept)
+    } else if (MODE != 0) {
+        // ext_q != NO_EXT (list B's rows, ONE-CLASS sweep: sweep.hip launch_sweep_two): the row's window also reaches BACK, over
+        // the columns that start before the row and may still overlap it -- those whose quantised start is at most ext_q (the
+        // other list's largest quantised extent, from the fill) below the row's.  The key with the coordinate lowered keeps
+        // the rows' order, so the block's window search works as before.
+        const uint32_t xmask = g.xb >= 32 ? 0xFFFFFFFFu : ((1u << g.xb) - 1u);
+        auto back = [&](uint32_t k) -> uint32_t {
+            const uint32_t xq = k & xmask;
+            return (k & ~xmask) | (xq > ext_q ? xq - ext_q : 0u);
+        };
+        const bool one_class = MODE == 2 && ext_q != 0xFFFFFFFFu;
         const int w = threadIdx.x >> 6;
         if (w < 2) { // wave 0: the window's lower end from the block's first key; wave 1: its upper end from the last one
             const int e_first = block * (int)blockDim.x, e_last = min(e_first + (int)blockDim.x, m) - 1;
-            const uint32_t v = (key[w == 0 ? e_first : e_last] & ~own_strip) | other_or;
-            const unsigned at = MODE == 1 ? wave_bound_u32<false>(other, (unsigned)n_other, v)
-                                          : wave_bound_u32<true>(other, (unsigned)n_other, v);
+            uint32_t v = key[w == 0 ? e_first : e_last] & ~own_strip;
+            if (one_class && w == 0) v = back(v);
+            v |= other_or;
+            const unsigned at = (MODE == 1 || (one_class && w == 0)) ? wave_bound_u32<false>(other, (unsigned)n_other, v)
+                                                                     : wave_bound_u32<true>(other, (unsigned)n_other, v);
             if (lane_id() == 0) s_win[w] = at;
         }
         __syncthreads();
         const unsigned w0 = s_win[0], w1 = max(s_win[0], s_win[1]);
         if (valid)
-            start = MODE == 1 ? lower_bound_in(other, w0, w1, k_e | other_or) : upper_bound_in(other, w0, w1, k_e | other_or);
+            start = MODE == 1 ? lower_bound_in(other, w0, w1, k_e | other_or)
+                : one_class   ? lower_bound_in(other, w0, w1, back(k_e) | other_or)
+                              : upper_bound_in(other, w0, w1, k_e | other_or);
     }
     if (!valid) return;
     const sccd_aabb* src = raw + idx[e];
@@ -804,7 +835,8 @@ __global__ __launch_bounds__(ER_THREADS) void entry_record_k(RecordArgs a, const
 // both lists of a two-list build in ONE launch (the first blocks_a blocks: list A's rows; two launches in a row sat on the
 // critical path of every vertex-face pass)
 __global__ __launch_bounds__(ER_THREADS) void entry_record2_k(RecordArgs a, RecordArgs b, int blocks_a, const GridParams* __restrict__ gp,
-                                                              const uint32_t* __restrict__ d_tot, int expect_bits)
+                                                              const uint32_t* __restrict__ d_tot, int expect_bits,
+                                                              const uint32_t* __restrict__ d_extq /* one-class sweep: list A's extent, or null */)
 {
     __shared__ unsigned s_win[2];
     if (d_tot) { // device-side counts (entry_record_k): ONE merged, sorted array -- list A's pairs, then list B's
@@ -819,8 +851,8 @@ __global__ __launch_bounds__(ER_THREADS) void entry_record2_k(RecordArgs a, Reco
         blocks_a = (ma + ER_THREADS - 1) / ER_THREADS;
         if ((int)blockIdx.x >= blocks_a + (mb + ER_THREADS - 1) / ER_THREADS) return;
     }
-    if ((int)blockIdx.x < blocks_a) entry_record_body<1>(a, gp, s_win, (int)blockIdx.x);
-    else entry_record_body<2>(b, gp, s_win, (int)blockIdx.x - blocks_a);
+    if ((int)blockIdx.x < blocks_a) entry_record_body<1>(a, gp, s_win, (int)blockIdx.x, d_extq ? 0xFFFFFFFEu : 0xFFFFFFFFu);
+    else entry_record_body<2>(b, gp, s_win, (int)blockIdx.x - blocks_a, d_extq ? min(*d_extq, 0xFFFFFFF0u) : 0xFFFFFFFFu);
 }
 
 // sum and sum of squares of the box centres per axis (sort_and_sweep.cpp:176-186): per-block
@@ -1075,14 +1107,15 @@ void launch_entry_records(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key
 // the records of both lists of a two-list build in one launch (list A's rows look their first column up among keys_b, ...)
 void launch_entry_records_two(sccd_ctx* c, const sccd_aabb* raw_a, const uint32_t* key_a, const uint32_t* idx_a, int ma,
                               const sccd_aabb* raw_b, const uint32_t* key_b, const uint32_t* idx_b, int mb, bool b_tagged,
-                              const GridParams* g, SortedList* out_a, SortedList* out_b, const uint32_t* d_tot, int expect_bits)
+                              const GridParams* g, SortedList* out_a, SortedList* out_b, const uint32_t* d_tot, int expect_bits,
+                              const uint32_t* d_extq)
 {
     if (ma == 0 || mb == 0) return;
     const RecordArgs a = record_args(raw_a, key_a, idx_a, ma, key_b, mb, false, b_tagged, out_a);
     const RecordArgs b = record_args(raw_b, key_b, idx_b, mb, key_a, ma, b_tagged, false, out_b);
     const int blocks_a = (ma + ER_THREADS - 1) / ER_THREADS, blocks_b = (mb + ER_THREADS - 1) / ER_THREADS;
     // (device-side counts: one block more than the bounds need -- the split between the lists moves with the real counts)
-    hipLaunchKernelGGL(entry_record2_k, dim3((unsigned)(blocks_a + blocks_b + (d_tot ? 1 : 0))), dim3(ER_THREADS), 0, c->stream, a, b, blocks_a, g, d_tot, expect_bits);
+    hipLaunchKernelGGL(entry_record2_k, dim3((unsigned)(blocks_a + blocks_b + (d_tot ? 1 : 0))), dim3(ER_THREADS), 0, c->stream, a, b, blocks_a, g, d_tot, expect_bits, d_extq);
     SCCD_HIP(hipGetLastError());
 }
 

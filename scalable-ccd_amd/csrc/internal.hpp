@@ -98,6 +98,7 @@ struct sccd_broad_phase {
         double cell_factor = 0;
         uint32_t total[2] = { 0, 0 };
     } guess;
+    bool one_class = false;                // a two-list build whose sweep runs list B's rows only (api.hip bp_build)
     bool speculative = false;              // la.m / lb.m are BOUNDS until bp_detect_partial has checked the guess
     bool spec_window = false;              // ... of a rank's cell window, dealt out on the device
     uint32_t spec_bound[2] = { 0, 0 };     // what the records were sized for
@@ -154,7 +155,8 @@ void launch_cell_fill(sccd_ctx* c, const sccd_aabb* raw, int n, const GridParams
 // both lists of a two-list build in one launch (b_tagged: list B's keys carry the list tag of a merged sort)
 void launch_entry_records_two(sccd_ctx* c, const sccd_aabb* raw_a, const uint32_t* key_a, const uint32_t* idx_a, int ma,
                               const sccd_aabb* raw_b, const uint32_t* key_b, const uint32_t* idx_b, int mb, bool b_tagged,
-                              const GridParams* g, SortedList* out_a, SortedList* out_b, const uint32_t* d_tot = nullptr, int expect_bits = 0);
+                              const GridParams* g, SortedList* out_a, SortedList* out_b, const uint32_t* d_tot = nullptr, int expect_bits = 0,
+                              const uint32_t* d_extq = nullptr);
 // own_tagged / other_tagged: this list's / the column list's keys carry the list tag of a merged sort
 void launch_entry_records(sccd_ctx* c, const sccd_aabb* raw, const uint32_t* key, const uint32_t* idx, int m,
                           const GridParams* g, int mode, const uint32_t* other, int n_other, bool own_tagged,
