@@ -73,12 +73,15 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cloth1m", choices=["cloth1m", "clothball10k", "boxes1m", "sort16m"])
     ap.add_argument("--cloth-n", type=int, default=708, help="cloth grid side for cloth1m (708 -> 999,698 tris)")
-    ap.add_argument("--arith", type=int, default=0, help="0 strict, 1 fused multiply-add contract")
+    ap.add_argument("--arith", type=int, default=1, help="1 (library default): a*b+c fused as the reference's nvcc --use_fast_math build fuses them; 0 strict (every product and sum rounded separately)")
     ap.add_argument("--sweep-algo", type=int, default=0, help="0 auto, 1 plain SAP, 2 filter/queue/confirm, 3 direct")
     ap.add_argument("--max-iter", type=int, default=-1, help="Tight-Inclusion check limit per query (the IPC Toolkit passes 10000000); -1: none")
     ap.add_argument("--limit-level-order", action="store_true", help="SCCD_OPT_LIMIT_LEVEL_ORDER: check limits on the level-synchronous kernels (round 2's default)")
     ap.add_argument("--boxes-n", type=int, default=1_000_000, help="boxes1m: number of boxes (SURVEY 8d also asks for 16,000,000; extents shrink so that ~10 overlaps per box remain)")
     ap.add_argument("--boxes-variant", default="iso", choices=["iso", "thin"], help="boxes1m: isotropic, or cloth-like (z extents x 0.01: SURVEY 8d)")
+    ap.add_argument("--jitter", type=float, default=0.0, help="cloth workloads: the mesh MOVES between steps (end positions + A x uniform noise, eight "
+                    "device-resident variants in turn, sccd_mesh_update_vertices inside the timed region): speculative builds can miss; "
+                    "reports spec_hit_rate, p50 / p99 ms per step and the cost of a missed guess.  0 (default): the frozen mesh of the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="cloth side of the CPU sample (0 = auto)")
     return ap.parse_args()
@@ -150,6 +153,15 @@ def main():
         if args.limit_level_order:
             ctx.set_option(sccd.OPT_LIMIT_LEVEL_ORDER, 1)
 
+        if args.jitter > 0:
+            result = bench_jitter(args, ctx, sccd, torch, mesh, tV0, tV1, params, wl, world)
+            if use_dist:
+                dist.destroy_process_group()
+            if rank == 0:
+                sys.stdout.flush()
+                print(json.dumps(result), flush=True)
+            return
+
         def step():
             # one ccd() per rank on its shard of the cell grid (SHARD_RANK / SHARD_COUNT options of the context),
             # then ONE all-reduce(min) of the 8-byte TOI; SCCD_BENCH_SPLIT=1 runs the pass-by-pass protocol instead
@@ -157,8 +169,16 @@ def main():
                 return sdist.ccd_sharded(
                     lambda is_vf, toi: sccd.ccd_mesh_pass(mesh, is_vf, toi, **params),
                     rank, world, device=red_dev, prepare=lambda: sccd.ccd_mesh_prepare(mesh, 0.0))
+            if dev_min is not None:
+                # RCCL: the TOI stays in a persistent device word that is all-reduced in place, stream-ordered behind the step;
+                # the host does not wait for the collective (the value is read once, after the timed region)
+                t, st = sccd.ccd_mesh_dev(mesh, dev_min.ptr(), want_stats=True, **params)
+                dev_min.reduce()
+                return t, st
             t, st = sccd.ccd_mesh(mesh, want_stats=True, **params)
             return sdist.allreduce_min(t, device=red_dev), st
+
+        dev_min = sdist.DeviceMin(ctx, dev) if (use_dist and backend == "nccl" and os.environ.get("SCCD_BENCH_SPLIT") != "1") else None
 
         # Warm-up, then two more untimed steps with hipEvents around EVERY kernel class: the per-class breakdown,
         # and which class dominates.  The timed region keeps events on that one class only -- two event records
@@ -188,6 +208,8 @@ def main():
             q_local += stats["n_vf_pairs"] + stats["n_ee_pairs"]
         barrier()
         dt = time.perf_counter() - t0
+        if dev_min is not None:
+            toi = dev_min.value()  # (the reduced word of the last step; every step of this frozen mesh has the same)
         prof = ctx.profile()
         ctx.set_option(sccd.OPT_PROFILE, 0)
         # max over ranks of the elapsed time, sum over ranks of the queries
@@ -313,10 +335,12 @@ def main():
                            checks_per_step=float(qq[1].item()), candidates_per_step=float(qq[2].item()),
                            parallelism=f"cell windows sharded over {world} GPU(s), one RCCL all-reduce(min) of the TOI per step",
                            rccl_ranks=rccl_ranks, backend=(backend if use_dist else "none")),
-            # the reference's ccd() takes host matrices and uploads them inside the call: ITS min-TOI latency is the host path
-            "min_toi_latency_ms": host_ms if host_ms is not None else dt / args.steps * 1e3,
+            # schema 2 (round 4): min_toi_latency_ms is ONE thing again -- the step's latency on a device-resident mesh, = ms_per_step,
+            # as in rounds 1-2 and for any number of ranks; the reference-shaped call from host matrices is host_path_ms only
+            "schema": 2,
+            "min_toi_latency_ms": dt / args.steps * 1e3,
             "host_path_ms": host_ms,
-            "min_toi_latency_note": "sccd_ccd() from pageable host matrices, upload and packing inside the call (best of 5); ms_per_step is the same step on a device-resident mesh",
+            "host_path_note": "sccd_ccd() from pageable host matrices, upload and packing inside the call (best of 5; the reference's ccd() uploads inside the call too, ccd.cu:103-106); one rank only",
             "max_iter": args.max_iter,
             "broad_phase": broad,
             "rank_max": rank_max,
@@ -334,6 +358,67 @@ def main():
     if rank == 0:  # the ONE JSON line is the last thing on stdout (RCCL may print a banner at init / teardown)
         sys.stdout.flush()
         print(json.dumps(result), flush=True)
+
+
+def bench_jitter(args, ctx, sccd, torch, mesh, tV0, tV1, params, wl, world):
+    """A step that looks like a simulation (the reference's caller moves the mesh between ccd() calls,
+    cuda/ipc_ccd_strategy.cu:97-152): before every step the end positions are replaced by one of eight device-resident
+    variants V1 + A x noise (sccd_mesh_update_vertices, INSIDE the timed region: a caller pays it), so the entry counts, the key
+    width and the pair counts change from step to step and the speculative build's guesses (api.hip bp_build) can miss."""
+    n_var = 8
+    g = torch.Generator(device=tV1.device).manual_seed(12345)
+    variants = [tV1 + args.jitter * (torch.rand(tV1.shape, generator=g, dtype=tV1.dtype, device=tV1.device) * 2.0 - 1.0) for _ in range(n_var)]
+    torch.cuda.synchronize()
+
+    def step(k):
+        mesh.update_vertices(tV0.data_ptr(), variants[k % n_var].data_ptr(), on_device=True)
+        return sccd.ccd_mesh(mesh, want_stats=True, **params)
+
+    for k in range(max(args.warmup, n_var)):
+        step(k)
+    # the update alone (pack kernel + the synchronisation that releases the caller's buffers)
+    ctx.synchronize()
+    tu = time.perf_counter()
+    for k in range(20):
+        mesh.update_vertices(tV0.data_ptr(), variants[k % n_var].data_ptr(), on_device=True)
+    ctx.synchronize()
+    update_ms = (time.perf_counter() - tu) / 20 * 1e3
+    step(0)
+    ctx.set_option(sccd.OPT_SPEC_HITS, 0)
+    steps = max(args.steps, 200)
+    times, missed, tois, queries = [], [], [], 0
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        m0 = ctx.get_option(sccd.OPT_SPEC_MISSES)
+        ts = time.perf_counter()
+        toi, st = step(k + 1)
+        times.append((time.perf_counter() - ts) * 1e3)
+        missed.append(ctx.get_option(sccd.OPT_SPEC_MISSES) - m0)
+        tois.append(toi)
+        queries += st["n_vf_pairs"] + st["n_ee_pairs"]
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    hits, misses = ctx.get_option(sccd.OPT_SPEC_HITS), ctx.get_option(sccd.OPT_SPEC_MISSES)
+    ts_sorted = sorted(times)
+    hit_t = [t for t, m in zip(times, missed) if m == 0]
+    miss_t = [t for t, m in zip(times, missed) if m > 0]
+    med = lambda v: (sorted(v)[len(v) // 2] if v else None)  # noqa: E731
+    return {
+        "metric": "CCD queries/sec (broad+narrow), moving mesh", "value": queries / dt, "unit": "queries/s", "n_gpus": world,
+        "steps": steps, "warmup": max(args.warmup, n_var), "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": dict(wl, jitter=args.jitter, variants=n_var, arith=["strict", "fma"][args.arith],
+                       note="end positions + jitter x U(-1, 1)^3 per vertex, eight variants in turn; the vertex update is inside the timed region"),
+        "p50_ms": round(ts_sorted[len(ts_sorted) // 2], 4), "p99_ms": round(ts_sorted[min(len(ts_sorted) - 1, int(len(ts_sorted) * 0.99))], 4),
+        "min_ms": round(ts_sorted[0], 4), "max_ms": round(ts_sorted[-1], 4),
+        "update_vertices_ms": round(update_ms, 4),
+        "spec_builds": hits + misses, "spec_hits": hits, "spec_misses": misses,
+        "spec_hit_rate": round(hits / max(1, hits + misses), 4),
+        "steps_with_a_miss": len(miss_t), "median_ms_hit": med(hit_t), "median_ms_miss": med(miss_t),
+        "miss_over_hit": (round(med(miss_t) / med(hit_t), 3) if miss_t and hit_t else None),
+        "toi_min": min(tois), "toi_max": max(tois), "queries_per_step": queries / steps,
+    }
 
 
 def bench_boxes(args, ctx, sccd, scenes, torch):

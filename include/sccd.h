@@ -66,13 +66,16 @@ const char* sccd_version(void);
 /* hipStream_t to launch on (e.g. torch's current stream); NULL = the context's own stream. */
 int sccd_set_stream(sccd_ctx* ctx, void* hip_stream);
 int sccd_synchronize(sccd_ctx* ctx);
+/* the hipStream_t the context launches on (its own, or the one handed to sccd_set_stream) */
+void* sccd_get_stream(const sccd_ctx* ctx);
 /* Self-test of the hand-written memory idioms of the narrow-phase kernel (no reference counterpart): n_waves
  * wavefronts each gather n_active (0..64) 48-byte vertex records into LDS by LDS-direct loads with a deliberately
  * late wait while other LDS traffic runs.  *n_bad = number of LDS / memory words that differ from the expected layout (0 = pass). */
 int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* n_bad);
 
 /* options (sccd_set_option) */
-#define SCCD_OPT_ARITH 1            /* 0 strict (default): *, +/- rounded separately; 1: a*b+c fused (nvcc -fmad form) */
+#define SCCD_OPT_ARITH 1            /* 1 (default since 0.2): a*b+c of root_finder.cu:137-155 fused -- the reference's CUDA build is
+                                       compiled with --use_fast_math (CMakeLists.txt:219-225), i.e. -fmad=true; 0 strict: *, +/- rounded separately */
 #define SCCD_OPT_NARROW_ALGO 2      /* 0 per-wave work queues (default); 1 level-synchronous BFS (root_finder.cu:431-447) */
 #define SCCD_OPT_SWEEP_ALGO 3       /* 0 = 2 filter/queue/confirm STQ (default); 1 plain sweep-and-prune (sweep.cu:48-99); 3 direct exact sweep */
 #define SCCD_OPT_SORT_AXIS 4        /* 0/1/2 = x/y/z (reference device path: x, aabb.cu:85-86); -1 = arg-max variance   */
@@ -88,11 +91,14 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        level-synchronous kernels (bit-equal to the oracle's float twin on the GPU, tests/test_gpu_parity.py) */
 #define SCCD_OPT_PASSES_APART 13      /* ccd(): 1 = the vertex-face and the edge-edge pass one after the other on one stream (what
                                        * SCCD_OVERLAP=0 does for the whole process): measurements of the passes' own durations */
-#define SCCD_OPT_LIMIT_LEVEL_ORDER 12 /* check limits (max_iter >= 0, root_finder.cu:287-305): 0 (default) the fast kernel runs
+/* id 12 is RETIRED (it was SCCD_OPT_MAX_ITER_FAST in 0.1 with the opposite sense: setting it now fails with SCCD_E_INVALID) */
+#define SCCD_OPT_LIMIT_LEVEL_ORDER 14 /* check limits (max_iter >= 0, root_finder.cu:287-305): 0 (default) the fast kernel runs
                                        * without the limit and the library proves that the limit would not have changed the
                                        * answer (one query redone in the reference's level order on the host), falling back to the
                                        * level-synchronous kernels where the proof fails; 1: level-synchronous kernels always
                                        * (cross-check).  Either way the result is that of the reference's level order. */
+#define SCCD_OPT_SPEC_HITS 15   /* read: speculative builds (sort, records and sweep enqueued for the previous build's entry counts) whose */
+#define SCCD_OPT_SPEC_MISSES 16 /* guess held / broke and were redone, since the context was made; setting either resets both counters */
 int sccd_set_option(sccd_ctx* ctx, int option, int64_t value);
 int64_t sccd_get_option(const sccd_ctx* ctx, int option);
 
@@ -211,11 +217,19 @@ int sccd_ccd_collisions(sccd_ctx* ctx, const double* V0, const double* V1, int n
 /* Same on a device-resident mesh; stats may be NULL.  This is what bench.py times. */
 int sccd_ccd_mesh(sccd_ctx* ctx, const sccd_mesh* mesh, double min_distance, int max_iterations,
                   double tolerance, int allow_zero_toi, double* toi, sccd_stats* stats);
-/* The two halves of ccd() for multi-GPU runs (one process per GPU): every rank builds and sorts
- * all boxes (prepare), sweeps only its SCCD_OPT_SHARD_RANK/COUNT share of the candidates and
- * runs the narrow phase on the pairs it found (pass).  The caller min-reduces *toi over the
- * ranks (RCCL all-reduce) after the VF pass and after the EE pass -- the only exchange step,
- * mirroring how ccd.cu:125-143 threads toi from the VF pass into the EE pass. */
+/* The same step with its result ALSO left in device memory: *d_toi (8 bytes of device memory, a double) receives the TOI by a
+ * copy enqueued on the context's stream (sccd_get_stream), so that a multi-GPU caller can all-reduce(min) that word in place,
+ * stream-ordered behind the step, without the host waiting for the collective (bench.py, sccd/dist.py allreduce_min_device).
+ * toi (host) may be NULL.  No reference counterpart: the reference has no working multi-device path
+ * (src/scalable_ccd/cuda/broad_phase/CMakeLists.txt:21 leaves _multigpu out of the build). */
+int sccd_ccd_mesh_dev(sccd_ctx* ctx, const sccd_mesh* mesh, double min_distance, int max_iterations,
+                      double tolerance, int allow_zero_toi, double* d_toi, double* toi, sccd_stats* stats);
+/* The two halves of ccd() for multi-GPU runs (one process per GPU).  A rank (SCCD_OPT_SHARD_RANK / SCCD_OPT_SHARD_COUNT) owns a
+ * contiguous window of grid cells cut ON THE DEVICE from a sampled cell histogram; prepare builds the vertex boxes only (the
+ * edge and face boxes of a sharded call are computed inside the fill, and stored only where they fall into the rank's
+ * window); pass builds, sorts and sweeps the window and runs the narrow phase on the pairs it found.  A pair belongs to
+ * exactly one cell, hence to one rank: the only exchange is an all-reduce(min) of *toi (RCCL), once after the EE pass
+ * (optionally also after the VF pass: ccd.cu:125-143 threads toi from the VF pass into the EE pass, which only prunes). */
 int sccd_ccd_mesh_prepare(sccd_ctx* ctx, const sccd_mesh* mesh, double min_distance);
 int sccd_ccd_mesh_pass(sccd_ctx* ctx, const sccd_mesh* mesh, int is_vf, double min_distance,
                        int max_iterations, double tolerance, int allow_zero_toi, double* toi_inout,

@@ -14,6 +14,8 @@ _LIB = None
 
 ARITH_STRICT = 0
 ARITH_FMA = 1
+# the contract callers get when they name none: the reference's CUDA build fuses (CMakeLists.txt:219-225 --use_fast_math => -fmad=true)
+ARITH_DEFAULT = ARITH_FMA
 
 AABB_DTYPE = np.dtype(
     [("min", "<f8", (3,)), ("max", "<f8", (3,)), ("vertex_ids", "<i4", (3,)), ("element_id", "<i4")],
@@ -135,7 +137,7 @@ def brute_force(boxes, boxes_b=None):
 
 
 def narrow_phase(V0, V1, E, F, pairs, is_vf, ms=0.0, max_iter=-1, tol=1e-6, allow_zero_toi=True,
-                 arith=ARITH_STRICT, toi=1.0, per_query=False, scalar="f64"):
+                 arith=ARITH_DEFAULT, toi=1.0, per_query=False, scalar="f64"):
     """Level-synchronous restatement.  Returns (toi, per_query_toi|None, stats dict)."""
     L = lib()
     c_real, np_real, sfx = _rty(scalar)
@@ -155,7 +157,7 @@ def narrow_phase(V0, V1, E, F, pairs, is_vf, ms=0.0, max_iter=-1, tol=1e-6, allo
 
 
 def narrow_phase_mt(V0, V1, E, F, pairs, is_vf, ms=0.0, max_iter=-1, tol=1e-6, allow_zero_toi=True,
-                    arith=ARITH_STRICT, toi=1.0, nthreads=1, want_checks=False, scalar="f64"):
+                    arith=ARITH_DEFAULT, toi=1.0, nthreads=1, want_checks=False, scalar="f64"):
     L = lib()
     c_real, _, sfx = _rty(scalar)
     V0c, V1c, Ec, Fc = _rcm(V0, scalar), _rcm(V1, scalar), _i32cm(E), _i32cm(F)
@@ -170,7 +172,7 @@ def narrow_phase_mt(V0, V1, E, F, pairs, is_vf, ms=0.0, max_iter=-1, tol=1e-6, a
     return t.value, chk
 
 
-def ccd(V0, V1, E, F, ms=0.0, max_iter=-1, tol=1e-6, allow_zero_toi=True, arith=ARITH_STRICT, nthreads=1, scalar="f64"):
+def ccd(V0, V1, E, F, ms=0.0, max_iter=-1, tol=1e-6, allow_zero_toi=True, arith=ARITH_DEFAULT, nthreads=1, scalar="f64"):
     """Restatement of scalable_ccd::cuda::ccd (ccd.cu:80-146).  Returns (toi, n_vf, n_ee)."""
     L = lib()
     c_real, _, sfx = _rty(scalar)
@@ -187,7 +189,7 @@ def ccd(V0, V1, E, F, ms=0.0, max_iter=-1, tol=1e-6, allow_zero_toi=True, arith=
     return t.value, nvf.value, nee.value
 
 
-def ipc_ccd_strategy(V0, V1, E, F, ms=0.0, max_iter=-1, tol=1e-6, arith=ARITH_STRICT, want_branches=False):
+def ipc_ccd_strategy(V0, V1, E, F, ms=0.0, max_iter=-1, tol=1e-6, arith=ARITH_DEFAULT, want_branches=False):
     """Restatement of scalable_ccd::cuda::ipc_ccd_strategy (ipc_ccd_strategy.cu:12-152), one chunk per pass
     (the reference's `while (!broad_phase.is_complete())` runs once when the overlaps fit its buffer).
     Returns earliest_toi (and, on request, which passes took the conservative re-run branch :72-91)."""
@@ -215,7 +217,7 @@ def query_constants(v24, is_vf, use_ms, tol):
     return t3, e3
 
 
-def inclusion(v24, dom6, err3, ms, is_vf, arith=ARITH_STRICT):
+def inclusion(v24, dom6, err3, ms, is_vf, arith=ARITH_DEFAULT):
     L = lib()
     v = np.ascontiguousarray(v24, dtype=np.float64).reshape(24)
     d = np.ascontiguousarray(dom6, dtype=np.float64).reshape(6)

@@ -146,7 +146,7 @@ static void merge_side_profile(sccd_ctx* c)
 
 extern "C" {
 
-const char* sccd_version(void) { return "sccd-hip 0.1 (gfx950)"; }
+const char* sccd_version(void) { return "sccd-hip 0.2 (gfx950)"; } // 0.2: default contract fused (SCCD_OPT_ARITH = 1), option id 12 retired
 
 int sccd_create(int device, sccd_ctx** out)
 {
@@ -218,6 +218,8 @@ int sccd_set_stream(sccd_ctx* c, void* s)
     });
 }
 
+void* sccd_get_stream(const sccd_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
 int sccd_synchronize(sccd_ctx* c)
 {
     if (!c) return SCCD_E_INVALID;
@@ -250,6 +252,12 @@ int sccd_set_option(sccd_ctx* c, int opt, int64_t v)
     case SCCD_OPT_SCALAR: c->scalar_f32 = v ? 1 : 0; break;
     case SCCD_OPT_LIMIT_LEVEL_ORDER: c->limit_level_order = v ? 1 : 0; break;
     case SCCD_OPT_PASSES_APART: c->passes_apart = v ? 1 : 0; break;
+    case SCCD_OPT_SPEC_HITS:
+    case SCCD_OPT_SPEC_MISSES: // (counters: any value resets both, here and on the helper context)
+        c->spec_hits = c->spec_misses = 0;
+        if (c->side) c->side->spec_hits = c->side->spec_misses = 0;
+        break;
+    case 12: c->err = "option 12 is retired (SCCD_OPT_MAX_ITER_FAST of 0.1): see SCCD_OPT_LIMIT_LEVEL_ORDER"; return SCCD_E_INVALID;
     default: c->err = "unknown option"; return SCCD_E_INVALID;
     }
     return SCCD_OK;
@@ -272,6 +280,8 @@ int64_t sccd_get_option(const sccd_ctx* c, int opt)
     case SCCD_OPT_SCALAR: return c->scalar_f32;
     case SCCD_OPT_LIMIT_LEVEL_ORDER: return c->limit_level_order;
     case SCCD_OPT_PASSES_APART: return c->passes_apart;
+    case SCCD_OPT_SPEC_HITS: return c->spec_hits + (c->side ? c->side->spec_hits : 0);
+    case SCCD_OPT_SPEC_MISSES: return c->spec_misses + (c->side ? c->side->spec_misses : 0);
     default: return 0;
     }
 }
@@ -1185,6 +1195,7 @@ static bool speculation_settle(sccd_broad_phase* bp, const GridReadBack& built, 
                 ? !(hwin.total_est > (unsigned long long)std::max<int64_t>(3 * n_total, n_total + 4096)) && hwin.n_cells >= 4 * bp->ctx->shard_count
                 : !over_budget(ta, bp->A->n) && !(two && over_budget(tb, bp->B->n)));
     bp->speculative = false;
+    (ok ? bp->ctx->spec_hits : bp->ctx->spec_misses) += 1;
     if (!ok) {
         bp->guess.valid = false;
         return false;
@@ -1784,6 +1795,23 @@ extern "C" int sccd_ccd_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max
     });
 }
 
+constexpr size_t TOI_OUT_MIRROR = 11280; // the source of sccd_ccd_mesh_dev's 8-byte upload in the pinned mirror (common.hpp: h_scalars)
+extern "C" int sccd_ccd_mesh_dev(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter, double tol, int allow_zero_toi,
+                                 double* d_toi, double* toi, sccd_stats* stats)
+{
+    if (!c || !m || !d_toi) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(m->ctx == c, "ccd: mesh belongs to another context");
+        double t = toi ? *toi : 1.0;
+        ccd_on_mesh(c, m, ms, max_iter, tol, allow_zero_toi, &t, stats);
+        // (the slot is rewritten by the next call's end at the earliest: that call has synchronised with this stream by then)
+        double* const slot = reinterpret_cast<double*>(c->h_scalars.as<char>() + TOI_OUT_MIRROR);
+        *slot = t;
+        SCCD_HIP(hipMemcpyAsync(d_toi, slot, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (toi) *toi = t;
+    });
+}
+
 extern "C" int sccd_ccd_mesh_prepare(sccd_ctx* c, const sccd_mesh* m, double ms)
 {
     if (!c || !m) return SCCD_E_INVALID;
@@ -1822,8 +1850,10 @@ extern "C" int sccd_ccd(sccd_ctx* c, const double* V0, const double* V1, int nV,
     sccd_mesh* m = nullptr;
     int rc = guarded(c, [&] { m = scratch_mesh_from_host(c, V0, V1, nV, E, nE, F, nF, /*defer_verdict=*/true); });
     if (rc != SCCD_OK) return rc;
-    rc = sccd_ccd_mesh(c, m, ms, max_iter, tol, allow_zero_toi, toi, nullptr);
+    double t = *toi; // (the step runs on clamped indices until the verdict is in: its result is discarded with a bad mesh)
+    rc = sccd_ccd_mesh(c, m, ms, max_iter, tol, allow_zero_toi, &t, nullptr);
     const int rc_mesh = guarded(c, [&] { mesh_deferred_verdict(c); }); // (an index out of range outranks whatever the step made of it)
+    if (rc_mesh == SCCD_OK && rc == SCCD_OK) *toi = t;
     return rc_mesh != SCCD_OK ? rc_mesh : rc;
 }
 

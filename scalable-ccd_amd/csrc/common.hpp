@@ -93,7 +93,8 @@ struct sccd_ctx {
     std::string err;
 
     // options (sccd.h SCCD_OPT_*)
-    int arith = 0;
+    int64_t spec_hits = 0, spec_misses = 0; // speculative builds whose guess held / broke (api.hip speculation_settle; SCCD_OPT_SPEC_*)
+    int arith = 1; // fused multiply-adds where nvcc -fmad=true (the reference builds with --use_fast_math, CMakeLists.txt:219-225) fuses; 0: strict
     int narrow_algo = 0;
     int sweep_algo = 0;
     int sort_axis = 0;

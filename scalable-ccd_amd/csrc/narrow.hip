@@ -381,6 +381,7 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
 {
     // toi is in/out and must be >= 0 (narrow_phase.cu:126)
     SCCD_REQUIRE(*h_toi_inout >= 0, "narrow_phase: toi must be >= 0");
+    c->np_limit_fast = false; // (context-sticky between begin and end: a begin whose end never came must not leave it set)
     // pinned mirror: [8 KB, 12 KB) the counters handed to the caller, [12 KB, 16 KB) the upload source
     if (!(c->np_uploaded && std::memcmp(&c->np_uploaded_toi, h_toi_inout, 8) == 0)) narrow_counters_upload(c, d_cnt, *h_toi_inout);
     c->np_uploaded = false;
@@ -431,9 +432,9 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
                 c->np_scratch3_ovf.ensure(sizeof(int) * 4 * (size_t)cap + 256);
                 NarrowParams pn = p;
                 pn.max_iter = -2;
-                c->np_limit_fast = true;
                 c->np_toi_init = *h_toi_inout;
                 run_walk(c, pn, d_cnt, n, nullptr, c->np_scratch3_ovf.as<int>(), cap);
+                c->np_limit_fast = true; // (only once the launch is enqueued)
             } else if (d_per_query_toi) { // (bookkeeping kernels: they can list queries beyond level 31 themselves)
                 const unsigned cap = (unsigned)std::min<long long>(n, 1 << 20);
                 c->np_scratch3_ovf.ensure(sizeof(int) * (size_t)cap);

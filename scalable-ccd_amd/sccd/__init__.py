@@ -34,11 +34,14 @@ assert AABB_DTYPE.itemsize == 64 and COLLISION_DTYPE.itemsize == 16
 
 # sccd.h option ids
 OPT_ARITH, OPT_NARROW_ALGO, OPT_SWEEP_ALGO, OPT_SORT_AXIS = 1, 2, 3, 4
+ARITH_STRICT, ARITH_FMA = 0, 1
+ARITH_DEFAULT = ARITH_FMA  # the library's default contract (include/sccd.h SCCD_OPT_ARITH): the reference's nvcc build fuses
 OPT_SHARD_RANK, OPT_SHARD_COUNT, OPT_OVERLAP_CAPACITY, OPT_PROFILE, OPT_MAX_OVERLAP_CUTOFF = 5, 6, 7, 8, 9
 OPT_MEMORY_LIMIT_MB = 10
 OPT_SCALAR = 11  # 1: the reference's float build (SCALABLE_CCD_USE_DOUBLE=OFF)
 OPT_PASSES_APART = 13  # 1: ccd() runs its two passes one after the other (measurements)
-OPT_LIMIT_LEVEL_ORDER = 12  # 1: check limits always on the level-synchronous kernels; default: fast kernel + certificate (same result)
+OPT_SPEC_HITS, OPT_SPEC_MISSES = 15, 16  # read-only counters of the speculative build (set: reset)
+OPT_LIMIT_LEVEL_ORDER = 14  # 1: check limits always on the level-synchronous kernels; default: fast kernel + certificate (same result)
 PROF_NAMES = ["boxes", "sort", "ranges", "sweep", "narrow_vf", "narrow_ee"]
 
 # every symbol include/sccd.h declares (tests check that the library exports all of them)
@@ -53,6 +56,7 @@ ABI_SYMBOLS = [
     "sccd_ccd_mesh", "sccd_ccd_mesh_prepare", "sccd_ccd_mesh_pass", "sccd_ipc_ccd_strategy", "sccd_get_profile", "sccd_reset_profile", "sccd_sort_pairs_u32",
     "sccd_shard_bounds", "sccd_boxes_variance_axis", "sccd_selftest_lds_gather",
     "sccd_dev_alloc", "sccd_dev_free", "sccd_dev_upload", "sccd_dev_download", "sccd_dev_copy", "sccd_ccd_collisions",
+    "sccd_ccd_mesh_dev", "sccd_get_stream",
 ]
 
 
@@ -154,6 +158,12 @@ class Context:
 
     def set_stream(self, hip_stream):
         self._check(lib().sccd_set_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else 0)))
+
+    def stream_ptr(self):
+        """The hipStream_t the context launches on, as an integer (torch.cuda.ExternalStream(ptr) wraps it)."""
+        f = lib().sccd_get_stream
+        f.restype = C.c_void_p
+        return int(f(self._h) or 0)
 
     def synchronize(self):
         self._check(lib().sccd_synchronize(self._h))
@@ -499,6 +509,18 @@ def ccd_mesh(mesh, min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow_ze
     mesh.ctx._check(lib().sccd_ccd_mesh(
         mesh.ctx._h, mesh._h, C.c_double(min_distance), C.c_int(max_iterations), C.c_double(tolerance),
         C.c_int(int(allow_zero_toi)), C.byref(t), C.byref(st) if want_stats else None))
+    return (t.value, st.as_dict()) if want_stats else t.value
+
+
+def ccd_mesh_dev(mesh, d_toi, min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow_zero_toi=True, want_stats=False):
+    """ccd_mesh() whose result is ALSO left in device memory: `d_toi` is the address of a device double (e.g. a persistent
+    torch tensor's data_ptr()) that receives the TOI by a copy on the context's stream -- what a multi-GPU caller all-reduces in
+    place (sccd.dist.allreduce_min_device).  -> toi or (toi, stats dict), like ccd_mesh()."""
+    t = C.c_double(1.0)
+    st = Stats()
+    mesh.ctx._check(lib().sccd_ccd_mesh_dev(
+        mesh.ctx._h, mesh._h, C.c_double(min_distance), C.c_int(max_iterations), C.c_double(tolerance),
+        C.c_int(int(allow_zero_toi)), C.c_void_p(int(d_toi)), C.byref(t), C.byref(st) if want_stats else None))
     return (t.value, st.as_dict()) if want_stats else t.value
 
 

@@ -45,6 +45,43 @@ def allreduce_min(value, group=None, device=None):
     return float(t.item())
 
 
+class DeviceMin:
+    """all-reduce(min) of a step's TOI WITHOUT a host round trip: the TOI sits in a persistent device tensor (written by
+    sccd.ccd_mesh_dev on the context's stream), the collective is enqueued stream-ordered behind the step (an event recorded on
+    the context's stream, torch's current stream waits for it), reduces the tensor in place, and nobody calls .item() until the
+    caller wants the number (value()).  Round 3 built a tensor from a host float and read the result back on every step."""
+
+    def __init__(self, ctx, device, group=None):
+        import torch
+
+        self.torch = torch
+        self.group = group
+        self.word = torch.ones(1, dtype=torch.float64, device=device)
+        self.ext = torch.cuda.ExternalStream(ctx.stream_ptr(), device=device)
+        self.event = torch.cuda.Event()
+        self.done = torch.cuda.Event()
+
+    def ptr(self):
+        return self.word.data_ptr()
+
+    def reduce(self):
+        import torch.distributed as dist
+
+        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return
+        self.event.record(self.ext)
+        self.torch.cuda.current_stream().wait_event(self.event)
+        dist.all_reduce(self.word, op=dist.ReduceOp.MIN, group=self.group)  # asynchronous w.r.t. the host
+        # the next step's result must not land in the word before the collective has read it: the context's stream waits
+        self.done.record()
+        self.ext.wait_event(self.done)
+
+    def value(self):
+        self.event.record(self.ext)
+        self.torch.cuda.current_stream().wait_event(self.event)
+        return float(self.word.item())
+
+
 def ccd_sharded(run_pass, rank, world, group=None, device=None, prepare=None, reduce_between_passes=False):
     """ccd() across `world` ranks.
 

@@ -264,7 +264,7 @@ int main()
     const Scalar toi = ccd(vertices_t0, vertices_t1, edges, faces, min_distance, max_iterations, tolerance, allow_zero_toi);
     double want_toi = 1;
     orc_ccd(V0.data(), V1.data(), nV, E.data(), nE, F.data(), nF, min_distance, max_iterations, tolerance, 1,
-            ORC_ARITH_STRICT, 4, &want_toi, nullptr, nullptr);
+            ORC_ARITH_FMA, 4, &want_toi, nullptr, nullptr);
     CHECK(toi == want_toi);
     CHECK(toi < 1 && toi > 0);
 

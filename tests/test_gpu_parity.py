@@ -392,7 +392,7 @@ def test_toi_matches_oracle(sccd, ctx, orc, name, arith, algo):
         got_vf = sccd.narrow_phase(mesh, vf, True)
         got_ee = sccd.narrow_phase(mesh, ee, False, toi=got_vf)
     finally:
-        ctx.set_option(sccd.OPT_ARITH, 0)
+        ctx.set_option(sccd.OPT_ARITH, sccd.ARITH_DEFAULT)
         ctx.set_option(sccd.OPT_NARROW_ALGO, 0)
     assert abs(got_vf - want_vf) <= TOI_TOL and abs(got_ee - want_ee) <= TOI_TOL
     assert got_vf == want_vf and got_ee == want_ee  # bit-equal under the same arithmetic contract
@@ -593,7 +593,7 @@ def test_ccd_matches_golden(sccd, ctx, name, arith):
         mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
         toi2, st = sccd.ccd_mesh(mesh, ms, want_stats=True)
     finally:
-        ctx.set_option(sccd.OPT_ARITH, 0)
+        ctx.set_option(sccd.OPT_ARITH, sccd.ARITH_DEFAULT)
     want = float.fromhex(G["toi_fma" if arith else "toi_strict"])
     assert toi == want and toi2 == want
     assert st["n_vf_pairs"] == G["n_vf"] and st["n_ee_pairs"] == G["n_ee"]
@@ -614,7 +614,7 @@ def test_golden_case_that_tells_the_arithmetic_contracts_apart(sccd, ctx, arith)
         ctx.set_option(sccd.OPT_NARROW_ALGO, 1)  # ... and the level-order kernels
         toi_level = sccd.ccd(V0, V1, E, F, ms, -1, 1e-6, True, ctx=ctx)
     finally:
-        ctx.set_option(sccd.OPT_ARITH, 0)
+        ctx.set_option(sccd.OPT_ARITH, sccd.ARITH_DEFAULT)
         ctx.set_option(sccd.OPT_NARROW_ALGO, 0)
     want = float.fromhex(G["toi_fma" if arith else "toi_strict"])
     assert toi == want and toi_level == want
@@ -648,7 +648,7 @@ def test_randomised_scenes_against_the_oracle(sccd, ctx, orc, seed):
         assert np.array_equal(_sorted(bp.detect_overlaps()), want_ee)
         assert sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero) == want
     finally:
-        ctx.set_option(sccd.OPT_ARITH, 0)
+        ctx.set_option(sccd.OPT_ARITH, sccd.ARITH_DEFAULT)
 
 
 def test_odd_meshes(sccd, ctx, orc):
@@ -819,7 +819,7 @@ def test_check_limits_where_the_certificate_fails_fall_back_to_level_order(sccd,
                 seen.add(want)
             assert len(seen) >= 2, sel
     finally:
-        ctx.set_option(sccd.OPT_ARITH, 0)
+        ctx.set_option(sccd.OPT_ARITH, sccd.ARITH_DEFAULT)
         ctx.set_option(sccd.OPT_LIMIT_LEVEL_ORDER, 0)
 
 
@@ -851,7 +851,7 @@ def test_check_limits_follow_the_reference_level_order(sccd, ctx, orc, arith):
             assert np.array_equal(col["toi"], want_pq[hit]), k
         assert len(seen) >= 2  # different limits, different answers: the test can tell them apart
     finally:
-        ctx.set_option(sccd.OPT_ARITH, 0)
+        ctx.set_option(sccd.OPT_ARITH, sccd.ARITH_DEFAULT)
 
 
 def test_sort_is_a_stable_permutation(sccd, ctx):
@@ -960,7 +960,7 @@ def test_full_size_ccd_matches_golden_toi(sccd, ctx, cloth1m, arith):
         # idempotence: a second call on the same resident mesh returns the same bits
         toi2 = sccd.ccd_mesh(mesh)
     finally:
-        ctx.set_option(sccd.OPT_ARITH, 0)
+        ctx.set_option(sccd.OPT_ARITH, sccd.ARITH_DEFAULT)
     assert toi == toi2 == float.fromhex(G["toi_fma" if arith else "toi_strict"])
     assert st["n_vf_pairs"] == G["n_vf"] and st["n_ee_pairs"] == G["n_ee"]
     # the level-synchronous kernel (reference scheme) agrees on the VF pass at full size
@@ -971,7 +971,7 @@ def test_full_size_ccd_matches_golden_toi(sccd, ctx, cloth1m, arith):
         t_vf, _ = sccd.ccd_mesh_pass(mesh, True, 1.0)
     finally:
         ctx.set_option(sccd.OPT_NARROW_ALGO, 0)
-        ctx.set_option(sccd.OPT_ARITH, 0)
+        ctx.set_option(sccd.OPT_ARITH, sccd.ARITH_DEFAULT)
     assert t_vf == float.fromhex(G["toi_vf_fma" if arith else "toi_vf_strict"])
 
 
@@ -1120,7 +1120,7 @@ def test_float_build_matches_the_oracle_twin(sccd, ctx, orc, arith):
             assert toi == want_toi and toi == float(np.float32(toi))
         finally:
             ctx.set_option(sccd.OPT_SCALAR, 0)
-            ctx.set_option(sccd.OPT_ARITH, 0)
+            ctx.set_option(sccd.OPT_ARITH, sccd.ARITH_DEFAULT)
 
 
 @pytest.mark.parametrize("n_active", [64, 24, 1, 0])
@@ -1167,7 +1167,7 @@ def test_soak_seeds_that_once_failed(sccd, ctx, orc, seed):
         for _ in range(3):  # (the failure depended on timing)
             assert sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero) == want
     finally:
-        ctx.set_option(sccd.OPT_ARITH, 0)
+        ctx.set_option(sccd.OPT_ARITH, sccd.ARITH_DEFAULT)
         ctx.set_option(sccd.OPT_SWEEP_ALGO, 0)
 
 
@@ -1208,5 +1208,65 @@ def test_soak_scenes(sccd, ctx, orc, seed):
     finally:
         ctx.set_option(sccd.OPT_SHARD_COUNT, 1)
         ctx.set_option(sccd.OPT_SHARD_RANK, 0)
-        ctx.set_option(sccd.OPT_ARITH, 0)
+        ctx.set_option(sccd.OPT_ARITH, sccd.ARITH_DEFAULT)
         ctx.set_option(sccd.OPT_SWEEP_ALGO, 0)
+
+
+def test_option_defaults_and_the_retired_id(sccd):
+    """A fresh context computes in the reference's production contract (nvcc --use_fast_math => fused, CMakeLists.txt:219-225);
+    option id 12 (SCCD_OPT_MAX_ITER_FAST of 0.1, opposite sense) is refused instead of silently selecting the slow path."""
+    c = sccd.Context(0)
+    try:
+        assert c.get_option(sccd.OPT_ARITH) == sccd.ARITH_DEFAULT == sccd.ARITH_FMA
+        assert sccd.lib().sccd_set_option(c._h, 12, 1) != 0
+        assert c.get_option(sccd.OPT_LIMIT_LEVEL_ORDER) == 0
+        c.set_option(sccd.OPT_LIMIT_LEVEL_ORDER, 1)
+        assert c.get_option(sccd.OPT_LIMIT_LEVEL_ORDER) == 1
+    finally:
+        c.close()
+
+
+def test_ccd_with_many_bad_indices_fails_fast_and_leaves_toi_alone(sccd, ctx):
+    """sccd_ccd() from host matrices runs the step on clamped indices until the verdict is in (every bad element hangs on
+    vertex 0): the call must still come back quickly with the error, and *toi must not be written (sccd.h)."""
+    import ctypes as C
+    import time
+
+    V0, V1, E, F = _scene("cloth_ball_small")
+    badF = np.array(F, np.int32, copy=True)
+    badF[::3, 1] = len(V0) + 7  # a third of the faces
+    badE = np.array(E, np.int32, copy=True)
+    badE[::2, 0] = -5
+    V0c, V1c = np.asfortranarray(V0, dtype=np.float64), np.asfortranarray(V1, dtype=np.float64)
+    Ec, Fc = np.asfortranarray(badE, dtype=np.int32), np.asfortranarray(badF, dtype=np.int32)
+    t = C.c_double(0.75)
+    t0 = time.perf_counter()
+    rc = sccd.lib().sccd_ccd(ctx._h, V0c.ctypes.data_as(C.c_void_p), V1c.ctypes.data_as(C.c_void_p), C.c_int(len(V0)),
+                             Ec.ctypes.data_as(C.c_void_p), C.c_int(len(E)), Fc.ctypes.data_as(C.c_void_p), C.c_int(len(F)),
+                             C.c_double(0.0), C.c_int(-1), C.c_double(1e-6), C.c_int(1), C.c_int(0), C.byref(t))
+    dt = time.perf_counter() - t0
+    assert rc != 0 and t.value == 0.75
+    assert dt < 20.0, dt
+    assert sccd.ccd(V0, V1, E, F, ctx=ctx) == sccd.ccd(V0, V1, E, F, ctx=ctx)  # the context is usable afterwards
+
+
+def test_ccd_mesh_dev_leaves_the_toi_in_device_memory(sccd, ctx):
+    """sccd_ccd_mesh_dev: the step's TOI also lands in a caller-owned device word, by a copy on the context's stream (what a
+    multi-GPU caller all-reduces in place: sccd/dist.py DeviceMin)."""
+    import torch
+
+    V0, V1, E, F = _scene("cloth_ball_small")
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    word = torch.full((1,), 7.0, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    t, st = sccd.ccd_mesh_dev(mesh, word.data_ptr(), want_stats=True)
+    ctx.synchronize()
+    assert word.item() == t == sccd.ccd_mesh(mesh) and st["n_vf_pairs"] > 0
+    assert ctx.stream_ptr() != 0
+    from sccd import dist as sdist
+
+    dm = sdist.DeviceMin(ctx, torch.device("cuda", 0))  # (no process group: reduce() is a no-op, value() reads the word)
+    sccd.ccd_mesh_dev(mesh, dm.ptr())
+    dm.reduce()
+    assert dm.value() == t
+    mesh.close()

@@ -148,7 +148,7 @@ def main():
         finally:
             ctx.set_option(sccd.OPT_SHARD_COUNT, 1)
             ctx.set_option(sccd.OPT_SHARD_RANK, 0)
-            ctx.set_option(sccd.OPT_ARITH, 0)
+            ctx.set_option(sccd.OPT_ARITH, sccd.ARITH_DEFAULT)
             ctx.set_option(sccd.OPT_SWEEP_ALGO, 0)
             ctx.set_option(sccd.OPT_NARROW_ALGO, 0)
         if not ok:
