@@ -82,6 +82,10 @@ def parse():
     ap.add_argument("--jitter", type=float, default=0.0, help="cloth workloads: the mesh MOVES between steps (end positions + A x uniform noise, eight "
                     "device-resident variants in turn, sccd_mesh_update_vertices inside the timed region): speculative builds can miss; "
                     "reports spec_hit_rate, p50 / p99 ms per step and the cost of a missed guess.  0 (default): the frozen mesh of the headline")
+    ap.add_argument("--jitter-alternate", type=float, default=1.0, help="--jitter: every second variant's amplitude is scaled by this factor "
+                    "(e.g. 0.05: large and small motions alternate, the entry counts jump from step to step and the speculative guesses break)")
+    ap.add_argument("--jitter-fraction", type=float, default=1.0, help="--jitter: only this fraction of the vertices moves (a few large boxes "
+                    "among small ones change how many cells a box spans, i.e. the entry counts the speculative build guesses)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="cloth side of the CPU sample (0 = auto)")
     return ap.parse_args()
@@ -355,8 +359,14 @@ def main():
 
     if use_dist:
         dist.destroy_process_group()
-    if rank == 0:  # the ONE JSON line is the last thing on stdout (RCCL may print a banner at init / teardown)
+    if rank == 0:  # the ONE JSON line is the last thing on stdout (RCCL prints a banner through C stdio: flush that first)
         sys.stdout.flush()
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(result), flush=True)
 
 
@@ -367,7 +377,14 @@ def bench_jitter(args, ctx, sccd, torch, mesh, tV0, tV1, params, wl, world):
     width and the pair counts change from step to step and the speculative build's guesses (api.hip bp_build) can miss."""
     n_var = 8
     g = torch.Generator(device=tV1.device).manual_seed(12345)
-    variants = [tV1 + args.jitter * (torch.rand(tV1.shape, generator=g, dtype=tV1.dtype, device=tV1.device) * 2.0 - 1.0) for _ in range(n_var)]
+    amps = [args.jitter * (args.jitter_alternate if (k & 1) else 1.0) for k in range(n_var)]
+    def noise(k):
+        r = torch.rand(tV1.shape, generator=g, dtype=tV1.dtype, device=tV1.device) * 2.0 - 1.0
+        if args.jitter_fraction < 1.0:  # tV1 is [3][nV]: one mask per vertex
+            r = r * (torch.rand((1, tV1.shape[1]), generator=g, dtype=tV1.dtype, device=tV1.device) < args.jitter_fraction)
+        return amps[k] * r
+
+    variants = [tV1 + noise(k) for k in range(n_var)]
     torch.cuda.synchronize()
 
     def step(k):
@@ -408,7 +425,7 @@ def bench_jitter(args, ctx, sccd, torch, mesh, tV0, tV1, params, wl, world):
         "metric": "CCD queries/sec (broad+narrow), moving mesh", "value": queries / dt, "unit": "queries/s", "n_gpus": world,
         "steps": steps, "warmup": max(args.warmup, n_var), "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": dict(wl, jitter=args.jitter, variants=n_var, arith=["strict", "fma"][args.arith],
+        "config": dict(wl, jitter=args.jitter, jitter_alternate=args.jitter_alternate, jitter_fraction=args.jitter_fraction, variants=n_var, arith=["strict", "fma"][args.arith],
                        note="end positions + jitter x U(-1, 1)^3 per vertex, eight variants in turn; the vertex update is inside the timed region"),
         "p50_ms": round(ts_sorted[len(ts_sorted) // 2], 4), "p99_ms": round(ts_sorted[min(len(ts_sorted) - 1, int(len(ts_sorted) * 0.99))], 4),
         "min_ms": round(ts_sorted[0], 4), "max_ms": round(ts_sorted[-1], 4),

@@ -890,7 +890,10 @@ static void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes
         // lazy lists live on the device-window path only
         static const bool dw_env = !(std::getenv("SCCD_DEVICE_WINDOW") && std::atoi(std::getenv("SCCD_DEVICE_WINDOW")) == 0);
         const bool scan_env = std::getenv("SCCD_BUILD") && std::string(std::getenv("SCCD_BUILD")) == "scan";
-        if (!(c->shard_count > 1 && dw_env && !scan_env && c->sort_axis >= 0)) {
+        // (one GPU: the one-pass append build computes a lazy list's boxes in the fill just as well -- SCCD_LAZY_ONE)
+        static const bool lazy_one = std::getenv("SCCD_LAZY_ONE") && std::atoi(std::getenv("SCCD_LAZY_ONE")) != 0;
+        const bool merged_off = std::getenv("SCCD_MERGED_SORT") && std::atoi(std::getenv("SCCD_MERGED_SORT")) == 0;
+        if (!(((c->shard_count > 1 && dw_env) || (c->shard_count == 1 && lazy_one && !merged_off && c->max_overlap_cutoff == 0)) && !scan_env && c->sort_axis >= 0)) {
             materialise(c, A);
             materialise(c, B);
         }
@@ -1590,7 +1593,8 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
     }
     // (a rank of a multi-GPU job builds the edge and face boxes of its window of cells only: see boxes_from_mesh)
     static const bool lazy_env = !(std::getenv("SCCD_LAZY_BOXES") && std::atoi(std::getenv("SCCD_LAZY_BOXES")) == 0);
-    const bool lazy_ef = lazy_env && c->shard_count > 1 && c->sort_axis >= 0 && c->max_overlap_cutoff == 0;
+    static const bool lazy_one_env = std::getenv("SCCD_LAZY_ONE") && std::atoi(std::getenv("SCCD_LAZY_ONE")) != 0;
+    const bool lazy_ef = lazy_env && (c->shard_count > 1 || lazy_one_env) && c->sort_axis >= 0 && c->max_overlap_cutoff == 0;
     boxes_from_mesh(c, m, ms, pl, true, true, true, lazy_ef); // inflation radius = min_distance (ccd.cu:112)
     double toi = 1; // ccd.cu:125
     // The edge-edge lists do not depend on the vertex-face pass: a helper context (own stream, scratch, pinned mirror)

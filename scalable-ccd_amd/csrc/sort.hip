@@ -265,9 +265,15 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restri
     uint32_t* wk = s_keys + w * RS_WAVE_SPAN;
     uint32_t* wv = s_vals + w * RS_WAVE_SPAN;
 
-    if (threadIdx.x == 0) s_tk[0] = atomicAdd(ticket, 1u);
-    __syncthreads();
-    uint32_t t0 = s_tk[0];
+    // ticket == nullptr: a launch with a block per tile takes the tile from the block index -- no atomics at all on the one
+    // ticket word (a few hundred of them at the start of every pass of a broad-phase sort were 7 of its 27 us).  A tile only
+    // waits for LOWER tiles, and workgroups are handed to each XCD in increasing order: a lower tile is resident, or next in
+    // line on its XCD, whenever a higher one spins -- also with a second sort of another stream on the chip.
+    if (ticket) {
+        if (threadIdx.x == 0) s_tk[0] = atomicAdd(ticket, 1u);
+        __syncthreads();
+    }
+    uint32_t t0 = ticket ? s_tk[0] : blockIdx.x;
     TileRegs pre;
     if ((int)t0 < num_tiles) tile_load(pre, keys_in, vals_in, (long long)t0 * RS_TILE + (long long)w * RS_WAVE_SPAN, lane, n_load);
 
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restri
         // request the next ticket (a launch with a block per tile has none to give: the broad phase's size, where the 400
         // wasted atomics on the one ticket word were a third of the 7 us a pass spends queueing there)
         uint32_t t1_req = (uint32_t)num_tiles;
-        if (threadIdx.x == 0 && (int)gridDim.x < num_tiles) t1_req = atomicAdd(ticket, 1u);
+        if (ticket && threadIdx.x == 0 && (int)gridDim.x < num_tiles) t1_req = atomicAdd(ticket, 1u);
         wave_lds_fence();
         uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
         bool valid[RS_ITEMS];
@@ -521,9 +527,13 @@ bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
     hipLaunchKernelGGL(os_bases_k, dim3(4), dim3(1024), 0, c->stream, partial, hist_blocks, bases);
     for (int pass = 0; pass < passes; pass++) {
         static const int pass_blocks = std::getenv("SCCD_SORT_BLOCKS") ? std::atoi(std::getenv("SCCD_SORT_BLOCKS")) : 3;
-        hipLaunchKernelGGL(os_pass_k, dim3(std::min(num_tiles, c->num_cus * pass_blocks)), dim3(RS_THREADS), 0, c->stream, k_in,
+        static const bool force_tickets = std::getenv("SCCD_SORT_TICKETS") && std::atoi(std::getenv("SCCD_SORT_TICKETS")) != 0;
+        const int blocks = std::min(num_tiles, c->num_cus * pass_blocks);
+        // (a block per tile: tiles by block index, no ticket word -- os_pass_k)
+        uint32_t* const tk = (blocks == num_tiles && !force_tickets) ? nullptr : tickets + pass * 32;
+        hipLaunchKernelGGL(os_pass_k, dim3(blocks), dim3(RS_THREADS), 0, c->stream, k_in,
                            v_in, k_out, v_out, (long long)n, 8 * pass, num_tiles, bases + 256 * pass,
-                           status + (size_t)pass * num_tiles * 256, tickets + pass * 32, dbg, pass == 0 ? d_n_real : nullptr);
+                           status + (size_t)pass * num_tiles * 256, tk, dbg, pass == 0 ? d_n_real : nullptr);
         std::swap(k_in, k_out);
         std::swap(v_in, v_out);
     }
