@@ -7,7 +7,7 @@ OUT     := scalable-ccd_amd/sccd/libsccd_hip.so
 # only FMAs are explicit __builtin_fma calls (SCCD_OPT_ARITH = 1).
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
             -Wall -Wextra -Wno-unused-parameter -Wno-unused-function -Wno-missing-field-initializers
-SRCS    := $(CSRC)/api.hip $(CSRC)/boxes.hip $(CSRC)/scan.hip $(CSRC)/sort.hip $(CSRC)/sweep.hip $(CSRC)/narrow.hip
+SRCS    := $(CSRC)/api.hip $(CSRC)/build.hip $(CSRC)/drivers.hip $(CSRC)/boxes.hip $(CSRC)/scan.hip $(CSRC)/sort.hip $(CSRC)/sweep.hip $(CSRC)/narrow.hip
 OBJS    := $(SRCS:.hip=.o) $(CSRC)/ti_census.o
 CPPTEST := tests/cpp/test_ccd_api
 HDRS    := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inc) include/sccd.h

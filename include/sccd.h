@@ -97,6 +97,9 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        * answer (one query redone in the reference's level order on the host), falling back to the
                                        * level-synchronous kernels where the proof fails; 1: level-synchronous kernels always
                                        * (cross-check).  Either way the result is that of the reference's level order. */
+#define SCCD_OPT_CELL_FACTOR_MILLI 17 /* grid cell size in thousandths of the mean box extent per minor axis (0 = default: 4000; < 0: one cell).
+                                       * Any value is correct (grid.hpp); the SCCD_CELL_FACTOR environment variable of 0.1 is gone */
+#define SCCD_OPT_BUILD_SCAN 18        /* 1: entries by count -> device-wide scan -> fill, in box order (reproducible entry order; was SCCD_BUILD=scan) */
 #define SCCD_OPT_SPEC_HITS 15   /* read: speculative builds (sort, records and sweep enqueued for the previous build's entry counts) whose */
 #define SCCD_OPT_SPEC_MISSES 16 /* guess held / broke and were redone, since the context was made; setting either resets both counters */
 int sccd_set_option(sccd_ctx* ctx, int option, int64_t value);

@@ -1,0 +1,124 @@
+// api_internal.hpp -- what the three host files behind the C ABI share: api.hip (context, options, meshes, box lists),
+// build.hip (BroadPhase: cell grid, entry lists, sort, records, speculative build, sweep + overflow / cursor, sharding
+// windows) and drivers.hip (narrow_phase, ccd(), ccd() with collisions, ipc_ccd_strategy).  Host code only.
+#pragma once
+#include "internal.hpp"
+#include "grid.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <condition_variable>
+#include <exception>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------
+// error trampolines
+extern thread_local std::string g_create_error; // (api.hip)
+
+template <class Fn> int guarded(sccd_ctx* c, Fn&& fn)
+{
+    try {
+        if (c) SCCD_HIP(hipSetDevice(c->device));
+        fn();
+        return SCCD_OK;
+    } catch (const SccdError& e) {
+        (void)hipGetLastError(); // (sticky: a later launch check must not trip over this call's failure)
+        if (c) c->err = e.msg;
+        else g_create_error = e.msg;
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        if (c) c->err = "host allocation failed";
+        return SCCD_E_NOMEM;
+    } catch (const std::exception& e) {
+        if (c) c->err = e.what();
+        return SCCD_E_INVALID;
+    }
+}
+
+// One persistent helper thread per context: ccd() hands it the construction of the edge-edge lists.
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, busy = false, quit = false;
+    std::exception_ptr err;
+    void submit(std::function<void()> f)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (!th.joinable()) th = std::thread([this] { loop(); });
+        job = std::move(f);
+        has_job = busy = true;
+        err = nullptr;
+        cv.notify_all();
+    }
+    void wait() // rethrows what the job threw
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this] { return !busy; });
+        if (err) {
+            std::exception_ptr e = err;
+            err = nullptr;
+            std::rethrow_exception(e);
+        }
+    }
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [this] { return has_job || quit; });
+                if (quit) return;
+                f = std::move(job);
+                has_job = false;
+            }
+            std::exception_ptr e;
+            try {
+                f();
+            } catch (...) {
+                e = std::current_exception();
+            }
+            std::unique_lock<std::mutex> lk(m);
+            err = e;
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    ~Worker()
+    {
+        {
+            std::unique_lock<std::mutex> lk(m);
+            quit = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
+};
+
+// pipeline objects cached in the context so that repeated ccd() calls allocate nothing
+struct Pipeline {
+    sccd_boxes vb, eb, fb; // boxes in element order (raw)
+    sccd_broad_phase bp;
+    sccd_broad_phase bp_ee; // edge-edge lists of ccd(): belongs to the helper context c->side
+    Worker worker;
+};
+Pipeline* pipeline_of(sccd_ctx* c); // (api.hip)
+
+// api.hip
+void merge_side_profile(sccd_ctx* c);
+void copy_in(sccd_ctx* c, void* dst, const void* src, size_t bytes, int src_on_device);
+sccd_mesh* scratch_mesh_from_host(sccd_ctx* c, const double* V0, const double* V1, int nV, const int32_t* E, int nE, const int32_t* F,
+                                  int nF, bool defer_verdict = false);
+void mesh_deferred_verdict(sccd_ctx* c);
+void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline* pl, bool want_v, bool want_e, bool want_f, bool lazy_ef = false);
+void ensure_stats(sccd_ctx* c, const sccd_boxes* b);
+// build.hip
+void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes* B);
+void bp_detect_partial(sccd_broad_phase* bp, int phase = 0);

@@ -965,9 +965,7 @@ void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a,
                        const double* part_b, int n_part_b, int n_total, int axis, double cell_factor, int shrink,
                        GridParams* g, uint32_t* cursors, bool reserve_tag, uint32_t* zero_hist)
 {
-    // SCCD_MAX_CELLS_ENV: experiments with coarser grids (<= SCCD_MAX_CELLS)
-    const char* mc = std::getenv("SCCD_MAX_CELLS");
-    const int max_cells = mc ? std::max(1, std::min(SCCD_MAX_CELLS, std::atoi(mc))) : SCCD_DEFAULT_CELLS;
+    const int max_cells = SCCD_DEFAULT_CELLS;
     hipLaunchKernelGGL(grid_setup_k, dim3(1), dim3(SCCD_STATS_BLOCKS), 0, c->stream, st_a, part_a, n_part_a, st_b, part_b, n_part_b,
                        n_total, axis, cell_factor, shrink, g, cursors, max_cells, reserve_tag ? 1 : 0, zero_hist);
     SCCD_HIP(hipGetLastError());

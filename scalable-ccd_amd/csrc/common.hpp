@@ -85,6 +85,44 @@ struct PinnedBuf {
 };
 
 // ------------------------------------------------------------------------------------------
+// The laboratory switches that are left (tools/README.md), read ONCE, when the first context is made.  Everything else that
+// used to be an environment variable is either gone with the path it selected (SCCD_SORT=classic, SCCD_SWEEP_CHUNK,
+// SCCD_MERGED_SORT, SCCD_NP_PERM, ...) or an option of the context (SCCD_OPT_CELL_FACTOR_MILLI, SCCD_OPT_BUILD_SCAN).
+struct LabEnv {
+    int np_diag = 0, sweep_diag = 0;   // SCCD_NP_DIAG / SCCD_SWEEP_DIAG: counters and cycle stamps of the narrow / sweep kernels
+    bool speculate = true;             // SCCD_SPECULATE=0: every build waits for its entry counts (no speculative build)
+    bool overlap = true;               // SCCD_OVERLAP=0: no helper context (the edge-edge lists after the vertex-face pass)
+    bool presweep = true;              // SCCD_PRESWEEP=0: the edge-edge sweep not beside the vertex-face narrow phase
+    bool narrow_beside = true;         // SCCD_NARROW_BESIDE=0: the edge-edge narrow kernel after, not beside, the vertex-face one
+    bool sync_block = false;           // SCCD_SYNC=block: read-backs wait with hipStreamSynchronize instead of polling an event
+    bool sort_tickets = false;         // SCCD_SORT_TICKETS=1: sort tiles by atomic ticket even when every tile has its block
+    long long level_budget_mb = 0;     // SCCD_LEVEL_BUDGET_MB: budget per level buffer of the level-synchronous narrow phase
+    static int num(const char* name, int dflt)
+    {
+        const char* e = std::getenv(name);
+        return e ? std::atoi(e) : dflt;
+    }
+    LabEnv()
+    {
+        np_diag = num("SCCD_NP_DIAG", 0);
+        sweep_diag = num("SCCD_SWEEP_DIAG", 0);
+        speculate = num("SCCD_SPECULATE", 1) != 0;
+        overlap = num("SCCD_OVERLAP", 1) != 0;
+        presweep = num("SCCD_PRESWEEP", 1) != 0;
+        narrow_beside = num("SCCD_NARROW_BESIDE", 1) != 0;
+        sort_tickets = num("SCCD_SORT_TICKETS", 0) != 0;
+        level_budget_mb = num("SCCD_LEVEL_BUDGET_MB", 0);
+        const char* s = std::getenv("SCCD_SYNC");
+        sync_block = s && std::string(s) == "block";
+    }
+};
+inline const LabEnv& lab_env()
+{
+    static const LabEnv e;
+    return e;
+}
+
+// ------------------------------------------------------------------------------------------
 struct sccd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -106,6 +144,8 @@ struct sccd_ctx {
     int sweep_blocks_per_cu = 0; // 0 = the sweep kernel's own choice (a full CU); ccd()'s helper context sweeps with half
     int passes_apart = 0;      // SCCD_OPT_PASSES_APART
     int limit_level_order = 0; // SCCD_OPT_LIMIT_LEVEL_ORDER: 1 = every check limit on the level-synchronous kernels (cross-check)
+    int cell_factor_milli = 0; // SCCD_OPT_CELL_FACTOR_MILLI: grid cell size in thousandths of the mean box extent (0: the default, 4000; < 0: one cell)
+    int build_scan = 0;        // SCCD_OPT_BUILD_SCAN: 1 = count -> device-wide scan -> fill (entries in box order) instead of the one-pass append
     // narrow_counters_upload() already put {zeros, this TOI} into the narrow phase's counters (it rides ahead of
     // the sweep in ccd(), so that the narrow kernel can start right behind the sweep's read-back)
     bool np_uploaded = false;
@@ -202,8 +242,7 @@ struct ReadBack {
         // Poll an event instead of hipStreamSynchronize: the blocking wait puts the thread to sleep and the
         // wake-up alone costs tens of microseconds -- with six of these per ccd() step that is ~10 % of it.
         // SCCD_SYNC=block restores the blocking wait (e.g. when host cores are scarce).
-        static const bool block = std::getenv("SCCD_SYNC") && std::string(std::getenv("SCCD_SYNC")) == "block";
-        if (block) {
+        if (lab_env().sync_block) {
             SCCD_HIP(hipStreamSynchronize(c->stream));
         } else {
             if (!c->rb_event) SCCD_HIP(hipEventCreateWithFlags(&c->rb_event, hipEventDisableTiming));

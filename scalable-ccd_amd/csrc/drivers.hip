@@ -1,0 +1,542 @@
+// drivers.hip -- the C ABI of include/sccd.h, part 3: narrow_phase (narrow_phase.cuh:30-46), ccd() with and without the
+// collision list (ccd.cu:14-146), the two halves of a multi-GPU step, ipc_ccd_strategy (ipc_ccd_strategy.cu:12-152).
+#include "api_internal.hpp"
+
+// ------------------------------------------------------------------------------------------
+// narrow phase
+static NarrowCounters* narrow_counters(sccd_ctx* c)
+{
+    return reinterpret_cast<NarrowCounters*>(c->scalars.as<char>() + 2048);
+}
+
+struct NarrowResult {
+    unsigned long long n_checks;
+};
+
+static NarrowParams narrow_params(sccd_ctx* c, const sccd_mesh* m, const int2* d_pairs, int64_t n, int is_vf, int max_iter,
+                                  double tol, double ms, int allow_zero_toi)
+{
+    if (c->scalar_f32) { // the float build takes Scalar (= float) arguments (narrow_phase.cuh:30-46)
+        tol = (double)(float)tol;
+        ms = (double)(float)ms;
+    }
+    // Condition 1 (root_finder.cu:322) can only end a bisection for a positive finite tolerance; the reference
+    // asserts nothing and would bisect down to empty intervals (Condition 4) -- refused here instead
+    SCCD_REQUIRE(tol > 0 && std::isfinite(tol), "narrow_phase: tolerance must be positive and finite");
+    SCCD_REQUIRE(ms >= 0 && std::isfinite(ms), "narrow_phase: minimum separation must be >= 0 and finite");
+    NarrowParams p;
+    p.V = m->V.as<double>();
+    p.E = m->E.as<int2>();
+    p.F = m->F.as<int4>();
+    p.pairs = d_pairs;
+    p.n_pairs = n;
+    p.is_vf = is_vf;
+    p.max_iter = max_iter;
+    p.tol = tol;
+    p.ms = ms;
+    p.allow_zero_toi = allow_zero_toi;
+    p.arith = c->arith;
+    return p;
+}
+static NarrowResult narrow_result(sccd_ctx* c)
+{
+    NarrowCounters h;
+    std::memcpy(&h, c->h_scalars.as<char>() + 8192, sizeof h);
+    return NarrowResult { h.n_checks };
+}
+static NarrowResult run_narrow(sccd_ctx* c, const sccd_mesh* m, const int2* d_pairs, int64_t n, int is_vf, int max_iter,
+                               double tol, double ms, int allow_zero_toi, double* toi, double* d_per_query)
+{
+    const NarrowParams p = narrow_params(c, m, d_pairs, n, is_vf, max_iter, tol, ms, allow_zero_toi);
+    if (c->scalar_f32) *toi = (double)(float)*toi;
+    narrow_phase_run(c, p, narrow_counters(c), toi, d_per_query);
+    return narrow_result(c);
+}
+
+// copy_out_collisions (narrow_phase.cu:84-103): the queries with toi < 1, appended as (aid, bid, toi).  The filter runs on
+// the device (ballot + one atomic per wave); only the records that survive cross the bus.
+__global__ void collisions_compact_k(const int2* __restrict__ pairs, const double* __restrict__ per_query, long long n,
+                                     sccd_collision* __restrict__ out, long long* __restrict__ out_idx,
+                                     unsigned long long* __restrict__ n_out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const double t = i < n ? per_query[i] : 2.0;
+    const bool hit = t < 1;
+    const unsigned long long mask = __ballot(hit);
+    if (mask == 0) return;
+    const int leader = (int)__builtin_ctzll(mask);
+    unsigned long long base = 0;
+    if (lane_id() == leader) base = atomicAdd(n_out, (unsigned long long)popc64(mask));
+    base = __shfl(base, leader, 64);
+    if (hit) {
+        const int2 p = pairs[i];
+        const unsigned long long at = base + (unsigned long long)mbcnt64(mask);
+        out[at] = sccd_collision { p.x, p.y, t };
+        out_idx[at] = i;
+    }
+}
+static void copy_out_collisions(sccd_ctx* c, const int2* d_pairs, const double* d_pq, int64_t n, std::vector<sccd_collision>& acc)
+{
+    if (n <= 0) return;
+    DevBuf out, idx, cnt;
+    out.ensure(sizeof(sccd_collision) * (size_t)n);
+    idx.ensure(sizeof(long long) * (size_t)n);
+    cnt.ensure(sizeof(unsigned long long));
+    SCCD_HIP(hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(collisions_compact_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_pairs, d_pq,
+                       (long long)n, out.as<sccd_collision>(), idx.as<long long>(), cnt.as<unsigned long long>());
+    SCCD_HIP(hipGetLastError());
+    unsigned long long k = 0;
+    SCCD_HIP(hipMemcpyAsync(&k, cnt.p, sizeof k, hipMemcpyDeviceToHost, c->stream));
+    SCCD_HIP(hipStreamSynchronize(c->stream));
+    if (k == 0) return;
+    std::vector<sccd_collision> rec((size_t)k);
+    std::vector<long long> at((size_t)k);
+    SCCD_HIP(hipMemcpy(rec.data(), out.p, sizeof(sccd_collision) * (size_t)k, hipMemcpyDeviceToHost));
+    SCCD_HIP(hipMemcpy(at.data(), idx.p, sizeof(long long) * (size_t)k, hipMemcpyDeviceToHost));
+    // waves reserve their slots in order of arrival: put the records back into query order (what a serial
+    // copy_out_collisions gives; the reference's own order comes from atomics and is unspecified)
+    std::vector<size_t> order((size_t)k);
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return at[a] < at[b]; });
+    acc.reserve(acc.size() + (size_t)k);
+    for (size_t i = 0; i < order.size(); i++) acc.push_back(rec[order[i]]);
+}
+static sccd_collision* collisions_to_c(const std::vector<sccd_collision>& acc)
+{
+    sccd_collision* o = (sccd_collision*)std::malloc(std::max<size_t>(16, sizeof(sccd_collision) * acc.size()));
+    if (!o) throw SccdError { SCCD_E_NOMEM, "host allocation failed" };
+    if (!acc.empty()) std::memcpy(o, acc.data(), sizeof(sccd_collision) * acc.size());
+    return o;
+}
+
+extern "C" int sccd_narrow_phase(sccd_ctx* c, const sccd_mesh* m, const int32_t* pairs, int64_t n, int pairs_on_device,
+                                 int is_vf, int max_iter, double tol, double ms, int allow_zero_toi, double* toi,
+                                 sccd_collision** collisions, int64_t* n_collisions)
+{
+    if (!c || !m || !toi) return SCCD_E_INVALID;
+    if (collisions) *collisions = nullptr;
+    if (n_collisions) *n_collisions = 0;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(n >= 0 && (n == 0 || pairs), "narrow_phase: bad pair list");
+        SCCD_REQUIRE(*toi >= 0, "narrow_phase: toi must be >= 0");
+        const int2* d_pairs = reinterpret_cast<const int2*>(pairs);
+        std::vector<int32_t> h_pairs;
+        if (n > 0) {
+            // validate indices on the host copy (the reference asserts nothing and would fault)
+            if (!pairs_on_device) {
+                const int na = is_vf ? m->nV : m->nE, nb = is_vf ? m->nF : m->nE;
+                for (int64_t i = 0; i < n; i++)
+                    SCCD_REQUIRE(pairs[2 * i] >= 0 && pairs[2 * i] < na && pairs[2 * i + 1] >= 0 && pairs[2 * i + 1] < nb,
+                                 "narrow_phase: pair index out of range");
+                c->np_scratch3.ensure(sizeof(int2) * (size_t)n);
+                copy_in(c, c->np_scratch3.p, pairs, sizeof(int2) * (size_t)n, 0);
+                d_pairs = c->np_scratch3.as<int2>();
+            }
+        }
+        double* d_pq = nullptr;
+        DevBuf pq;
+        if (collisions && n > 0) {
+            pq.ensure(sizeof(double) * (size_t)n);
+            d_pq = pq.as<double>();
+        }
+        run_narrow(c, m, d_pairs, n, is_vf, max_iter, tol, ms, allow_zero_toi, toi, d_pq);
+        if (collisions && n > 0) {
+            std::vector<sccd_collision> acc;
+            copy_out_collisions(c, d_pairs, d_pq, n, acc);
+            *collisions = collisions_to_c(acc);
+            if (n_collisions) *n_collisions = (int64_t)acc.size();
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// drivers
+
+// partial_ccd<run_vf> (ccd.cu:14-78): build, then alternate detect_overlaps_partial / narrow_phase
+// (bp may belong to the helper context: its sweeps then run on that context's stream; every sweep ends with a host
+// round trip, so the narrow phase on c->stream starts after the pairs are complete either way)
+static void ccd_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, sccd_broad_phase* bp, bool vf, double ms, int max_iter,
+                     double tol, int allow_zero_toi, double* toi, sccd_stats* st, bool built = false, bool swept = false,
+                     std::function<void()>* before_narrow = nullptr)
+{
+    if (built) {} // (ccd() had the lists built already, by the helper)
+    else if (vf) bp_build(bp, &pl->vb, &pl->fb);
+    else bp_build(bp, &pl->eb, nullptr);
+    bool started = swept; // (... and the first sweep enqueued as well: bp_detect_partial(bp, 1))
+    while (bp->cursor < bp->total_rows) {
+        narrow_counters_upload(c, narrow_counters(c), *toi); // ahead of the sweep: one copy less between sweep and narrow phase
+        bp_detect_partial(bp, started ? 2 : 0);
+        started = false;
+        if (before_narrow && *before_narrow) {
+            (*before_narrow)();
+            *before_narrow = nullptr; // once
+        }
+        const NarrowResult r = run_narrow(c, m, bp->overlaps.as<int2>(), bp->n_overlaps, vf ? 1 : 0, max_iter, tol, ms,
+                                          allow_zero_toi, toi, nullptr);
+        if (st) {
+            (vf ? st->n_vf_pairs : st->n_ee_pairs) += bp->n_overlaps;
+            (vf ? st->n_vf_checks : st->n_ee_checks) += (int64_t)r.n_checks;
+        }
+    }
+    if (st) (vf ? st->n_vf_candidates : st->n_ee_candidates) = bp->candidates;
+}
+
+static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter, double tol, int allow_zero_toi,
+                        double* toi_out, sccd_stats* st)
+{
+    Pipeline* pl = pipeline_of(c);
+    if (st) std::memset(st, 0, sizeof *st);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (st && c->profile == 1) {
+        SCCD_HIP(hipEventCreate(&e0));
+        SCCD_HIP(hipEventCreate(&e1));
+        SCCD_HIP(hipEventRecord(e0, c->stream));
+    }
+    double before[SCCD_PROF_COUNT];
+    if (st && c->profile == 1) {
+        merge_side_profile(c);
+        std::memcpy(before, c->prof_ms, sizeof before);
+    }
+    // (a rank of a multi-GPU job builds the edge and face boxes of its window of cells only: see boxes_from_mesh)
+    const bool lazy_ef = c->shard_count > 1 && c->sort_axis >= 0 && c->max_overlap_cutoff == 0 && !c->build_scan;
+    boxes_from_mesh(c, m, ms, pl, true, true, true, lazy_ef); // inflation radius = min_distance (ccd.cu:112)
+    double toi = 1; // ccd.cu:125
+    // The edge-edge lists do not depend on the vertex-face pass: a helper context (own stream, scratch, pinned mirror)
+    // builds them on a worker thread meanwhile.  Both builds are chains of short, latency-bound kernels with host
+    // round trips in between, so two of them interleave almost for free (2.23 instead of 2.34 ms per step on the
+    // 1M-triangle cloth; 1.99 instead of 2.11 with the round-2 kernels).  On by default since the whole GPU suite
+    // and the soak run with it; SCCD_OVERLAP=0 keeps the passes apart.
+    const bool overlap_env = lab_env().overlap;
+    bool helper = false, presweep_done = false;
+    const bool presweep_env = lab_env().presweep;
+    if (overlap_env && !c->passes_apart && m->nE > 0) {
+        if (!c->side) {
+            if (sccd_create(c->device, &c->side) != SCCD_OK) throw SccdError { SCCD_E_NOMEM, "ccd: cannot create the helper context" };
+            SCCD_HIP(hipEventCreateWithFlags(&c->side_event, hipEventDisableTiming));
+            pl->bp_ee.ctx = c->side;
+            // (the helper's stream with the lowest / highest queue priority was measured in round 3: no effect)
+        }
+        sccd_ctx* const sc = c->side;
+        sc->sort_axis = c->sort_axis;
+        sc->sweep_algo = c->sweep_algo;
+        sc->cell_factor_milli = c->cell_factor_milli;
+        sc->build_scan = c->build_scan;
+        sc->shard_rank = c->shard_rank;
+        sc->shard_count = c->shard_count;
+        sc->overlap_capacity = c->overlap_capacity;
+        sc->max_overlap_cutoff = c->max_overlap_cutoff;
+        sc->memory_limit_mb = c->memory_limit_mb;
+        sc->profile = c->profile;
+        SCCD_HIP(hipEventRecord(c->side_event, c->stream)); // the boxes are complete behind this point
+        const int device = c->device;
+        hipEvent_t const ev = c->side_event;
+        sccd_broad_phase* const bp_ee = &pl->bp_ee;
+        const sccd_boxes* const eb = &pl->eb;
+        pl->worker.submit([=] {
+            SCCD_HIP(hipSetDevice(device));
+            SCCD_HIP(hipStreamWaitEvent(sc->stream, ev, 0));
+            bp_build(bp_ee, eb, nullptr);
+        });
+        helper = true;
+    }
+    // The edge-edge SWEEP runs beside the vertex-face NARROW phase: it is enqueued on the helper's stream right before
+    // that kernel is launched, with half a CU's worth of blocks (they are resident first, the narrow kernel's blocks
+    // take the rest and, being ticket-driven, make do with what they get).  The sweep waits on dependent gathers most
+    // of the time, the narrow phase is bound by vector issue: sharing the CUs, the two take little longer than the
+    // narrow phase alone.  SCCD_PRESWEEP=0 keeps them apart.
+    std::function<void()> start_ee_sweep;
+    if (helper && presweep_env)
+        start_ee_sweep = [&] {
+            pl->worker.wait(); // the lists are built (long since: the build is shorter than the vertex-face broad phase)
+            // ... behind whatever this context's stream holds now (the vertex-face sweep): ordered on the DEVICE, so the
+            // edge-edge sweep starts the moment that sweep ends -- not a host round trip later
+            SCCD_HIP(hipEventRecord(c->side_event, c->stream));
+            SCCD_HIP(hipStreamWaitEvent(c->side->stream, c->side_event, 0));
+            c->side->sweep_blocks_per_cu = 2;
+            try {
+                bp_detect_partial(&pl->bp_ee, 1);
+            } catch (...) {
+                c->side->sweep_blocks_per_cu = 0;
+                throw;
+            }
+            c->side->sweep_blocks_per_cu = 0;
+            presweep_done = true;
+        };
+    // ... and the edge-edge NARROW kernel starts on the helper's stream the moment that sweep is done, beside the tail of
+    // the vertex-face kernel (a wave-step of a deep query is a long dependent chain: the last part of a narrow launch
+    // keeps few lanes busy).  The two kernels share ONE running TOI (the vertex-face launch's word), so each prunes with
+    // what the other finds -- the final minimum does not depend on the order (Appendix A.20).  Only when both passes are
+    // served by the walk kernel in one chunk each; SCCD_NARROW_BESIDE=0 turns it off.
+    const bool beside_env = lab_env().narrow_beside;
+    bool both_done = false;
+    try {
+        // (a check limit: each pass proves on its own that the limit did not matter -- narrow.hip, the certificate -- which needs
+        // the pass's own running TOI: the passes stay in sequence)
+        if (helper && presweep_env && beside_env && c->max_overlap_cutoff == 0 && max_iter < 0) {
+            sccd_ctx* const sc = c->side;
+            sc->arith = c->arith;
+            sc->scalar_f32 = c->scalar_f32;
+            sc->narrow_algo = c->narrow_algo;
+            sc->limit_level_order = c->limit_level_order;
+            bp_build(&pl->bp, &pl->vb, &pl->fb);
+            narrow_counters_upload(c, narrow_counters(c), toi);
+            // the vertex-face sweep is enqueued, the edge-edge sweep behind it (on the helper's stream, by an event), and only
+            // then does the host wait for the vertex-face pairs: the narrow kernel it launches next finds the edge-edge
+            // sweep's blocks resident already and takes the rest of the chip
+            bp_detect_partial(&pl->bp, 1);
+            start_ee_sweep();
+            start_ee_sweep = nullptr;
+            bp_detect_partial(&pl->bp, 2);
+            const bool vf_one_chunk = pl->bp.cursor >= pl->bp.total_rows;
+            const NarrowParams pv = narrow_params(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, 1, max_iter, tol, ms, allow_zero_toi);
+            if (vf_one_chunk && narrow_uses_walk_kernel(c, pv, false)) {
+                double toi_vf = toi, toi_ee = toi;
+                narrow_phase_begin(c, pv, narrow_counters(c), &toi_vf, nullptr); // (asynchronous)
+                bp_detect_partial(&pl->bp_ee, 2);                                 // waits for the edge-edge sweep
+                if (pl->bp_ee.cursor >= pl->bp_ee.total_rows) {
+                    NarrowParams pe = narrow_params(sc, m, pl->bp_ee.overlaps.as<int2>(), pl->bp_ee.n_overlaps, 0, max_iter, tol, ms, allow_zero_toi);
+                    pe.toi_word = &narrow_counters(c)->toi_bits;
+                    narrow_counters_upload(sc, narrow_counters(sc), toi_ee);
+                    c->np_peer_stream = sc->stream;
+                    try {
+                        narrow_phase_begin(sc, pe, narrow_counters(sc), &toi_ee, nullptr);
+                        narrow_phase_end(c, pv, narrow_counters(c), &toi_vf, nullptr);
+                    } catch (...) {
+                        c->np_peer_stream = nullptr;
+                        throw;
+                    }
+                    c->np_peer_stream = nullptr;
+                    const NarrowResult rv = narrow_result(c);
+                    narrow_phase_end(sc, pe, narrow_counters(sc), &toi_ee, nullptr);
+                    const NarrowResult re = narrow_result(sc);
+                    toi = std::min(toi_vf, toi_ee);
+                    if (st) {
+                        st->n_vf_pairs += pl->bp.n_overlaps;
+                        st->n_vf_checks += (int64_t)rv.n_checks;
+                        st->n_vf_candidates = pl->bp.candidates;
+                        st->n_ee_pairs += pl->bp_ee.n_overlaps;
+                        st->n_ee_checks += (int64_t)re.n_checks;
+                        st->n_ee_candidates = pl->bp_ee.candidates;
+                    }
+                    both_done = true;
+                } else { // (the edge-edge overlaps come in chunks: finish the vertex-face pass, then chunk by chunk as usual)
+                    narrow_phase_end(c, pv, narrow_counters(c), &toi_vf, nullptr);
+                    const NarrowResult rv = narrow_result(c);
+                    toi = toi_vf;
+                    if (st) {
+                        st->n_vf_pairs += pl->bp.n_overlaps;
+                        st->n_vf_checks += (int64_t)rv.n_checks;
+                        st->n_vf_candidates = pl->bp.candidates;
+                    }
+                    // the first edge-edge chunk is swept already: its narrow phase, then the rest of the loop
+                    const NarrowResult re = run_narrow(c, m, pl->bp_ee.overlaps.as<int2>(), pl->bp_ee.n_overlaps, 0, max_iter, tol, ms,
+                                                       allow_zero_toi, &toi, nullptr);
+                    if (st) {
+                        st->n_ee_pairs += pl->bp_ee.n_overlaps;
+                        st->n_ee_checks += (int64_t)re.n_checks;
+                    }
+                    presweep_done = false; // (consumed)
+                }
+            } else { // not this time: the vertex-face pass as usual (its lists are built and its first chunk swept)
+                const NarrowResult rv = run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, 1, max_iter, tol, ms,
+                                                   allow_zero_toi, &toi, nullptr);
+                if (st) {
+                    st->n_vf_pairs += pl->bp.n_overlaps;
+                    st->n_vf_checks += (int64_t)rv.n_checks;
+                }
+                ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true);
+            }
+        } else {
+            ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st, false, false, &start_ee_sweep);
+        }
+    } catch (...) {
+        if (helper) {
+            try {
+                pl->worker.wait();
+            } catch (...) {
+            }
+            (void)hipStreamSynchronize(c->side->stream);
+        }
+        throw;
+    }
+    if (both_done) {
+        // (both passes are behind us)
+    } else if (helper) {
+        pl->worker.wait();
+        ccd_pass(c, m, pl, &pl->bp_ee, false, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true, /*swept=*/presweep_done);
+    } else {
+        ccd_pass(c, m, pl, &pl->bp, false, ms, max_iter, tol, allow_zero_toi, &toi, st);
+    }
+    *toi_out = toi;
+    if (st && c->profile == 1) {
+        SCCD_HIP(hipEventRecord(e1, c->stream));
+        SCCD_HIP(hipEventSynchronize(e1));
+        float msf = 0;
+        SCCD_HIP(hipEventElapsedTime(&msf, e0, e1));
+        st->ms_total = msf;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        merge_side_profile(c); // (the edge-edge half of the step ran on the helper context)
+        st->ms_boxes = c->prof_ms[SCCD_PROF_BOXES] - before[SCCD_PROF_BOXES];
+        st->ms_sort = c->prof_ms[SCCD_PROF_SORT] - before[SCCD_PROF_SORT];
+        st->ms_sweep = (c->prof_ms[SCCD_PROF_SWEEP] - before[SCCD_PROF_SWEEP])
+            + (c->prof_ms[SCCD_PROF_RANGES] - before[SCCD_PROF_RANGES]);
+        st->ms_narrow = (c->prof_ms[SCCD_PROF_NARROW_VF] - before[SCCD_PROF_NARROW_VF])
+            + (c->prof_ms[SCCD_PROF_NARROW_EE] - before[SCCD_PROF_NARROW_EE]);
+    }
+}
+
+extern "C" int sccd_ccd_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter, double tol, int allow_zero_toi,
+                             double* toi, sccd_stats* stats)
+{
+    if (!c || !m || !toi) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(m->ctx == c, "ccd: mesh belongs to another context");
+        ccd_on_mesh(c, m, ms, max_iter, tol, allow_zero_toi, toi, stats);
+    });
+}
+
+constexpr size_t TOI_OUT_MIRROR = 11280; // the source of sccd_ccd_mesh_dev's 8-byte upload in the pinned mirror (common.hpp: h_scalars)
+extern "C" int sccd_ccd_mesh_dev(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter, double tol, int allow_zero_toi,
+                                 double* d_toi, double* toi, sccd_stats* stats)
+{
+    if (!c || !m || !d_toi) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(m->ctx == c, "ccd: mesh belongs to another context");
+        double t = toi ? *toi : 1.0;
+        ccd_on_mesh(c, m, ms, max_iter, tol, allow_zero_toi, &t, stats);
+        // (the slot is rewritten by the next call's end at the earliest: that call has synchronised with this stream by then)
+        double* const slot = reinterpret_cast<double*>(c->h_scalars.as<char>() + TOI_OUT_MIRROR);
+        *slot = t;
+        SCCD_HIP(hipMemcpyAsync(d_toi, slot, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (toi) *toi = t;
+    });
+}
+
+extern "C" int sccd_ccd_mesh_prepare(sccd_ctx* c, const sccd_mesh* m, double ms)
+{
+    if (!c || !m) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(m->ctx == c, "ccd: mesh belongs to another context");
+        boxes_from_mesh(c, m, ms, pipeline_of(c), true, true, true);
+    });
+}
+
+extern "C" int sccd_ccd_mesh_pass(sccd_ctx* c, const sccd_mesh* m, int is_vf, double ms, int max_iter, double tol,
+                                  int allow_zero_toi, double* toi, sccd_stats* st)
+{
+    if (!c || !m || !toi) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(m->ctx == c, "ccd: mesh belongs to another context");
+        Pipeline* pl = pipeline_of(c);
+        SCCD_REQUIRE(pl->vb.n == m->nV && pl->eb.n == m->nE && pl->fb.n == m->nF,
+                     "ccd_mesh_pass: call sccd_ccd_mesh_prepare first");
+        if (st) std::memset(st, 0, sizeof *st);
+        ccd_pass(c, m, pl, &pl->bp, is_vf != 0, ms, max_iter, tol, allow_zero_toi, toi, st);
+    });
+}
+
+extern "C" int sccd_ccd(sccd_ctx* c, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
+                        const int32_t* F, int nF, double ms, int max_iter, double tol, int allow_zero_toi,
+                        int memory_limit_GB, double* toi)
+{
+    if (!c || !toi) return SCCD_E_INVALID;
+    const int64_t saved_limit = c->memory_limit_mb; // memory_limit_GB applies to this call (ccd.cu:40-43)
+    if (memory_limit_GB > 0) c->memory_limit_mb = (int64_t)memory_limit_GB << 10;
+    struct Restore {
+        sccd_ctx* c;
+        int64_t v;
+        ~Restore() { c->memory_limit_mb = v; }
+    } restore { c, saved_limit };
+    sccd_mesh* m = nullptr;
+    int rc = guarded(c, [&] { m = scratch_mesh_from_host(c, V0, V1, nV, E, nE, F, nF, /*defer_verdict=*/true); });
+    if (rc != SCCD_OK) return rc;
+    double t = *toi; // (the step runs on clamped indices until the verdict is in: its result is discarded with a bad mesh)
+    rc = sccd_ccd_mesh(c, m, ms, max_iter, tol, allow_zero_toi, &t, nullptr);
+    const int rc_mesh = guarded(c, [&] { mesh_deferred_verdict(c); }); // (an index out of range outranks whatever the step made of it)
+    if (rc_mesh == SCCD_OK && rc == SCCD_OK) *toi = t;
+    return rc_mesh != SCCD_OK ? rc_mesh : rc;
+}
+
+// ccd() with the per-query collision list (ccd.cu:14-78 in a SCALABLE_CCD_TOI_PER_QUERY build): build, then alternate
+// detect_overlaps_partial / narrow_phase with per-query output; the pairs stay on the device throughout
+static void ccd_pass_collisions(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, bool vf, double ms, int max_iter, double tol,
+                                int allow_zero_toi, double* toi, std::vector<sccd_collision>& acc)
+{
+    if (vf) bp_build(&pl->bp, &pl->vb, &pl->fb);
+    else bp_build(&pl->bp, &pl->eb, nullptr);
+    DevBuf pq;
+    while (pl->bp.cursor < pl->bp.total_rows) {
+        bp_detect_partial(&pl->bp);
+        const int64_t n = pl->bp.n_overlaps;
+        if (n > 0) pq.ensure(sizeof(double) * (size_t)n);
+        run_narrow(c, m, pl->bp.overlaps.as<int2>(), n, vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi, toi,
+                   n > 0 ? pq.as<double>() : nullptr);
+        copy_out_collisions(c, pl->bp.overlaps.as<int2>(), pq.as<double>(), n, acc);
+    }
+}
+
+extern "C" int sccd_ccd_collisions(sccd_ctx* c, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
+                                   const int32_t* F, int nF, double ms, int max_iter, double tol, int allow_zero_toi,
+                                   int memory_limit_GB, double* toi, sccd_collision** collisions, int64_t* n_collisions)
+{
+    if (!c || !toi || !collisions || !n_collisions) return SCCD_E_INVALID;
+    *collisions = nullptr;
+    *n_collisions = 0;
+    const int64_t saved_limit = c->memory_limit_mb; // memory_limit_GB applies to this call (ccd.cu:40-43)
+    if (memory_limit_GB > 0) c->memory_limit_mb = (int64_t)memory_limit_GB << 10;
+    struct Restore {
+        sccd_ctx* c;
+        int64_t v;
+        ~Restore() { c->memory_limit_mb = v; }
+    } restore { c, saved_limit };
+    return guarded(c, [&] {
+        sccd_mesh* const m = scratch_mesh_from_host(c, V0, V1, nV, E, nE, F, nF);
+        Pipeline* pl = pipeline_of(c);
+        boxes_from_mesh(c, m, ms, pl, true, true, true); // inflation radius = min_distance (ccd.cu:112)
+        double t = 1;                                    // ccd.cu:125
+        std::vector<sccd_collision> acc;
+        ccd_pass_collisions(c, m, pl, true, ms, max_iter, tol, allow_zero_toi, &t, acc);
+        ccd_pass_collisions(c, m, pl, false, ms, max_iter, tol, allow_zero_toi, &t, acc);
+        *collisions = collisions_to_c(acc);
+        *n_collisions = (int64_t)acc.size();
+        *toi = t;
+    });
+}
+
+// partial_ipc_ccd_strategy<run_vf> (ipc_ccd_strategy.cu:12-92)
+static void ipc_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, bool vf, double ms, int max_iter, double tol,
+                     double* earliest)
+{
+    if (vf) bp_build(&pl->bp, &pl->vb, &pl->fb);
+    else bp_build(&pl->bp, &pl->eb, nullptr);
+    while (pl->bp.cursor < pl->bp.total_rows) {
+        bp_detect_partial(&pl->bp);
+        const double before = *earliest;
+        run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, vf ? 1 : 0, max_iter, tol, ms,
+                   /*allow_zero_toi=*/1, earliest, nullptr);
+        if (*earliest < 1e-6) { // :72-91: conservative re-run without minimum separation
+            *earliest = before;
+            run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, vf ? 1 : 0, /*max_iter=*/-1, tol,
+                       /*ms=*/0.0, /*allow_zero_toi=*/0, earliest, nullptr);
+            *earliest *= 0.8;
+        }
+    }
+}
+
+extern "C" int sccd_ipc_ccd_strategy(sccd_ctx* c, const double* V0, const double* V1, int nV, const int32_t* E, int nE,
+                                     const int32_t* F, int nF, double ms, int max_iter, double tol, double* toi)
+{
+    if (!c || !toi) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        sccd_mesh* const m = scratch_mesh_from_host(c, V0, V1, nV, E, nE, F, nF);
+        Pipeline* pl = pipeline_of(c);
+        boxes_from_mesh(c, m, ms, pl, true, true, true); // ipc_ccd_strategy.cu:123-125
+        double earliest = 1.0;                           // :136
+        ipc_pass(c, m, pl, true, ms, max_iter, tol, &earliest);
+        ipc_pass(c, m, pl, false, ms, max_iter, tol, &earliest);
+        *toi = earliest;
+    });
+}
+

@@ -249,8 +249,7 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
     // (8 GB per level buffer = 1.4e8 live domains: beyond that a slice is cut; 4096 queries that still need
     // more are hopeless in level order, and failing early beats filling 288 GB first)
     // (SCCD_LEVEL_BUDGET_MB: a smaller budget per level buffer, for soak runs on shared test machines)
-    static const size_t budget_cap = std::getenv("SCCD_LEVEL_BUDGET_MB")
-        ? std::max<size_t>(64, (size_t)std::atoll(std::getenv("SCCD_LEVEL_BUDGET_MB"))) << 20 : (size_t)8 << 30;
+    const size_t budget_cap = lab_env().level_budget_mb > 0 ? std::max<size_t>(64, (size_t)lab_env().level_budget_mb) << 20 : (size_t)8 << 30;
     const size_t budget = std::min<size_t>(budget_cap,
                                            std::max<size_t>((free_b + c->np_scratch1.cap + c->np_scratch2.cap) / 3, (size_t)64 << 20));
     LvlSnap* snap = nullptr; // (a check limit: level-snapshot serialisation, see LvlSnap)
@@ -515,24 +514,24 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
         h.overflow = 0;
         h.n_ovf = 0;
     }
-    if (std::getenv("SCCD_NP_DIAG") && h.wave_steps)
+    if (lab_env().np_diag && h.wave_steps)
         std::fprintf(stderr, "[sccd np] n=%lld checks=%llu wave_steps=%llu (waves %llu, mean %.1f, longest %llu) lane_util=%.3f refill_execs=%llu steals=%llu pops=%llu checked ahead=%llu\n",
                      n, h.n_checks, h.wave_steps, h.waves_run, (double)h.wave_steps / (double)std::max<unsigned long long>(1, h.waves_run),
                      h.max_wave_steps, (double)h.lane_steps / (64.0 * (double)h.wave_steps), h.refill_execs, h.steals,
                      h.pops_reg, h.checked_ahead);
-    if (std::getenv("SCCD_NP_DIAG") && h.wave_steps)
+    if (lab_env().np_diag && h.wave_steps)
         std::fprintf(stderr, "[sccd np] tail (after a wave's query stream ran dry): %llu of %llu wave-steps, longest %llu steps / %.0f of %.0f kcycles; mean tail %.0f kcycles\n",
                      h.tail_steps, h.wave_steps, h.max_tail_steps, h.max_tail_cycles / 1e3, h.max_total_cycles / 1e3,
                      (double)h.sum_tail_cycles / 1e3 / (double)std::max<unsigned long long>(1, h.waves_run));
-    if (std::getenv("SCCD_NP_DIAG") && h.wave_steps) {
+    if (lab_env().np_diag && h.wave_steps) {
         std::fprintf(stderr, "[sccd np] waves by steps (x16):");
         for (int k = 0; k < 16; k++) std::fprintf(stderr, " %llu", h.wave_hist[k]);
         std::fprintf(stderr, " | mean steps per XCD:");
         for (int k = 0; k < 8; k++) std::fprintf(stderr, " %.0f(%llu)", (double)h.xcd_steps[k] / (double)std::max<unsigned long long>(1, h.xcd_waves[k]), h.xcd_waves[k]);
         std::fprintf(stderr, "\n");
     }
-    if (std::getenv("SCCD_NP_DIAG") && std::atoi(std::getenv("SCCD_NP_DIAG")) >= 3 && h.tail_steps) h.wave_steps = h.tail_steps; // (per tail step)
-    if (std::getenv("SCCD_NP_DIAG") && h.stamp[4])
+    if (lab_env().np_diag >= 3 && h.tail_steps) h.wave_steps = h.tail_steps; // (per tail step)
+    if (lab_env().np_diag && h.stamp[4])
         std::fprintf(stderr, "[sccd np] cycles/wave-step: toi=%.0f pop=%.0f steal=%.0f refill=%.0f check=%.0f push=%.0f | cycles/ingest: total=%.0f gather wait=%.0f\n",
                      (double)h.stamp[0] / h.wave_steps, (double)h.stamp[1] / h.wave_steps, (double)h.stamp[2] / h.wave_steps,
                      (double)h.stamp[3] / h.wave_steps, (double)h.stamp[4] / h.wave_steps, (double)h.stamp[5] / h.wave_steps,

@@ -19,8 +19,8 @@
 // order, so the sort is stable.  Tiles take their index from an atomic ticket, so a tile only
 // ever waits for tiles that already run (no dependence on the dispatch order).
 //
-// SCCD_SORT=classic selects the simple count / scan / scatter pipeline (5 launches per pass),
-// kept as an in-library cross-check.
+// (The simple count / scan / scatter pipeline of round 1 -- SCCD_SORT=classic -- is gone: tests/test_gpu_parity.py checks the
+// sort against torch.sort instead.)
 #include "internal.hpp"
 
 #include <algorithm>
@@ -406,68 +406,6 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restri
     }
 }
 
-// ---- classic count / scan / scatter -------------------------------------------------------------
-__global__ __launch_bounds__(RS_THREADS) void rs_count_k(const uint32_t* __restrict__ keys, long long n, int shift,
-                                                         int num_tiles, uint32_t* __restrict__ counts)
-{
-    __shared__ uint32_t hist[256];
-    hist[threadIdx.x] = 0;
-    __syncthreads();
-    const long long base = (long long)blockIdx.x * RS_TILE;
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-        const long long i = base + (long long)r * RS_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&hist[(keys[i] >> shift) & 255u], 1u);
-    }
-    __syncthreads();
-    counts[(size_t)threadIdx.x * num_tiles + blockIdx.x] = hist[threadIdx.x];
-}
-
-__global__ __launch_bounds__(RS_THREADS) void rs_scatter_k(const uint32_t* __restrict__ keys_in,
-                                                           const uint32_t* __restrict__ vals_in,
-                                                           uint32_t* __restrict__ keys_out,
-                                                           uint32_t* __restrict__ vals_out, long long n, int shift,
-                                                           int num_tiles, const uint32_t* __restrict__ offsets)
-{
-    __shared__ uint32_t wcnt[RS_WAVES][256];
-    const int lane = lane_id(), w = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < RS_WAVES; k++) wcnt[k][threadIdx.x] = 0;
-    __syncthreads();
-    const long long wave_base = (long long)blockIdx.x * RS_TILE + (long long)w * RS_WAVE_SPAN;
-    uint32_t key[RS_ITEMS], rank[RS_ITEMS];
-    bool valid[RS_ITEMS];
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-        const long long i = wave_base + r * 64 + lane;
-        valid[r] = i < n;
-        key[r] = valid[r] ? keys_in[i] : 0xFFFFFFFFu;
-    }
-    wave_rank_rows(key, valid, shift, wcnt[w], rank);
-    __syncthreads();
-    {
-        const int d = threadIdx.x;
-        uint32_t run = offsets[(size_t)d * num_tiles + blockIdx.x];
-#pragma unroll
-        for (int k = 0; k < RS_WAVES; k++) {
-            const uint32_t t = wcnt[k][d];
-            wcnt[k][d] = run;
-            run += t;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-        const long long i = wave_base + r * 64 + lane;
-        if (valid[r]) {
-            const uint32_t d = (key[r] >> shift) & 255u;
-            const uint32_t pos = wcnt[w][d] + rank[r];
-            keys_out[pos] = key[r];
-            vals_out[pos] = vals_in[i];
-        }
-    }
-}
-
 } // namespace
 
 // Sorts by the low `key_bits` bits (a multiple of 8).  Returns true when the result ended in the
@@ -484,35 +422,13 @@ bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
     uint32_t* v_in = vals;
     uint32_t* k_out = c->sort_tmp_keys.as<uint32_t>();
     uint32_t* v_out = c->sort_tmp_vals.as<uint32_t>();
-    static const bool classic = [] {
-        const char* e = std::getenv("SCCD_SORT");
-        return e && std::strcmp(e, "classic") == 0;
-    }();
-    SCCD_REQUIRE(!(classic && d_n_real), "radix sort: the classic sort takes an exact count");
-    if (classic) {
-        c->sort_hist.ensure(sizeof(uint32_t) * 256 * (size_t)num_tiles);
-        uint32_t* counts = c->sort_hist.as<uint32_t>();
-        for (int pass = 0; pass < passes; pass++) {
-            const int shift = 8 * pass;
-            hipLaunchKernelGGL(rs_count_k, dim3(num_tiles), dim3(RS_THREADS), 0, c->stream, k_in, (long long)n, shift,
-                               num_tiles, counts);
-            exclusive_scan_u32(c, counts, counts, 256 * num_tiles,
-                               reinterpret_cast<uint32_t*>(c->scalars.as<char>() + 1024));
-            hipLaunchKernelGGL(rs_scatter_k, dim3(num_tiles), dim3(RS_THREADS), 0, c->stream, k_in, v_in, k_out, v_out,
-                               (long long)n, shift, num_tiles, counts);
-            std::swap(k_in, k_out);
-            std::swap(v_in, v_out);
-        }
-        SCCD_HIP(hipGetLastError());
-        return (passes & 1) != 0;
-    }
     // onesweep: [4 tickets, one per 128-B line] [status passes x tiles x 256] [bases 4x256] [partial hist blocks x 1024]
     // (Per-segment tickets + bases were tried: the bases of a segment are only known for the FIRST pass,
     // later passes see permuted keys; ticket streams without a global order can deadlock the look-back; and a
     // ticket worth two consecutive tiles serialises it -- the second tile publishes its count only after the
     // first is finished, so every predecessor chain runs at one tile time per link: 70x slower.)
     const int hist_blocks = (int)std::min<long long>((n + 4 * HS_THREADS - 1) / (4 * HS_THREADS), c->num_cus); // (>= one 16-byte load per thread)
-    const int dbg = std::getenv("SCCD_SORT_DBG") ? std::atoi(std::getenv("SCCD_SORT_DBG")) : 0; // timing ablations only
+    const int dbg = 0; // (os_pass_k's timing ablations -- 1 no global writes, 2 no ranking, 4 no look-back -- are a rebuild away: tools/sortdbg.sh)
     const size_t status_bytes = (size_t)passes * num_tiles * 256 * sizeof(uint32_t);
     const size_t off_status = 512, off_bases = off_status + status_bytes, off_partial = off_bases + 4096;
     c->sort_hist.ensure(off_partial + (size_t)hist_blocks * 4096);
@@ -526,8 +442,8 @@ bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
                        reinterpret_cast<uint4*>(base), (long long)((512 + status_bytes) / 16), passes, d_n_real);
     hipLaunchKernelGGL(os_bases_k, dim3(4), dim3(1024), 0, c->stream, partial, hist_blocks, bases);
     for (int pass = 0; pass < passes; pass++) {
-        static const int pass_blocks = std::getenv("SCCD_SORT_BLOCKS") ? std::atoi(std::getenv("SCCD_SORT_BLOCKS")) : 3;
-        static const bool force_tickets = std::getenv("SCCD_SORT_TICKETS") && std::atoi(std::getenv("SCCD_SORT_TICKETS")) != 0;
+        constexpr int pass_blocks = 3; // resident blocks per CU (41 KB of LDS each)
+        const bool force_tickets = lab_env().sort_tickets;
         const int blocks = std::min(num_tiles, c->num_cus * pass_blocks);
         // (a block per tile: tiles by block index, no ticket word -- os_pass_k)
         uint32_t* const tk = (blocks == num_tiles && !force_tickets) ? nullptr : tickets + pass * 32;

@@ -729,26 +729,22 @@ void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, c
         const int num_tiles = (row_end - row_begin + 63) / 64;
         // RESIDENT blocks only: tiles are dealt statically over the grid, so a block that has to wait
         // for a slot doubles the tail.  78 KB of LDS per block -> 2 blocks per CU; a multiple of 8 blocks (the XCD-aware deal).
-        static const int per_cu_env = std::getenv("SCCD_SWEEP_BLOCKS") ? std::atoi(std::getenv("SCCD_SWEEP_BLOCKS")) : 2;
-        const int per_cu = c->sweep_blocks_per_cu > 0 ? c->sweep_blocks_per_cu : per_cu_env;
+        const int per_cu = c->sweep_blocks_per_cu > 0 ? c->sweep_blocks_per_cu : 2;
         int grid = std::min((num_tiles + SW_WAVES - 1) / SW_WAVES, c->num_cus * per_cu);
         grid = std::max(8, (grid + 7) / 8 * 8);
         // consecutive tiles per wave and deal (measured on 1M random boxes and the 1M-triangle cloth: a wave has only ~12
         // tiles per launch, and with 2 / 4 / 8 of them in a row the deal's quantisation costs more than the shared
         // windows save: 0.27 / 0.28 / 0.29 / 0.32 ms for chunks of 1 / 2 / 4 / 8)
-        static const int chunk_env = std::getenv("SCCD_SWEEP_CHUNK") ? std::max(1, std::atoi(std::getenv("SCCD_SWEEP_CHUNK"))) : 1;
-        const int waves = grid * SW_WAVES;
-        const int chunk = std::max(1, std::min(chunk_env, num_tiles / (2 * waves)));
+        const int chunk = 1;
         // what the lists' vertex ids are known to be (filter_step): mesh-built lists test shared vertices in the filter
-        static const bool ids_env = !(std::getenv("SCCD_SWEEP_IDS") && std::atoi(std::getenv("SCCD_SWEEP_IDS")) == 0);
         int kind = 0;
-        if (ids_env) {
+        {
             if (one && rows->kind == BOX_EDGE) kind = 1;
             else if (!one && rows->kind == BOX_VERTEX && cols->kind == BOX_FACE) kind = 2;
             else if (!one && rows->kind == BOX_FACE && cols->kind == BOX_VERTEX) kind = 3;
         }
         auto go = [&](auto kernel) {
-            static const int diag = std::getenv("SCCD_SWEEP_DIAG") ? std::atoi(std::getenv("SCCD_SWEEP_DIAG")) : 0;
+            const int diag = lab_env().sweep_diag;
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(SW_THREADS), 0, c->stream, R, row_begin, row_end, C, cols->m, gp, emit,
                                chunk, out, (long long)capacity, d_cnt, diag, d_m_rows, d_m_cols, expect_bits);
         };
@@ -766,20 +762,17 @@ void launch_sweep_two(sccd_ctx* c, const SortedList* A, const SortedList* B, con
                       int b_begin, int b_end, int2* out, int64_t capacity, SweepCounters* d_cnt, const uint32_t* d_tot, int expect_bits)
 {
     const int tiles_a = std::max(0, (a_end - a_begin + 63) / 64), tiles_b = std::max(0, (b_end - b_begin + 63) / 64);
-    static const bool fuse_env = !(std::getenv("SCCD_SWEEP_FUSE") && std::atoi(std::getenv("SCCD_SWEEP_FUSE")) == 0);
-    if (c->sweep_algo == 1 || !fuse_env || tiles_a == 0 || tiles_b == 0 || A->m == 0 || B->m == 0) {
+    if (c->sweep_algo == 1 || tiles_a == 0 || tiles_b == 0 || A->m == 0 || B->m == 0) {
         launch_sweep(c, A, B, gp, a_begin, a_end, EMIT_ROWS_A, out, capacity, d_cnt, d_tot, d_tot ? d_tot + 1 : nullptr, expect_bits);
         launch_sweep(c, B, A, gp, b_begin, b_end, EMIT_ROWS_B, out, capacity, d_cnt, d_tot ? d_tot + 1 : nullptr, d_tot, expect_bits);
         return;
     }
-    static const int per_cu_env = std::getenv("SCCD_SWEEP_BLOCKS") ? std::atoi(std::getenv("SCCD_SWEEP_BLOCKS")) : 2;
-    const int per_cu = c->sweep_blocks_per_cu > 0 ? c->sweep_blocks_per_cu : per_cu_env;
+    const int per_cu = c->sweep_blocks_per_cu > 0 ? c->sweep_blocks_per_cu : 2;
     const int tiles = std::max(tiles_a, tiles_b);
     int grid = std::min((tiles + SW_WAVES - 1) / SW_WAVES, c->num_cus * per_cu);
     grid = std::max(8, (grid + 7) / 8 * 8);
-    static const bool ids_env = !(std::getenv("SCCD_SWEEP_IDS") && std::atoi(std::getenv("SCCD_SWEEP_IDS")) == 0);
-    const bool vf = ids_env && A->kind == BOX_VERTEX && B->kind == BOX_FACE;
-    static const int diag = std::getenv("SCCD_SWEEP_DIAG") ? std::atoi(std::getenv("SCCD_SWEEP_DIAG")) : 0;
+    const bool vf = A->kind == BOX_VERTEX && B->kind == BOX_FACE;
+    const int diag = lab_env().sweep_diag;
     const SweepRecs RA = sweep_recs(A), RB = sweep_recs(B);
     auto go = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(SW_THREADS), 0, c->stream, RA, a_begin, a_end, A->m, RB, b_begin, b_end, B->m, gp,

@@ -83,9 +83,10 @@ def test_overlap_pairs_identical(sccd, ctx, orc, name, algo):
 
 
 @pytest.mark.parametrize("cell_factor", ["0", "1", "2.5", "16"])
-def test_pair_set_independent_of_cell_grid(sccd, ctx, orc, cell_factor, monkeypatch):
-    """the composite (cell, x) key changes the work, never the result"""
-    monkeypatch.setenv("SCCD_CELL_FACTOR", cell_factor)
+def test_pair_set_independent_of_cell_grid(sccd, ctx, orc, cell_factor, request):
+    """the composite (cell, x) key changes the work, never the result (SCCD_OPT_CELL_FACTOR_MILLI; "0": the grid switched off)"""
+    ctx.set_option(sccd.OPT_CELL_FACTOR_MILLI, int(float(cell_factor) * 1000) or -1)
+    request.addfinalizer(lambda: ctx.set_option(sccd.OPT_CELL_FACTOR_MILLI, 0))
     V0, V1, E, F = _scene("soup_dense")
     vb, eb, fb = orc.build_boxes(V0, V1, E, F)
     want_vf, _, _ = orc.sort_and_sweep(vb, fb, nthreads=8)
@@ -106,10 +107,11 @@ def test_pair_set_independent_of_cell_grid(sccd, ctx, orc, cell_factor, monkeypa
     assert np.array_equal(_sorted(bp.detect_overlaps()), want)
 
 
-def test_scan_build_path(sccd, ctx, orc, monkeypatch):
-    """SCCD_BUILD=scan: count -> device-wide prefix scan -> fill instead of the one-pass append
+def test_scan_build_path(sccd, ctx, orc, request):
+    """SCCD_OPT_BUILD_SCAN: count -> device-wide prefix scan -> fill instead of the one-pass append
     (entries in box order).  Same pair sets, one and two lists."""
-    monkeypatch.setenv("SCCD_BUILD", "scan")
+    ctx.set_option(sccd.OPT_BUILD_SCAN, 1)
+    request.addfinalizer(lambda: ctx.set_option(sccd.OPT_BUILD_SCAN, 0))
     V0, V1, E, F = _scene("cloth_ball_10k")
     vb, eb, fb = orc.build_boxes(V0, V1, E, F)
     bp = sccd.BroadPhase(ctx)
@@ -123,7 +125,7 @@ def test_scan_build_path(sccd, ctx, orc, monkeypatch):
     want, _, _ = orc.sort_and_sweep(b[:4000], nthreads=8)
     bp.build(sccd.DeviceAABBs(b[:4000], ctx))
     assert np.array_equal(_sorted(bp.detect_overlaps()), want)
-    monkeypatch.delenv("SCCD_BUILD")
+    ctx.set_option(sccd.OPT_BUILD_SCAN, 0)
     bp.build(sccd.DeviceAABBs(b[:4000], ctx))  # ... and the same through the append path
     assert np.array_equal(_sorted(bp.detect_overlaps()), want)
 
@@ -258,9 +260,10 @@ def test_sharded_sweeps_partition_the_pair_set(sccd, ctx, orc, world, two_lists)
     assert np.array_equal(_sorted(np.concatenate(parts)), want)  # disjoint and complete
 
 
-def test_sharded_sweep_on_a_single_cell_grid_splits_rows(sccd, ctx, orc, monkeypatch):
-    """SCCD_CELL_FACTOR<=0 switches the grid off: the shards fall back to slices of the rows."""
-    monkeypatch.setenv("SCCD_CELL_FACTOR", "0")
+def test_sharded_sweep_on_a_single_cell_grid_splits_rows(sccd, ctx, orc, request):
+    """SCCD_OPT_CELL_FACTOR_MILLI < 0 switches the grid off: the shards fall back to slices of the rows."""
+    ctx.set_option(sccd.OPT_CELL_FACTOR_MILLI, -1)
+    request.addfinalizer(lambda: ctx.set_option(sccd.OPT_CELL_FACTOR_MILLI, 0))
     b = scenes.random_boxes(20_000, seed=5, max_extent=0.05)
     want, _, _ = orc.sort_and_sweep(b, nthreads=8)
     parts = []

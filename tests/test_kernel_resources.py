@@ -44,7 +44,7 @@ def test_walk_kernels_keep_three_waves_per_simd_without_scratch(tmp_path):
 def test_no_kernel_uses_scratch_memory(tmp_path):
     # every kernel of the library: a spill, or an array indexed by a run-time value (`b.lo[g.aa]` put 56 bytes per thread of
     # the two-list fill into scratch until round 3: 19 us of a 1.3 ms step), shows up here
-    for src in ("sort", "sweep", "boxes", "scan", "api"):
+    for src in ("sort", "sweep", "boxes", "scan", "api", "build", "drivers"):
         for name, r in _kernels(src, tmp_path).items():
             assert r["private_segment_fixed_size"] == 0, (name, r)
             if "sweep_band_k" in name:

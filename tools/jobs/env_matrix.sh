@@ -2,8 +2,7 @@
 # (functional checks of the multi-process path: the timings of shared-GPU runs mean nothing).   bash tools/jobs/env_matrix.sh
 cd $GRAFT_REPO_ROOT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-for sw in SCCD_OVERLAP=0 SCCD_NARROW_BESIDE=0 SCCD_PRESWEEP=0 SCCD_MERGED_SORT=0 SCCD_BUILD=scan SCCD_SORT=classic \
-          SCCD_SWEEP_FUSE=0 SCCD_SWEEP_IDS=0 SCCD_SWEEP_CHUNK=3 SCCD_DEVICE_WINDOW=0 SCCD_LAZY_BOXES=0 SCCD_NP_PERM=0 SCCD_SYNC=block SCCD_SPECULATE=0 SCCD_ONE_CLASS=0; do
+for sw in SCCD_OVERLAP=0 SCCD_NARROW_BESIDE=0 SCCD_PRESWEEP=0 SCCD_SYNC=block SCCD_SPECULATE=0 SCCD_SORT_TICKETS=1; do
   echo "== $sw"
   env $sw timeout 900 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -1
 done

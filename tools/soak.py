@@ -101,10 +101,7 @@ def main():
         want_vf, _, _ = orc.sort_and_sweep(vb, fb, nthreads=8)
         want_ee, _, _ = orc.sort_and_sweep(eb, nthreads=8)
         want, _, _ = orc.ccd(V0, V1, E, F, ms, -1, 1e-6, allow_zero, arith=arith, nthreads=8)
-        if scan_build:
-            os.environ["SCCD_BUILD"] = "scan"
-        else:
-            os.environ.pop("SCCD_BUILD", None)
+        ctx.set_option(sccd.OPT_BUILD_SCAN, 1 if scan_build else 0)
         ok = False
         tois, got_vf, got_ee = [float("nan")], [np.zeros((0, 2), np.int32)], [np.zeros((0, 2), np.int32)]
         try:
