@@ -506,6 +506,7 @@ static bool speculation_settle(sccd_broad_phase* bp, const GridReadBack& built, 
     const bool two = bp->B != nullptr;
     const uint32_t ta = built.total[0], tb = two ? built.total[1] : 0u;
     const int64_t n_total = (int64_t)bp->A->n + (two ? bp->B->n : 0);
+    bool ok_forced_miss = false;
     const bool ok = built.gp.key_bits == gs.key_bits                  // the sort ran the right passes
         && ta > 0 && (!two || tb > 0)                                 // (an empty side ends a build early)
         && ta <= bp->spec_bound[0] && tb <= bp->spec_bound[1]         // records and sweep saw every entry
@@ -515,7 +516,13 @@ static bool speculation_settle(sccd_broad_phase* bp, const GridReadBack& built, 
                 ? !(hwin.total_est > (unsigned long long)std::max<int64_t>(3 * n_total, n_total + 4096)) && hwin.n_cells >= 4 * bp->ctx->shard_count
                 : !over_budget(ta, bp->A->n) && !(two && over_budget(tb, bp->B->n)));
     bp->speculative = false;
-    (ok ? bp->ctx->spec_hits : bp->ctx->spec_misses) += 1;
+    if (ok && lab_env().spec_break_every > 0 && (bp->ctx->spec_hits + bp->ctx->spec_misses + 1) % lab_env().spec_break_every == 0)
+        ok_forced_miss = true; // (measurement: the guess held, the build is redone as if it had not)
+    (ok && !ok_forced_miss ? bp->ctx->spec_hits : bp->ctx->spec_misses) += 1;
+    if (ok_forced_miss) {
+        bp->guess.valid = false; // (like a real miss: the rebuild waits for its counts and becomes the next guess)
+        return false;
+    }
     if (!ok) {
         bp->guess.valid = false;
         return false;

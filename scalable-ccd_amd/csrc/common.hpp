@@ -97,6 +97,7 @@ struct LabEnv {
     bool sync_block = false;           // SCCD_SYNC=block: read-backs wait with hipStreamSynchronize instead of polling an event
     bool sort_tickets = false;         // SCCD_SORT_TICKETS=1: sort tiles by atomic ticket even when every tile has its block
     long long level_budget_mb = 0;     // SCCD_LEVEL_BUDGET_MB: budget per level buffer of the level-synchronous narrow phase
+    int spec_break_every = 0;          // SCCD_SPEC_BREAK=N: every N-th speculative build is declared a failed guess (measures what a miss costs)
     static int num(const char* name, int dflt)
     {
         const char* e = std::getenv(name);
@@ -112,6 +113,7 @@ struct LabEnv {
         narrow_beside = num("SCCD_NARROW_BESIDE", 1) != 0;
         sort_tickets = num("SCCD_SORT_TICKETS", 0) != 0;
         level_budget_mb = num("SCCD_LEVEL_BUDGET_MB", 0);
+        spec_break_every = num("SCCD_SPEC_BREAK", 0);
         const char* s = std::getenv("SCCD_SYNC");
         sync_block = s && std::string(s) == "block";
     }
