@@ -38,18 +38,18 @@ BYTES_BROAD_PER_BOX = 548.0   # box build 124 + radix sort 204 + payl
 
 
 def pmc_kernels(workload):
-    """per-kernel HBM bytes of profiles/r03_pmc_traffic_<workload>.json if that profile is of THIS build, else None"""
+    """per-kernel HBM bytes of profiles/r04_pmc_traffic_<workload>.json if that profile is of THIS build, else None"""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_%s.json" % workload)))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic_%s.json" % workload)))
         return tj["kernels"] if tj.get("lib_sha256") == lib_sha256() else None
     except Exception:
         return None
 
 
 def pmc_sq(workload):
-    """SQ counters per kernel of profiles/r03_pmc_sq_<workload>.json (tools/pmc_sq.sh) if taken on THIS build, else None"""
+    """SQ counters per kernel of profiles/r04_pmc_sq_<workload>.json (tools/pmc_sq.sh) if taken on THIS build, else None"""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_sq_%s.json" % workload)))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_sq_%s.json" % workload)))
         return tj["kernels"] if tj.get("lib_sha256") == lib_sha256() else None
     except Exception:
         return None
@@ -86,6 +86,9 @@ def parse():
                     "(e.g. 0.05: large and small motions alternate, the entry counts jump from step to step and the speculative guesses break)")
     ap.add_argument("--jitter-fraction", type=float, default=1.0, help="--jitter: only this fraction of the vertices moves (a few large boxes "
                     "among small ones change how many cells a box spans, i.e. the entry counts the speculative build guesses)")
+    ap.add_argument("--cliffs", action="store_true", help="cloth workloads: also time the paths that do not run on the plain fast kernel -- ccd() with the "
+                    "per-query collision list (with and without a check limit), a check limit on the level-synchronous kernels, the float build "
+                    "-- each as a multiple of the default step (block `cliffs` of the line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="cloth side of the CPU sample (0 = auto)")
     return ap.parse_args()
@@ -251,13 +254,13 @@ def main():
         # THIS build of the library: the JSON carries the hash of the libsccd_hip.so it profiled
         traffic, traffic_note = None, "no PMC profile of this workload"
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_cloth1m.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic_cloth1m.json")))
             if args.workload == "cloth1m" and args.cloth_n == 708 and world == 1:
                 if tj.get("lib_sha256") == lib_sha256():
                     traffic = tj["kernels"][units[dom][2]]["hbm_bytes_per_launch_corrected"]
-                    traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build (profiles/r03_pmc_traffic_cloth1m.json)"
+                    traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build (profiles/r04_pmc_traffic_cloth1m.json)"
                 else:
-                    traffic_note = "profiles/r03_pmc_traffic_cloth1m.json was taken on another build of the library: dropped"
+                    traffic_note = "profiles/r04_pmc_traffic_cloth1m.json was taken on another build of the library: dropped"
         except Exception:
             pass
         checks = float(c_vf + c_ee)
@@ -331,6 +334,37 @@ def main():
                 sccd.ccd(hV0, hV1, hE, hF, 0.0, args.max_iter, 1e-6, True, ctx=ctx)
                 t_h.append((time.perf_counter() - th0) * 1e3)
             host_ms = round(min(t_h), 4)
+        cliffs = None
+        if args.cliffs and world == 1:
+            def best(fn, reps=3):
+                fn()
+                ts = []
+                for _ in range(reps):
+                    ctx.synchronize()
+                    tc = time.perf_counter()
+                    fn()
+                    ctx.synchronize()
+                    ts.append((time.perf_counter() - tc) * 1e3)
+                return round(min(ts), 4)
+
+            hV0, hV1 = np.asfortranarray(V0, dtype=np.float64), np.asfortranarray(V1, dtype=np.float64)
+            hE, hF = np.asfortranarray(E, dtype=np.int32), np.asfortranarray(F, dtype=np.int32)
+            base_host = best(lambda: sccd.ccd(hV0, hV1, hE, hF, 0.0, -1, 1e-6, True, ctx=ctx))
+            base_step = best(lambda: sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True), 5)
+            cliffs = {"default_step_ms": base_step, "default_host_path_ms": base_host}
+            cliffs["collisions_host_path_ms"] = best(lambda: sccd.ccd(hV0, hV1, hE, hF, 0.0, -1, 1e-6, True, ctx=ctx, want_collisions=True))
+            cliffs["collisions_max_iter_1e7_host_path_ms"] = best(lambda: sccd.ccd(hV0, hV1, hE, hF, 0.0, 10_000_000, 1e-6, True, ctx=ctx, want_collisions=True))
+            cliffs["collisions_max_iter_1000_host_path_ms"] = best(lambda: sccd.ccd(hV0, hV1, hE, hF, 0.0, 1000, 1e-6, True, ctx=ctx, want_collisions=True))
+            cliffs["max_iter_1e7_step_ms"] = best(lambda: sccd.ccd_mesh(mesh, 0.0, 10_000_000, 1e-6, True), 5)
+            ctx.set_option(sccd.OPT_LIMIT_LEVEL_ORDER, 1)
+            cliffs["max_iter_1e7_level_order_step_ms"] = best(lambda: sccd.ccd_mesh(mesh, 0.0, 10_000_000, 1e-6, True), 2)
+            ctx.set_option(sccd.OPT_LIMIT_LEVEL_ORDER, 0)
+            cliffs["max_iter_100_step_ms"] = best(lambda: sccd.ccd_mesh(mesh, 0.0, 100, 1e-6, True), 2)  # below 4096: level order
+            ctx.set_option(sccd.OPT_SCALAR, 1)
+            cliffs["float_build_step_ms"] = best(lambda: sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True), 2)
+            ctx.set_option(sccd.OPT_SCALAR, 0)
+            cliffs["note"] = ("host_path: sccd_ccd() from pageable host matrices (upload inside the call), collisions = the SCALABLE_CCD_TOI_PER_QUERY signature; "
+                              "step: sccd_ccd_mesh() on the resident mesh; best of 3 / 5 / 2")
         result = {
             "metric": "CCD queries/sec (broad+narrow)", "value": value, "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -347,6 +381,7 @@ def main():
             "host_path_note": "sccd_ccd() from pageable host matrices, upload and packing inside the call (best of 5; the reference's ccd() uploads inside the call too, ccd.cu:103-106); one rank only",
             "max_iter": args.max_iter,
             "broad_phase": broad,
+            "cliffs": cliffs,
             "rank_max": rank_max,
             "roofline": roofline,
         }

@@ -60,6 +60,10 @@ using MatrixXiView = ConstMatrixView<int32_t>;
 
 /// One device + stream + scratch memory.  The reference keeps this state in globals
 /// (device_init_id, __constant__ CONFIG); here it is explicit and defaulted.
+/// A Context is SINGLE-THREADED: one call at a time (the reference's globals are no different), and narrow_phase() /
+/// ccd() calls on one Context are not re-entrant -- the packed mesh behind the four-DeviceMatrix argument list
+/// (call_mesh) is ONE object owned by the Context, refilled by every such call; a call that fails on bad indices leaves
+/// it holding clamped indices until the next call refills it.  Threads that run CCD concurrently each make their own Context.
 class Context {
 public:
     explicit Context(int device = 0)

@@ -158,6 +158,9 @@ struct sccd_ctx {
     // a narrow-phase call with a check limit that runs on the fast kernel (narrow.hip: the certificate): the TOI it started from
     bool np_limit_fast = false;
     double np_toi_init = 0;
+    // per-query output WITH a check limit, served by the fast kernel without the limit: narrow_phase_end redoes the queries that
+    // reported an impact -- and only those -- in the reference's level order with the limit (narrow.hip)
+    bool np_pq_limit = false;
     int64_t max_overlap_cutoff = 0;
     int64_t memory_limit_mb = 0;
 
@@ -173,6 +176,9 @@ struct sccd_ctx {
 
     // scratch shared by the pipeline stages
     DevBuf sort_tmp_keys, sort_tmp_vals, sort_hist, sort_status;
+    // ccd() with the collision list: per-query TOIs of a pass, the compacted records and their query numbers (kept between calls:
+    // five allocations and frees per pass were most of a 9.7 ms call on the 1M-triangle cloth)
+    DevBuf col_pq, col_out, col_idx;
     DevBuf scalars;      // small device-side counters block
     PinnedBuf h_scalars; // pinned mirror for async read-back
     DevBuf np_scratch0, np_scratch1, np_scratch2, np_scratch3, np_scratch4, np_scratch3_ovf;

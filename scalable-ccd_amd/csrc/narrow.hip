@@ -349,6 +349,35 @@ __global__ void np_fetch_query_k(const double* __restrict__ V, const int2* __res
         for (int k = 0; k < 3; k++) out[3 * a + k] = v[a][k];
 }
 
+// per-query output with a check limit: the queries whose unlimited bisection reported an impact (finite per-query TOI) ...
+__global__ void np_select_finite_k(const double* __restrict__ per_query, long long n, int* __restrict__ list, unsigned* __restrict__ count)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool hit = i < n && per_query[i] < __builtin_huge_val();
+    const unsigned long long m = __ballot(hit);
+    __shared__ unsigned s_cnt[16], s_base; // (one atomic per block of 1024 queries, not per wave: the counter is one hot word)
+    const int w = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+    if (lane_id() == 0) s_cnt[w] = (unsigned)popc64(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned sum = 0;
+        for (int k = 0; k < nw; k++) {
+            const unsigned v = s_cnt[k];
+            s_cnt[k] = sum;
+            sum += v;
+        }
+        s_base = sum ? atomicAdd(count, sum) : 0u;
+    }
+    __syncthreads();
+    if (hit) list[s_base + s_cnt[w] + (unsigned)mbcnt64(m)] = (int)i;
+}
+// ... start again from "no impact" before they are redone in level order with the limit
+__global__ void np_reset_selected_k(double* __restrict__ per_query, const int* __restrict__ list, unsigned n_sel)
+{
+    const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_sel) per_query[list[j]] = __builtin_huge_val();
+}
+
 } // namespace
 
 #include "narrow_walk.inc"
@@ -371,8 +400,11 @@ bool narrow_uses_walk_kernel(const sccd_ctx* c, const NarrowParams& p, bool per_
 {
     (void)per_query;
     // (check limits below SCCD_QUEUE_MIN_MAX_ITER cut queries off as a rule: straight to level order)
+    // (per-query output with a limit: every query is pruned by its OWN earliest impact only (root_finder.cu:297), so the
+    // queries are independent -- the fast kernel finds those that report an impact at all, narrow_phase_end redoes exactly those
+    // in level order with the limit; any limit, small ones too)
     return !(c->narrow_algo == 1 || c->scalar_f32 // (the work-queue kernel is double only)
-             || (p.max_iter >= 0 && (p.max_iter < SCCD_QUEUE_MIN_MAX_ITER || per_query || c->limit_level_order)));
+             || (p.max_iter >= 0 && (c->limit_level_order || (!per_query && p.max_iter < SCCD_QUEUE_MIN_MAX_ITER))));
 }
 
 void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, const double* h_toi_inout,
@@ -381,6 +413,7 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
     // toi is in/out and must be >= 0 (narrow_phase.cu:126)
     SCCD_REQUIRE(*h_toi_inout >= 0, "narrow_phase: toi must be >= 0");
     c->np_limit_fast = false; // (context-sticky between begin and end: a begin whose end never came must not leave it set)
+    c->np_pq_limit = false;
     // pinned mirror: [8 KB, 12 KB) the counters handed to the caller, [12 KB, 16 KB) the upload source
     if (!(c->np_uploaded && std::memcmp(&c->np_uploaded_toi, h_toi_inout, 8) == 0)) narrow_counters_upload(c, d_cnt, *h_toi_inout);
     c->np_uploaded = false;
@@ -426,7 +459,17 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
                                    reinterpret_cast<unsigned long long*>(d_per_query_toi), n, 0x7FF0000000000000ull);
                 SCCD_HIP(hipGetLastError());
             }
-            if (p.max_iter >= 0) { // the fast kernel WITHOUT the limit, recording who lowered the TOI (behind the overflow list)
+            if (p.max_iter >= 0 && d_per_query_toi) {
+                // per-query output with a limit: the fast kernel WITHOUT the limit (bookkeeping instantiation, listing queries
+                // beyond level 31 itself); narrow_phase_end redoes the queries that report an impact with the limit
+                const unsigned cap = (unsigned)std::min<long long>(n, 1 << 20);
+                c->np_scratch3_ovf.ensure(sizeof(int) * (size_t)cap);
+                NarrowParams pn = p;
+                pn.max_iter = -1;
+                c->np_toi_init = *h_toi_inout;
+                run_walk(c, pn, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi), c->np_scratch3_ovf.as<int>(), cap);
+                c->np_pq_limit = true;
+            } else if (p.max_iter >= 0) { // the fast kernel WITHOUT the limit, recording who lowered the TOI (behind the overflow list)
                 const unsigned cap = (unsigned)std::min<long long>(std::max<long long>(n, 1024), 1 << 20);
                 c->np_scratch3_ovf.ensure(sizeof(int) * 4 * (size_t)cap + 256);
                 NarrowParams pn = p;
@@ -602,6 +645,44 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
             SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
             SCCD_HIP(hipStreamSynchronize(c->stream));
             if (h.overflow) throw SccdError { SCCD_E_OVERFLOW, "narrow phase: work queue capacity exhausted" };
+        }
+    }
+    if (c->np_pq_limit && d_per_query_toi && n > 0) {
+        // ---- per-query output with a check limit.  The reference counts the domains a query pops in LEVEL order and drops the
+        // query past the limit (root_finder.cu:287-305); with per-query output a query is pruned by its own earliest impact only
+        // (:297), so its bisection does not depend on any other query.  The fast kernel ran every query WITHOUT the limit: a
+        // query that reported no impact has no accepted domain at all, with or without a limit; the queries that did report
+        // one -- a few thousand of millions -- are redone, alone among themselves, by the level-synchronous kernels with the
+        // limit, from "no impact".  The same values as the whole call in level order, bit for bit, at a few per cent of its cost.
+        c->np_pq_limit = false;
+        const double toi_init = c->np_toi_init;
+        c->np_scratch3_ovf.ensure(sizeof(int) * (size_t)n + 256);
+        int* const d_list = c->np_scratch3_ovf.as<int>();
+        unsigned* const d_count = reinterpret_cast<unsigned*>(c->np_scratch3_ovf.as<char>() + sizeof(int) * (size_t)n + 64);
+        SCCD_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned), c->stream));
+        hipLaunchKernelGGL(np_select_finite_k, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, c->stream, d_per_query_toi, n, d_list, d_count);
+        SCCD_HIP(hipGetLastError());
+        unsigned n_sel = 0;
+        {
+            ReadBack rb(c);
+            rb.add(&n_sel, d_count, sizeof n_sel);
+            rb.sync();
+        }
+        const unsigned long long checks_so_far = h.n_checks;
+        std::memcpy(&h.toi_bits, &toi_init, 8); // (nothing accepted anywhere: the TOI the call started with)
+        if (n_sel > 0) {
+            hipLaunchKernelGGL(np_reset_selected_k, dim3((n_sel + 255) / 256), dim3(256), 0, c->stream, d_per_query_toi, d_list, n_sel);
+            NarrowCounters h2;
+            std::memset(&h2, 0, sizeof h2);
+            std::memcpy(&h2.toi_bits, &toi_init, 8);
+            SCCD_HIP(hipMemcpyAsync(d_cnt, &h2, sizeof h2, hipMemcpyHostToDevice, c->stream));
+            SCCD_HIP(hipStreamSynchronize(c->stream)); // (h2 is on the stack)
+            if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi, d_list, (long long)n_sel);
+            else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi, d_list, (long long)n_sel);
+            SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            SCCD_HIP(hipStreamSynchronize(c->stream));
+            if (h.overflow) throw SccdError { SCCD_E_OVERFLOW, "narrow phase: work queue capacity exhausted" };
+            h.n_checks += checks_so_far;
         }
     }
     std::memcpy(h_toi_inout, &h.toi_bits, 8);

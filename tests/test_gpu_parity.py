@@ -842,16 +842,21 @@ def test_check_limits_follow_the_reference_level_order(sccd, ctx, orc, arith):
     try:
         ctx.set_option(sccd.OPT_ARITH, arith)
         seen = set()
-        for k in (50, 500, 5000):
+        for k in (0, 7, 50, 500, 5000, 20000):
             want = orc.ccd(V0, V1, E, F, 0.0, k, 1e-6, True, arith=arith)[0]
             assert sccd.ccd_mesh(mesh, 0.0, k, 1e-6, True) == want, k
             seen.add(want)
             want_t, want_pq, _ = orc.narrow_phase(V0, V1, E, F, pv, True, 0.0, k, 1e-6, True, arith=arith, per_query=True)
-            got_t, col = sccd.narrow_phase(mesh, pv, True, k, 1e-6, 0.0, True, want_collisions=True)
-            assert got_t == want_t, k
-            hit = want_pq < 1
-            assert len(col) == int(hit.sum()), k
-            assert np.array_equal(col["toi"], want_pq[hit]), k
+            # per-query output with a limit: the fast kernel without the limit, then ONLY the queries that reported an impact
+            # redone in level order with it (narrow.hip) -- and, the cross-check, the whole call in level order
+            for level_order in (0, 1):
+                ctx.set_option(sccd.OPT_LIMIT_LEVEL_ORDER, level_order)
+                got_t, col = sccd.narrow_phase(mesh, pv, True, k, 1e-6, 0.0, True, want_collisions=True)
+                ctx.set_option(sccd.OPT_LIMIT_LEVEL_ORDER, 0)
+                assert got_t == want_t, (k, level_order)
+                hit = want_pq < 1
+                assert len(col) == int(hit.sum()), (k, level_order)
+                assert np.array_equal(col["toi"], want_pq[hit]), (k, level_order)
         assert len(seen) >= 2  # different limits, different answers: the test can tell them apart
     finally:
         ctx.set_option(sccd.OPT_ARITH, sccd.ARITH_DEFAULT)

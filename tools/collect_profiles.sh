@@ -1,18 +1,18 @@
-# Refresh profiles/ for the CURRENT build (run on the GPU box): bash tools/collect_profiles.sh [round tag, default r03]
+# Refresh profiles/ for the CURRENT build (run on the GPU box): bash tools/collect_profiles.sh [round tag, default r04]
 # Everything lands in gpurun_out/prof/; copy what is to be kept into profiles/ afterwards (the PMC traffic files carry
 # the hash of the library they were taken on: bench.py quotes them only for that very build).
-R=${1:-r03}
+R=${1:-r04}
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
 for W in cloth1m boxes1m sort16m; do
   rm -rf gpurun_out/prof/ks_$W
-  rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_$W --output-format csv -- python3 bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof/ks_$W.log 2>&1
-  cp $(ls gpurun_out/prof/ks_$W/*/*kernel_stats.csv | tail -1) gpurun_out/prof/${R}_${W}_kernel_stats.csv
+  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_$W --output-format csv -- python3 bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof/ks_$W.log 2>&1
+  cp $(ls gpurun_out/prof/ks_$W/*/*kernel_stats.csv | tail -n 1) gpurun_out/prof/${R}_${W}_kernel_stats.csv
 done
 # (the default step overlaps two streams: each kernel's own duration, one kernel at a time on the chip, is in this trace)
 rm -rf gpurun_out/prof/ks_cloth1m_apart
-SCCD_OVERLAP=0 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_cloth1m_apart --output-format csv -- python3 bench.py --workload cloth1m --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof/ks_cloth1m_apart.log 2>&1
+SCCD_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_cloth1m_apart --output-format csv -- python3 bench.py --workload cloth1m --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof/ks_cloth1m_apart.log 2>&1
 cp $(ls gpurun_out/prof/ks_cloth1m_apart/*/*kernel_stats.csv | tail -1) gpurun_out/prof/${R}_cloth1m_passes_apart_kernel_stats.csv
 for W in cloth1m sort16m boxes1m; do
   bash tools/pmc_traffic.sh $W > gpurun_out/prof/pmc_traffic_$W.txt 2>&1
@@ -23,22 +23,22 @@ SCCD_OVERLAP=0 bash tools/pmc_sq.sh cloth1m > gpurun_out/prof/pmc_sq_cloth1m.txt
 cp gpurun_out/pmc_sq_cloth1m.json gpurun_out/prof/${R}_pmc_sq_cloth1m.json
 bash tools/pmc_sq.sh boxes1m > gpurun_out/prof/pmc_sq_boxes1m.txt 2>&1
 cp gpurun_out/pmc_sq_boxes1m.json gpurun_out/prof/${R}_pmc_sq_boxes1m.json
-python3 tools/shard_balance.py --profile > gpurun_out/prof/${R}_shard_balance.log 2>&1
+timeout 600 python3 tools/shard_balance.py --profile > gpurun_out/prof/${R}_shard_balance.log 2>&1
 # the lines bench.py prints once the traffic files are in place (same build: the hashes match)
 cp gpurun_out/prof/${R}_pmc_traffic_*.json gpurun_out/prof/${R}_pmc_sq_*.json profiles/ 2>/dev/null
 for W in cloth1m boxes1m sort16m clothball10k; do
-  python3 bench.py --workload $W 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_$W.json.log
+  timeout 600 python3 bench.py --workload $W 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_$W.json.log
 done
-SCCD_OVERLAP=0 python3 bench.py --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_passes_apart.json.log
-python3 bench.py --no-cpu-baseline --max-iter 10000000 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_max_iter_1e7.json.log
-python3 bench.py --workload boxes1m --boxes-variant thin 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_boxes1m_thin.json.log
-python3 bench.py --workload boxes1m --boxes-n 16000000 --steps 10 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_boxes16m.json.log
+SCCD_OVERLAP=0 timeout 600 python3 bench.py --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_passes_apart.json.log
+timeout 600 python3 bench.py --no-cpu-baseline --max-iter 10000000 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_max_iter_1e7.json.log
+timeout 600 python3 bench.py --workload boxes1m --boxes-variant thin 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_boxes1m_thin.json.log
+timeout 600 python3 bench.py --workload boxes1m --boxes-n 16000000 --steps 10 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_boxes16m.json.log
 # SURVEY 8d's other C3 shapes: kernel stats and HBM traffic
 for V in "thin --boxes-variant thin" "16m --boxes-n 16000000"; do
   set -- $V; T=$1; shift
   rm -rf gpurun_out/prof/ks_boxes_$T
-  rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_boxes_$T --output-format csv -- python3 bench.py --workload boxes1m "$@" --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof/ks_boxes_$T.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_boxes_$T --output-format csv -- python3 bench.py --workload boxes1m "$@" --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof/ks_boxes_$T.log 2>&1
   cp $(ls gpurun_out/prof/ks_boxes_$T/*/*kernel_stats.csv | tail -1) gpurun_out/prof/${R}_boxes_${T}_kernel_stats.csv
 done
-python3 tools/boxes_variants.py > gpurun_out/prof/${R}_boxes_variants.log 2>&1
+timeout 600 python3 tools/boxes_variants.py > gpurun_out/prof/${R}_boxes_variants.log 2>&1
 ls -la gpurun_out/prof

@@ -1,6 +1,6 @@
 # per-kernel device time of one bench workload (3 timed + 1 warm-up + 2 profiled steps = 6 steps in the trace): bash tools/kstats.sh <workload> [extra bench args]
 W=${1:-cloth1m}; shift
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rm -rf gpurun_out/kstats && rocprofv3 --kernel-trace --stats -d gpurun_out/kstats --output-format csv -- python3 bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/kstats.log 2>&1
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rm -rf gpurun_out/kstats && timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/kstats --output-format csv -- python3 bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/kstats.log 2>&1
 python3 - <<PY
 import csv,glob
 f=sorted(glob.glob("gpurun_out/kstats/*/*kernel_stats.csv"))[-1]
