@@ -382,6 +382,137 @@ __global__ void np_reset_selected_k(double* __restrict__ per_query, const int* _
 
 #include "narrow_walk.inc"
 
+// ------------------------------------------------------------------------------------------
+// The FLOAT build (SCCD_OPT_SCALAR = 1, the reference's SCALABLE_CCD_USE_DOUBLE = OFF) depth first: one lane = one query at a
+// time from the lane's own strided share of the list, walked to its end with the stackless walk of ti_math.hpp (NQDom / NQWalk:
+// which dimension a node is split in depends on its depth alone in float, too) and the float arithmetic of ti_math_f32.hpp
+// (tif_step: the operations of root_finder.cu:137-254 in float, in the reference's order).  No queues, no staging, no work
+// sharing -- a float query is 30 registers, so a SIMD holds five or more waves and their divergence is covered by occupancy
+// rather than by machinery -- and 20 x faster than the level-synchronous kernels that served the float build until round 4
+// (14 ms per step on the 1M-triangle cloth: one launch and one read-back per level, every live domain in HBM).
+// An interval [k 2^-d, (k + 1) 2^-d] and its mid-point are exact in float while k < 2^23: a query that bisects a dimension
+// past level NF_MAX_LEVEL is LISTED (and dropped) and redone in level order by narrow_phase_end, like the double kernel's
+// level-31 queries.  The result is the minimum over accepted domains either way (Appendix A.20): bit-equal to the oracle's
+// float twin.  PQ: per-query output (a query is pruned by its own earliest impact only, root_finder.cu:297).
+constexpr unsigned NF_MAX_LEVEL = 23;
+constexpr int NF_REFILL_MIN = 12; // idle lanes that trigger a refill (or: nobody works) -- the refill's code runs for the whole wave
+template <bool VF, int ARITH, bool PQ>
+__global__ __launch_bounds__(256) void np_walk_f32_k(const double* __restrict__ V, const int2* __restrict__ E, const int4* __restrict__ F,
+                                                     const int2* __restrict__ pairs, long long n, float ms, float tol, bool use_ms,
+                                                     bool allow_zero_toi, NarrowCounters* __restrict__ cnt,
+                                                     unsigned long long* __restrict__ per_query, int* __restrict__ ovf_list,
+                                                     unsigned ovf_cap, unsigned long long* __restrict__ toi_word)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long next = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    TIQueryF q;
+    NQDom dom = { 0u, 0u, 0u, 0u };
+    NQWalk walk = { { 0ull, 0u }, { 0ull, 0u }, { 0ull, 0u } };
+    bool has_q = false;
+    float qtoi = __builtin_huge_valf();
+    long long qid = 0;
+    float toi = (float)toi_load(toi_word); // (every stored TOI is a float, widened: the casts are exact)
+    unsigned step = 0, checks = 0;
+    for (;;) {
+        const bool want = !has_q && next < n;
+        const unsigned long long wants = __ballot(want), busy = __ballot(has_q);
+        if (wants != 0 && (busy == 0 || popc64(wants) >= NF_REFILL_MIN)) {
+            if (want) {
+                double vd[8][3];
+                ti_gather<VF>(V, E, F, pairs[next], vd);
+#pragma unroll
+                for (int a = 0; a < 8; a++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) q.v[a][k] = (float)vd[a][k]; // vertices cast to float FIRST (ccd.cu:103-106)
+                tif_tolerance<VF>(q.v, tol, q.tol);
+                tif_error<VF>(q.v, use_ms, q.err);
+                dom = NQDom { 0u, 0u, 0u, 0u };
+                walk = NQWalk { { 0ull, 0u }, { 0ull, 0u }, { 0ull, 0u } };
+                qid = next;
+                qtoi = __builtin_huge_valf();
+                has_q = true;
+                next += stride;
+            }
+        } else if (busy == 0) {
+            break; // nobody works, nobody has anything left to take
+        }
+        if ((++step & 15u) == 0u) toi = (float)toi_load(toi_word);
+        if (has_q) {
+            float lo[3], hi[3];
+            {
+                const unsigned d0 = dom.d & 255u, d1 = (dom.d >> 8) & 255u, d2 = (dom.d >> 16) & 255u;
+                lo[0] = ldexpf((float)dom.k0, -(int)d0);
+                hi[0] = lo[0] + ldexpf(1.0f, -(int)d0);
+                lo[1] = ldexpf((float)dom.k1, -(int)d1);
+                hi[1] = lo[1] + ldexpf(1.0f, -(int)d1);
+                lo[2] = ldexpf((float)dom.k2, -(int)d2);
+                hi[2] = lo[2] + ldexpf(1.0f, -(int)d2);
+            }
+            const TIStepF s = tif_step<VF, ARITH>(q, lo, hi, ms, tol, allow_zero_toi, PQ ? qtoi : toi);
+            checks += s.checked ? 1u : 0u;
+            if (s.accept) {
+                if (PQ && lo[0] < qtoi) {
+                    qtoi = lo[0];
+                    atomicMin(&per_query[qid], (unsigned long long)__double_as_longlong((double)lo[0]));
+                }
+                if (lo[0] < toi) {
+                    toi = lo[0];
+                    toi_min(toi_word, (double)lo[0]);
+                }
+            }
+            if (s.nk >= 1) {
+                const unsigned nd = dom.d + (1u << (8 * s.split));
+                if (((nd >> (8 * s.split)) & 255u) > NF_MAX_LEVEL) {
+                    // the halves are no longer exact floats of the form k 2^-d: the whole query is redone in level order
+                    const unsigned at = atomicAdd(&cnt->n_ovf, 1u);
+                    if (at < ovf_cap) ovf_list[at] = (int)qid;
+                    has_q = false;
+                } else {
+                    dom = nq_descend(walk, dom, s.split, s.nk == 2);
+                }
+            } else if (nqb_any(walk.pend)) {
+                dom = nq_backtrack(walk, dom);
+            } else {
+                has_q = false;
+            }
+        }
+    }
+    unsigned long long c64 = checks;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o, 64);
+    if (lane_id() == 0 && c64) atomicAdd(&cnt->checks_part[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 7].n, c64);
+}
+
+// ovf_list / ovf_cap: where queries beyond level NF_MAX_LEVEL are listed (always given: narrow_phase_end redoes them in level order)
+static void run_walk_f32(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, long long n, unsigned long long* per_query,
+                         int* ovf_list, unsigned ovf_cap)
+{
+    SCCD_REQUIRE(n < (1ll << 31) - 4096, "narrow phase: at most 2^31 - 4097 queries per launch");
+    // (lane-per-query streams: enough waves to fill the chip several times over -- a wave is as slow as its slowest lane)
+    const long long want_blocks = (n + 255) / 256;
+    const int blocks = (int)std::max<long long>(1, std::min<long long>(want_blocks, (long long)c->num_cus * 16));
+    const dim3 grid((unsigned)blocks), block(256);
+    unsigned long long* const tw = p.toi_word ? p.toi_word : &d_cnt->toi_bits;
+#define SCCD_LAUNCH_NF(VF_, AR_, PQ_)                                                                                               \
+    hipLaunchKernelGGL((np_walk_f32_k<VF_, AR_, PQ_>), grid, block, 0, c->stream, p.V, p.E, p.F, p.pairs, n, (float)p.ms, (float)p.tol, \
+                       p.ms > 0, (bool)p.allow_zero_toi, d_cnt, per_query, ovf_list, ovf_cap, tw)
+#define SCCD_LAUNCH_NF2(VF_, AR_)                  \
+    do {                                           \
+        if (per_query) SCCD_LAUNCH_NF(VF_, AR_, true); \
+        else SCCD_LAUNCH_NF(VF_, AR_, false);      \
+    } while (0)
+    if (p.is_vf) {
+        if (p.arith == 1) SCCD_LAUNCH_NF2(true, 1);
+        else SCCD_LAUNCH_NF2(true, 0);
+    } else {
+        if (p.arith == 1) SCCD_LAUNCH_NF2(false, 1);
+        else SCCD_LAUNCH_NF2(false, 0);
+    }
+#undef SCCD_LAUNCH_NF2
+#undef SCCD_LAUNCH_NF
+    SCCD_HIP(hipGetLastError());
+}
+
 // counters = {zeros, toi}: from the pinned mirror [12 KB, 16 KB)
 void narrow_counters_upload(sccd_ctx* c, NarrowCounters* d_cnt, double toi)
 {
@@ -403,7 +534,9 @@ bool narrow_uses_walk_kernel(const sccd_ctx* c, const NarrowParams& p, bool per_
     // (per-query output with a limit: every query is pruned by its OWN earliest impact only (root_finder.cu:297), so the
     // queries are independent -- the fast kernel finds those that report an impact at all, narrow_phase_end redoes exactly those
     // in level order with the limit; any limit, small ones too)
-    return !(c->narrow_algo == 1 || c->scalar_f32 // (the work-queue kernel is double only)
+    // (the float build: its own depth-first kernel, np_walk_f32_k -- without a check limit; limits stay in level order there)
+    if (c->scalar_f32) return c->narrow_algo != 1 && p.max_iter < 0;
+    return !(c->narrow_algo == 1
              || (p.max_iter >= 0 && (c->limit_level_order || (!per_query && p.max_iter < SCCD_QUEUE_MIN_MAX_ITER))));
 }
 
@@ -459,7 +592,11 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
                                    reinterpret_cast<unsigned long long*>(d_per_query_toi), n, 0x7FF0000000000000ull);
                 SCCD_HIP(hipGetLastError());
             }
-            if (p.max_iter >= 0 && d_per_query_toi) {
+            if (c->scalar_f32) { // (no limit: narrow_uses_walk_kernel) the float build's depth-first kernel; it lists what it cannot hold
+                const unsigned cap = (unsigned)std::min<long long>(n, 1 << 20);
+                c->np_scratch3_ovf.ensure(sizeof(int) * (size_t)cap);
+                run_walk_f32(c, p, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi), c->np_scratch3_ovf.as<int>(), cap);
+            } else if (p.max_iter >= 0 && d_per_query_toi) {
                 // per-query output with a limit: the fast kernel WITHOUT the limit (bookkeeping instantiation, listing queries
                 // beyond level 31 itself); narrow_phase_end redoes the queries that report an impact with the limit
                 const unsigned cap = (unsigned)std::min<long long>(n, 1 << 20);

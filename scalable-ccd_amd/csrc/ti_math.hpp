@@ -823,16 +823,18 @@ __device__ __forceinline__ NQStep nw_step(const NWQuery& q, const NQDom& dm, dou
     const bool splits = live & in & !acc;
     const int split = nw_split_of(q, w);
     r.split = split;
-    const double slo = split == 0 ? lo[0] : (split == 1 ? lo[1] : lo[2]);
-    const double sw = split == 0 ? w[0] : (split == 1 ? w[1] : w[2]);
-    const double mid = slo + 0.5 * sw; // = (lo + hi) / 2, exact
     bool second;
     if (VF) {
+        const double slo = split == 0 ? lo[0] : (split == 1 ? lo[1] : lo[2]);
+        const double sw = split == 0 ? w[0] : (split == 1 ? w[1] : w[2]);
+        const double mid = slo + 0.5 * sw; // = (lo + hi) / 2, exact
         const double other = (split == 1) ? lo[2] : lo[1];
         second = split == 0 ? (mid <= prune_toi)                              // :229-232
                             : ((mid + other) <= 1 / (1 - TI_DBL_EPS));        // sum_less_than_one :21-29
     } else {
-        second = split == 0 ? (mid <= prune_toi) : true; // :248-250
+        // (edge-edge: the mid-point matters for a split in time only -- no selects over the three dimensions)
+        const double mid_t = lo[0] + 0.5 * w[0];
+        second = split == 0 ? (mid_t <= prune_toi) : true; // :229-232, :248-250
     }
     r.nk = splits ? (second ? 2 : 1) : 0;
     return r;

@@ -1124,9 +1124,28 @@ def test_float_build_matches_the_oracle_twin(sccd, ctx, orc, arith):
             assert np.array_equal(_sorted(bp.detect_overlaps()), want_vf)
             bp.build(sccd.DeviceAABBs(eb, ctx))
             assert np.array_equal(_sorted(bp.detect_overlaps()), want_ee)
-            toi = sccd.ccd(V0, V1, E, F, ms, -1, 1e-6, True, ctx=ctx)
+            toi = sccd.ccd(V0, V1, E, F, ms, -1, 1e-6, True, ctx=ctx)  # the float build's depth-first kernel (np_walk_f32_k)
             assert toi == want_toi and toi == float(np.float32(toi))
+            ctx.set_option(sccd.OPT_NARROW_ALGO, 1)  # ... and the level-synchronous kernels
+            assert sccd.ccd(V0, V1, E, F, ms, -1, 1e-6, True, ctx=ctx) == want_toi
+            ctx.set_option(sccd.OPT_NARROW_ALGO, 0)
+            # per-query output in float: every reported impact is the oracle twin's, both ways
+            mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+            want_t, want_pq, _ = orc.narrow_phase(V0, V1, E, F, want_vf, True, ms=ms, arith=arith, per_query=True, scalar="f32")
+            for algo in (0, 1):
+                ctx.set_option(sccd.OPT_NARROW_ALGO, algo)
+                got_t, col = sccd.narrow_phase(mesh, want_vf, True, -1, 1e-6, ms, True, want_collisions=True)
+                ctx.set_option(sccd.OPT_NARROW_ALGO, 0)
+                hit = want_pq < 1
+                assert got_t == want_t and len(col) == int(hit.sum()), algo
+                assert np.array_equal(col["toi"], want_pq[hit].astype(np.float64)), algo
+            # a tolerance that drives the bisection past level 23 (floats of the form k 2^-d end there): those queries are
+            # listed by the kernel and redone in level order -- the same TOI as level order throughout
+            tiny = orc.ccd(V0, V1, E, F, ms, -1, 1e-9, True, arith=arith, nthreads=4, scalar="f32")[0]
+            assert sccd.ccd(V0, V1, E, F, ms, -1, 1e-9, True, ctx=ctx) == tiny
+            mesh.close()
         finally:
+            ctx.set_option(sccd.OPT_NARROW_ALGO, 0)
             ctx.set_option(sccd.OPT_SCALAR, 0)
             ctx.set_option(sccd.OPT_ARITH, sccd.ARITH_DEFAULT)
 

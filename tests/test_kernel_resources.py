@@ -34,6 +34,11 @@ def test_walk_kernels_keep_three_waves_per_simd_without_scratch(tmp_path):
         assert r["private_segment_fixed_size"] == 0, (name, r)
         assert r["next_free_vgpr"] <= 168, (name, r)  # 512 / 3 waves, allocation granule 8
         assert r["group_segment_fixed_size"] <= 13 * 1024, (name, r)  # twelve one-wave blocks per CU
+    # the float build's depth-first kernel: three waves per SIMD or more, no scratch
+    f32 = {k: v for k, v in ks.items() if "np_walk_f32_k" in k}
+    assert len(f32) == 8
+    for name, r in f32.items():
+        assert r["private_segment_fixed_size"] == 0 and r["next_free_vgpr"] <= 168, (name, r)
     # the bookkeeping kernels (two waves per SIMD) must not spill either
     book = {k: v for k, v in ks.items() if re.match(r"_Z9np_walk_kILb[01]ELi[01]ELi1EE", k)}
     for name, r in book.items():
