@@ -483,6 +483,112 @@ __global__ __launch_bounds__(256) void np_walk_f32_k(const double* __restrict__ 
     if (lane_id() == 0 && c64) atomicAdd(&cnt->checks_part[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 7].n, c64);
 }
 
+// The queries np_walk_f32_k listed (their bisection passes level NF_MAX_LEVEL: scenes whose coordinates are large against
+// the tolerance) depth first with an EXPLICIT stack of float (lo, hi) boxes in HBM: beyond that level an interval is no longer
+// k 2^-d in float, so the boxes are carried as the reference carries them (SplitInterval, interval.cuh:18-28: mid = (lo + hi) / 2
+// in float) -- tif_step on them is the reference's kernel body operation for operation.  One lane per listed query; a stack of
+// NF_STACK boxes each (a depth-first stack holds at most one box per level of the tree and Condition 4 ends the tree where a
+// float interval cannot be halved any more; a stack that fills up raises the overflow flag and the call falls back to level
+// order).  Level order on these queries -- what round 3 did for the whole float build -- keeps every live domain of a level in
+// HBM and outgrew any budget on 10 % of the soak's scaled scenes; the traversal cannot change the result without a check
+// limit (Appendix A.20).
+constexpr int NF_STACK = 160;
+struct NFBox {
+    float lo[3], hi[3];
+};
+template <bool VF, int ARITH, bool PQ>
+__global__ __launch_bounds__(64) void np_dfs_f32_k(const double* __restrict__ V, const int2* __restrict__ E, const int4* __restrict__ F,
+                                                   const int2* __restrict__ pairs, const int* __restrict__ sel, unsigned n_sel, float ms,
+                                                   float tol, bool use_ms, bool allow_zero_toi, NarrowCounters* __restrict__ cnt,
+                                                   unsigned long long* __restrict__ per_query, NFBox* __restrict__ stacks,
+                                                   unsigned long long* __restrict__ toi_word)
+{
+    const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_sel) return;
+    const int qid = sel[j];
+    TIQueryF q;
+    {
+        double vd[8][3];
+        ti_gather<VF>(V, E, F, pairs[qid], vd);
+#pragma unroll
+        for (int a = 0; a < 8; a++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) q.v[a][k] = (float)vd[a][k];
+    }
+    tif_tolerance<VF>(q.v, tol, q.tol);
+    tif_error<VF>(q.v, use_ms, q.err);
+    NFBox* const st = stacks + (size_t)j * NF_STACK;
+    int top = 0;
+    st[top++] = NFBox { { 0.0f, 0.0f, 0.0f }, { 1.0f, 1.0f, 1.0f } };
+    float toi = (float)toi_load(toi_word);
+    float qtoi = PQ ? (float)__longlong_as_double((long long)per_query[qid]) : __builtin_huge_valf(); // (what the first pass found stays valid)
+    unsigned step = 0;
+    unsigned long long checks = 0;
+    while (top > 0) {
+        if ((++step & 15u) == 0u) toi = (float)toi_load(toi_word);
+        const NFBox d = st[--top];
+        const TIStepF s = tif_step<VF, ARITH>(q, d.lo, d.hi, ms, tol, allow_zero_toi, PQ ? qtoi : toi);
+        checks += s.checked ? 1u : 0u;
+        if (s.accept) {
+            if (PQ && d.lo[0] < qtoi) {
+                qtoi = d.lo[0];
+                atomicMin(&per_query[qid], (unsigned long long)__double_as_longlong((double)d.lo[0]));
+            }
+            if (d.lo[0] < toi) {
+                toi = d.lo[0];
+                toi_min(toi_word, (double)d.lo[0]);
+            }
+        }
+        if (s.nk >= 1) {
+            if (top + 2 > NF_STACK) { // (cannot happen on a tree that Condition 4 bounds; never write past the stack)
+                atomicOr(&cnt->overflow, 1u);
+                break;
+            }
+            // later half first, so that the earlier half is popped first (the walk kernels' order)
+            if (s.nk == 2) {
+                NFBox c2 = d;
+                if (s.split == 0) c2.lo[0] = s.mid;
+                else if (s.split == 1) c2.lo[1] = s.mid;
+                else c2.lo[2] = s.mid;
+                st[top++] = c2;
+            }
+            NFBox c1 = d;
+            if (s.split == 0) c1.hi[0] = s.mid;
+            else if (s.split == 1) c1.hi[1] = s.mid;
+            else c1.hi[2] = s.mid;
+            st[top++] = c1;
+        }
+    }
+    if (checks) atomicAdd(&cnt->n_checks, checks);
+}
+static void run_dfs_f32(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, const int* d_sel, unsigned n_sel,
+                        unsigned long long* per_query)
+{
+    if (n_sel == 0) return;
+    c->np_scratch1.ensure(sizeof(NFBox) * (size_t)NF_STACK * n_sel);
+    NFBox* const stacks = c->np_scratch1.as<NFBox>();
+    const dim3 grid((n_sel + 63) / 64), block(64);
+    unsigned long long* const tw = &d_cnt->toi_bits; // (seeded by the caller with the TOI reached so far, like the level-order rerun)
+#define SCCD_LAUNCH_DF(VF_, AR_, PQ_)                                                                                              \
+    hipLaunchKernelGGL((np_dfs_f32_k<VF_, AR_, PQ_>), grid, block, 0, c->stream, p.V, p.E, p.F, p.pairs, d_sel, n_sel, (float)p.ms, \
+                       (float)p.tol, p.ms > 0, (bool)p.allow_zero_toi, d_cnt, per_query, stacks, tw)
+#define SCCD_LAUNCH_DF2(VF_, AR_)                      \
+    do {                                               \
+        if (per_query) SCCD_LAUNCH_DF(VF_, AR_, true); \
+        else SCCD_LAUNCH_DF(VF_, AR_, false);          \
+    } while (0)
+    if (p.is_vf) {
+        if (p.arith == 1) SCCD_LAUNCH_DF2(true, 1);
+        else SCCD_LAUNCH_DF2(true, 0);
+    } else {
+        if (p.arith == 1) SCCD_LAUNCH_DF2(false, 1);
+        else SCCD_LAUNCH_DF2(false, 0);
+    }
+#undef SCCD_LAUNCH_DF2
+#undef SCCD_LAUNCH_DF
+    SCCD_HIP(hipGetLastError());
+}
+
 // ovf_list / ovf_cap: where queries beyond level NF_MAX_LEVEL are listed (always given: narrow_phase_end redoes them in level order)
 static void run_walk_f32(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, long long n, unsigned long long* per_query,
                          int* ovf_list, unsigned ovf_cap)
@@ -768,7 +874,12 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
                     std::memset(&h2, 0, sizeof h2);
                     h2.toi_bits = h.toi_bits;
                     SCCD_HIP(hipMemcpyAsync(d_cnt, &h2, sizeof h2, hipMemcpyHostToDevice, c->stream));
-                    if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi, d_list, (long long)ids.size());
+                    SCCD_HIP(hipStreamSynchronize(c->stream)); // (h2 and ids are on the stack)
+                    if (c->scalar_f32 && p.max_iter < 0) { // (the list holds at most 2^20 queries: 4 GB of stacks at the very most)
+                        // the float build: the listed queries depth first on explicit float boxes (np_dfs_f32_k) -- no level of
+                        // theirs has to fit anywhere
+                        run_dfs_f32(c, p, d_cnt, d_list, (unsigned)ids.size(), reinterpret_cast<unsigned long long*>(d_per_query_toi));
+                    } else if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi, d_list, (long long)ids.size());
                     else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi, d_list, (long long)ids.size());
                     SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
                     SCCD_HIP(hipStreamSynchronize(c->stream));

@@ -123,6 +123,20 @@ def main():
                 tois.append(sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero))
             ok = (np.array_equal(srt(np.concatenate(got_vf)), want_vf) and np.array_equal(srt(np.concatenate(got_ee)), want_ee)
                   and min(tois) == want)
+            if ok and seed % 3 == 0:  # the float build (SCCD_OPT_SCALAR = 1: np_walk_f32_k, level order for what it lists) against the oracle's float twin
+                ctx.set_option(sccd.OPT_SHARD_COUNT, 1)
+                ctx.set_option(sccd.OPT_SHARD_RANK, 0)
+                try:
+                    want_f = orc.ccd(V0, V1, E, F, ms, -1, 1e-6, allow_zero, arith=arith, nthreads=8, scalar="f32")[0]
+                    ctx.set_option(sccd.OPT_SCALAR, 1)
+                    got_f = sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero)
+                    ok = got_f == want_f
+                    if not ok:
+                        print("FLOAT MISMATCH", tag, got_f, want_f, flush=True)
+                except (RuntimeError, MemoryError) as e:  # (a level of the float level order outgrew its budget: reported, not counted)
+                    print("SKIP float", tag, "--", e, flush=True)
+                finally:
+                    ctx.set_option(sccd.OPT_SCALAR, 0)
             if ok and ms == 0 and 0 < len(want_ee) < 4000:  # per-query output, small scenes (the oracle's is serial level order)
                 ctx.set_option(sccd.OPT_SHARD_COUNT, 1)
                 ctx.set_option(sccd.OPT_SHARD_RANK, 0)
