@@ -205,6 +205,7 @@ def main():
         class_id = {"boxes": 0, "sort": 1, "ranges": 2, "sweep": 3, "narrow_vf": 4, "narrow_ee": 5}  # SCCD_PROF_*
         ctx.set_option(sccd.OPT_PROFILE, (1 << class_id[dom]) << 1)
         ctx.reset_profile()
+        ctx.set_option(sccd.OPT_TOI_GUESS_HITS, 0)
         barrier()
         t0 = time.perf_counter()
         q_local = 0
@@ -219,6 +220,20 @@ def main():
             toi = dev_min.value()  # (the reduced word of the last step; every step of this frozen mesh has the same)
         prof = ctx.profile()
         ctx.set_option(sccd.OPT_PROFILE, 0)
+        # the speculative TOI bound (a step of a mesh whose previous step found an impact at T starts from 1.125 T, verified):
+        # how often it held over the timed steps, and the same step WITHOUT it (20 untimed steps, every call from toi = 1 as ccd.cu:125)
+        guess = {"hits": ctx.get_option(sccd.OPT_TOI_GUESS_HITS), "misses": ctx.get_option(sccd.OPT_TOI_GUESS_MISSES)}
+        ctx.set_option(sccd.OPT_TOI_GUESS, 0)
+        for _ in range(3):
+            step()
+        barrier()
+        tg = time.perf_counter()
+        for _ in range(20):
+            step()
+        barrier()
+        guess["ms_per_step_without"] = round((time.perf_counter() - tg) / 20 * 1e3, 4)
+        ctx.set_option(sccd.OPT_TOI_GUESS, 1)
+        step()  # (learn the bound again for what follows)
         # max over ranks of the elapsed time, sum over ranks of the queries
         tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         qq = torch.tensor([float(q_local), float(stats["n_vf_checks"] + stats["n_ee_checks"]),
@@ -381,6 +396,8 @@ def main():
             "host_path_note": "sccd_ccd() from pageable host matrices, upload and packing inside the call (best of 5; the reference's ccd() uploads inside the call too, ccd.cu:103-106); one rank only",
             "max_iter": args.max_iter,
             "broad_phase": broad,
+            "toi_guess": dict(guess, note="speculative TOI bound: a step starts from 1.125 x the previous step's TOI on the same mesh and is redone from 1 "
+                              "if nothing is found below the bound (exact either way); `--jitter` lines show it on a mesh that moves"),
             "cliffs": cliffs,
             "rank_max": rank_max,
             "roofline": roofline,
@@ -437,6 +454,7 @@ def bench_jitter(args, ctx, sccd, torch, mesh, tV0, tV1, params, wl, world):
     update_ms = (time.perf_counter() - tu) / 20 * 1e3
     step(0)
     ctx.set_option(sccd.OPT_SPEC_HITS, 0)
+    ctx.set_option(sccd.OPT_TOI_GUESS_HITS, 0)
     steps = max(args.steps, 200)
     times, missed, tois, queries = [], [], [], 0
     ctx.synchronize()
@@ -467,6 +485,7 @@ def bench_jitter(args, ctx, sccd, torch, mesh, tV0, tV1, params, wl, world):
         "update_vertices_ms": round(update_ms, 4),
         "spec_builds": hits + misses, "spec_hits": hits, "spec_misses": misses,
         "spec_hit_rate": round(hits / max(1, hits + misses), 4),
+        "toi_guess_hits": ctx.get_option(sccd.OPT_TOI_GUESS_HITS), "toi_guess_misses": ctx.get_option(sccd.OPT_TOI_GUESS_MISSES),
         "steps_with_a_miss": len(miss_t), "median_ms_hit": med(hit_t), "median_ms_miss": med(miss_t),
         "miss_over_hit": (round(med(miss_t) / med(hit_t), 3) if miss_t and hit_t else None),
         "toi_min": min(tois), "toi_max": max(tois), "queries_per_step": queries / steps,

@@ -100,6 +100,11 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
 #define SCCD_OPT_CELL_FACTOR_MILLI 17 /* grid cell size in thousandths of the mean box extent per minor axis (0 = default: 4000; < 0: one cell).
                                        * Any value is correct (grid.hpp); the SCCD_CELL_FACTOR environment variable of 0.1 is gone */
 #define SCCD_OPT_BUILD_SCAN 18        /* 1: entries by count -> device-wide scan -> fill, in box order (reproducible entry order; was SCCD_BUILD=scan) */
+#define SCCD_OPT_TOI_GUESS 19         /* 1 (default): sccd_ccd_mesh / sccd_ccd on a mesh whose previous call found an impact at T start from the bound
+                                       * min(1, 1.125 T) instead of 1 and verify (a result below the bound is exact; a result at the bound: the step is
+                                       * redone from 1); 0: always from 1, as ccd.cu:125 */
+#define SCCD_OPT_TOI_GUESS_HITS 20    /* read: calls whose bound held / broke (redone); setting either resets both */
+#define SCCD_OPT_TOI_GUESS_MISSES 21
 #define SCCD_OPT_SPEC_HITS 15   /* read: speculative builds (sort, records and sweep enqueued for the previous build's entry counts) whose */
 #define SCCD_OPT_SPEC_MISSES 16 /* guess held / broke and were redone, since the context was made; setting either resets both counters */
 int sccd_set_option(sccd_ctx* ctx, int option, int64_t value);

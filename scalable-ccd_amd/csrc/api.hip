@@ -155,6 +155,12 @@ int sccd_set_option(sccd_ctx* c, int opt, int64_t v)
     case SCCD_OPT_PASSES_APART: c->passes_apart = v ? 1 : 0; break;
     case SCCD_OPT_CELL_FACTOR_MILLI: c->cell_factor_milli = (int)v; break;
     case SCCD_OPT_BUILD_SCAN: c->build_scan = v ? 1 : 0; break;
+    case SCCD_OPT_TOI_GUESS:
+        c->toi_guess_on = v ? 1 : 0;
+        c->toi_guess = 1.0; // (forget what was learnt)
+        break;
+    case SCCD_OPT_TOI_GUESS_HITS:
+    case SCCD_OPT_TOI_GUESS_MISSES: c->toi_guess_hits = c->toi_guess_misses = 0; break;
     case SCCD_OPT_SPEC_HITS:
     case SCCD_OPT_SPEC_MISSES: // (counters: any value resets both, here and on the helper context)
         c->spec_hits = c->spec_misses = 0;
@@ -185,6 +191,9 @@ int64_t sccd_get_option(const sccd_ctx* c, int opt)
     case SCCD_OPT_PASSES_APART: return c->passes_apart;
     case SCCD_OPT_CELL_FACTOR_MILLI: return c->cell_factor_milli;
     case SCCD_OPT_BUILD_SCAN: return c->build_scan;
+    case SCCD_OPT_TOI_GUESS: return c->toi_guess_on;
+    case SCCD_OPT_TOI_GUESS_HITS: return c->toi_guess_hits;
+    case SCCD_OPT_TOI_GUESS_MISSES: return c->toi_guess_misses;
     case SCCD_OPT_SPEC_HITS: return c->spec_hits + (c->side ? c->side->spec_hits : 0);
     case SCCD_OPT_SPEC_MISSES: return c->spec_misses + (c->side ? c->side->spec_misses : 0);
     default: return 0;

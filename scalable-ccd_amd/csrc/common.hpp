@@ -146,6 +146,15 @@ struct sccd_ctx {
     int sweep_blocks_per_cu = 0; // 0 = the sweep kernel's own choice (a full CU); ccd()'s helper context sweeps with half
     int passes_apart = 0;      // SCCD_OPT_PASSES_APART
     int limit_level_order = 0; // SCCD_OPT_LIMIT_LEVEL_ORDER: 1 = every check limit on the level-synchronous kernels (cross-check)
+    // ccd() on a mesh whose previous step found an impact starts from a BOUND a quarter above that step's TOI instead of 1
+    // (drivers.hip ccd_on_mesh: exact -- a result below the bound is the result; a result AT the bound proves nothing and the
+    // step is redone from 1); SCCD_OPT_TOI_GUESS = 0 turns it off
+    int toi_guess_on = 1;
+    double toi_guess = 1.0;
+    const void* toi_guess_mesh = nullptr;
+    int toi_guess_n[3] = { 0, 0, 0 };
+    int64_t toi_guess_hits = 0, toi_guess_misses = 0;
+    int toi_guess_rest = 0, toi_guess_backoff = 4; // steps without a bound after a miss (doubling up to 64, halved by a hit)
     int cell_factor_milli = 0; // SCCD_OPT_CELL_FACTOR_MILLI: grid cell size in thousandths of the mean box extent (0: the default, 4000; < 0: one cell)
     int build_scan = 0;        // SCCD_OPT_BUILD_SCAN: 1 = count -> device-wide scan -> fill (entries in box order) instead of the one-pass append
     // narrow_counters_upload() already put {zeros, this TOI} into the narrow phase's counters (it rides ahead of

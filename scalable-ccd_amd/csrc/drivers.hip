@@ -197,9 +197,69 @@ static void ccd_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, sccd_broad_p
     if (st) (vf ? st->n_vf_candidates : st->n_ee_candidates) = bp->candidates;
 }
 
+static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter, double tol, int allow_zero_toi, double toi0,
+                             double* toi_out, sccd_stats* st, bool* lists_resident);
+// ccd() of ccd.cu:80-146 on a resident mesh.  THE SPECULATIVE BOUND (round 4): the reference starts every call from toi = 1
+// (ccd.cu:125) and the vertex-face pass then runs without a bound until its first contact query has been bisected to the end --
+// 55 dependent steps, three quarters of the launch, in which every query also explores the later halves of its time splits:
+// 5.9 M of the 13.8 M vertex-face checks of the 1M-triangle cloth.  A caller that steps a simulation calls ccd() on a mesh that
+// hardly moved: if the previous call on this mesh found an impact at T, this one starts from min(1, 1.125 T).  narrow_phase's toi is
+// in/out (narrow_phase.cu:126): the call returns min(bound, earliest accepted domain below it), and pruning by a bound never
+// removes a domain earlier than the bound -- so a result BELOW the bound is exactly what a start from 1 returns.  A result AT the
+// bound proves nothing (the earliest impact may lie beyond it): the step is redone from 1.  Counted (SCCD_OPT_TOI_GUESS_HITS /
+// _MISSES), off with SCCD_OPT_TOI_GUESS = 0 or SCCD_SPECULATE=0; calls with a check limit start from 1 as before (their
+// certificate is about the TOI the call started with).
 static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter, double tol, int allow_zero_toi,
                         double* toi_out, sccd_stats* st)
 {
+    const bool same_mesh = c->toi_guess_mesh == (const void*)m && c->toi_guess_n[0] == m->nV && c->toi_guess_n[1] == m->nE
+        && c->toi_guess_n[2] == m->nF;
+    bool spec = c->toi_guess_on && lab_env().speculate && same_mesh && max_iter < 0 && c->toi_guess < 1.0 && c->toi_guess > 0.0;
+    if (spec && c->toi_guess_rest > 0) { // (a bound broke lately: a few steps from 1 before the next try)
+        c->toi_guess_rest -= 1;
+        spec = false;
+    }
+    double toi = 1.0;
+    bool resident = false;
+    if (spec) {
+        const double bound = c->toi_guess;
+        ccd_on_mesh_from(c, m, ms, max_iter, tol, allow_zero_toi, bound, &toi, st, &resident);
+        if (toi < bound) {
+            c->toi_guess_hits += 1;
+            c->toi_guess_backoff = std::max(4, c->toi_guess_backoff / 2);
+        } else { // nothing was accepted below the bound: the earliest impact lies at or beyond it -- from 1, as the reference does
+            c->toi_guess_misses += 1;
+            c->toi_guess_rest = c->toi_guess_backoff;
+            c->toi_guess_backoff = std::min(64, c->toi_guess_backoff * 2);
+            if (resident) {
+                // both pair lists are still on the device, each swept in one chunk: only the narrow phases again (ccd.cu:125-143)
+                Pipeline* const pl = pipeline_of(c);
+                toi = 1.0;
+                const NarrowResult rv = run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, 1, max_iter, tol, ms, allow_zero_toi, &toi, nullptr);
+                const NarrowResult re = run_narrow(c, m, pl->bp_ee.overlaps.as<int2>(), pl->bp_ee.n_overlaps, 0, max_iter, tol, ms, allow_zero_toi, &toi, nullptr);
+                if (st) {
+                    st->n_vf_checks += (int64_t)rv.n_checks;
+                    st->n_ee_checks += (int64_t)re.n_checks;
+                }
+            } else {
+                ccd_on_mesh_from(c, m, ms, max_iter, tol, allow_zero_toi, 1.0, &toi, st, nullptr);
+            }
+        }
+    } else {
+        ccd_on_mesh_from(c, m, ms, max_iter, tol, allow_zero_toi, 1.0, &toi, st, nullptr);
+    }
+    c->toi_guess = (toi < 1.0 && toi > 0.0) ? std::min(1.0, toi * 1.125) : 1.0; // (an eighth above: the pruning a bound buys comes in dyadic steps -- 1.25 x 0.408 = 0.51 keeps the later half of every first time split alive, 0.459 does not)
+    c->toi_guess_mesh = (const void*)m;
+    c->toi_guess_n[0] = m->nV;
+    c->toi_guess_n[1] = m->nE;
+    c->toi_guess_n[2] = m->nF;
+    *toi_out = toi;
+}
+
+static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter, double tol, int allow_zero_toi, double toi0,
+                             double* toi_out, sccd_stats* st, bool* lists_resident)
+{
+    if (lists_resident) *lists_resident = false;
     Pipeline* pl = pipeline_of(c);
     if (st) std::memset(st, 0, sizeof *st);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -216,7 +276,7 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
     // (a rank of a multi-GPU job builds the edge and face boxes of its window of cells only: see boxes_from_mesh)
     const bool lazy_ef = c->shard_count > 1 && c->sort_axis >= 0 && c->max_overlap_cutoff == 0 && !c->build_scan;
     boxes_from_mesh(c, m, ms, pl, true, true, true, lazy_ef); // inflation radius = min_distance (ccd.cu:112)
-    double toi = 1; // ccd.cu:125
+    double toi = toi0; // ccd.cu:125 starts from 1; ccd_on_mesh may hand a bound over
     // The edge-edge lists do not depend on the vertex-face pass: a helper context (own stream, scratch, pinned mirror)
     // builds them on a worker thread meanwhile.  Both builds are chains of short, latency-bound kernels with host
     // round trips in between, so two of them interleave almost for free (2.23 instead of 2.34 ms per step on the
@@ -376,7 +436,8 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
         throw;
     }
     if (both_done) {
-        // (both passes are behind us)
+        // (both passes are behind us; each pair list was swept in one chunk and is still on the device)
+        if (lists_resident) *lists_resident = true;
     } else if (helper) {
         pl->worker.wait();
         ccd_pass(c, m, pl, &pl->bp_ee, false, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true, /*swept=*/presweep_done);

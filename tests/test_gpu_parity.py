@@ -1297,3 +1297,36 @@ def test_ccd_mesh_dev_leaves_the_toi_in_device_memory(sccd, ctx):
     dm.reduce()
     assert dm.value() == t
     mesh.close()
+
+
+def test_speculative_toi_bound_is_exact_through_hits_and_misses(sccd, orc):
+    """ccd() on a mesh whose previous call found an impact at T starts from the bound 1.125 T (drivers.hip ccd_on_mesh): a result
+    below the bound is exact, a result AT the bound proves nothing and the step is redone from 1.  The mesh is stepped through
+    motions that keep the TOI (bound holds), push it beyond the bound (miss), remove every impact (miss, result 1) and bring it
+    back: every result is the oracle's, and both the hits and the misses really happened."""
+    c = sccd.Context(0)
+    try:
+        V0, V1, E, F = _scene("cloth_ball_small")
+        mesh = sccd.Mesh(V0, V1, E, F, ctx=c)
+        # (after a miss the library rests for a few steps before it tries a bound again: the sequence gives it the time)
+        scales = [1.0, 1.0, 0.999, 0.55, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.05, 0.05, 1.0, 1.0, 0.3, 0.3, 0.3, 0.3, 0.3, 1.0]
+        seen = []
+        for s in scales:
+            W1 = V0 + s * (V1 - V0)
+            mesh.update_vertices(V0, W1)
+            want = orc.ccd(V0, W1, E, F, 0.0, -1, 1e-6, True, nthreads=8)[0]
+            got = sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True)
+            assert got == want, (s, got, want)
+            seen.append(want)
+        hits, misses = c.get_option(sccd.OPT_TOI_GUESS_HITS), c.get_option(sccd.OPT_TOI_GUESS_MISSES)
+        assert hits >= 2 and misses >= 2, (hits, misses, seen)
+        assert min(seen) < 1.0 and max(seen) == 1.0, seen  # the sequence had impacts and a step without any
+        c.set_option(sccd.OPT_TOI_GUESS, 0)  # ... and switched off, every call starts from 1
+        c.set_option(sccd.OPT_TOI_GUESS_HITS, 0)
+        for s in (1.0, 1.0, 1.0):
+            mesh.update_vertices(V0, V0 + s * (V1 - V0))
+            assert sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True) == seen[0]
+        assert c.get_option(sccd.OPT_TOI_GUESS_HITS) == 0 and c.get_option(sccd.OPT_TOI_GUESS_MISSES) == 0
+        mesh.close()
+    finally:
+        c.close()
