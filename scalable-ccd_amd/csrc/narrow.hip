@@ -395,6 +395,14 @@ __global__ void np_reset_selected_k(double* __restrict__ per_query, const int* _
 // level-31 queries.  The result is the minimum over accepted domains either way (Appendix A.20): bit-equal to the oracle's
 // float twin.  PQ: per-query output (a query is pruned by its own earliest impact only, root_finder.cu:297).
 constexpr unsigned NF_MAX_LEVEL = 23;
+// One lane walks one query alone: a query in resting contact under a large minimum separation can need 10^6 checks and more in
+// float (Condition 1 is out of reach of float intervals, so every near-contact cell is bisected down to single ulps), and a lane
+// does ~10^6 checks a second.  A query that has used NF_QUERY_BUDGET checks is therefore LISTED like a level-24 one, and the
+// explicit-stack kernel gives a listed query NF_DFS_BUDGET checks before it raises the overflow flag and the call falls back to
+// level order (which parallelises over the domains of a level -- or ends with SCCD_E_NOMEM, as it did for such scenes in round 3).
+// No launch of the float build runs longer than about a second that way (soak seed 500388 ran for minutes without the budgets).
+constexpr unsigned NF_QUERY_BUDGET = 1u << 16;
+constexpr unsigned NF_DFS_BUDGET = 1u << 18;
 constexpr int NF_REFILL_MIN = 12; // idle lanes that trigger a refill (or: nobody works) -- the refill's code runs for the whole wave
 template <bool VF, int ARITH, bool PQ>
 __global__ __launch_bounds__(256) void np_walk_f32_k(const double* __restrict__ V, const int2* __restrict__ E, const int4* __restrict__ F,
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(256) void np_walk_f32_k(const double* __restrict__ 
     float qtoi = __builtin_huge_valf();
     long long qid = 0;
     float toi = (float)toi_load(toi_word); // (every stored TOI is a float, widened: the casts are exact)
-    unsigned step = 0, checks = 0;
+    unsigned step = 0, checks = 0, q_checks = 0;
     for (;;) {
         const bool want = !has_q && next < n;
         const unsigned long long wants = __ballot(want), busy = __ballot(has_q);
@@ -430,6 +438,7 @@ __global__ __launch_bounds__(256) void np_walk_f32_k(const double* __restrict__ 
                 walk = NQWalk { { 0ull, 0u }, { 0ull, 0u }, { 0ull, 0u } };
                 qid = next;
                 qtoi = __builtin_huge_valf();
+                q_checks = 0;
                 has_q = true;
                 next += stride;
             }
@@ -450,6 +459,7 @@ __global__ __launch_bounds__(256) void np_walk_f32_k(const double* __restrict__ 
             }
             const TIStepF s = tif_step<VF, ARITH>(q, lo, hi, ms, tol, allow_zero_toi, PQ ? qtoi : toi);
             checks += s.checked ? 1u : 0u;
+            q_checks += 1u;
             if (s.accept) {
                 if (PQ && lo[0] < qtoi) {
                     qtoi = lo[0];
@@ -462,8 +472,9 @@ __global__ __launch_bounds__(256) void np_walk_f32_k(const double* __restrict__ 
             }
             if (s.nk >= 1) {
                 const unsigned nd = dom.d + (1u << (8 * s.split));
-                if (((nd >> (8 * s.split)) & 255u) > NF_MAX_LEVEL) {
-                    // the halves are no longer exact floats of the form k 2^-d: the whole query is redone in level order
+                if (((nd >> (8 * s.split)) & 255u) > NF_MAX_LEVEL || q_checks > NF_QUERY_BUDGET) {
+                    // the halves are no longer exact floats of the form k 2^-d (or: this query is too much for one lane): the
+                    // whole query is handed on (narrow_phase_end)
                     const unsigned at = atomicAdd(&cnt->n_ovf, 1u);
                     if (at < ovf_cap) ovf_list[at] = (int)qid;
                     has_q = false;
@@ -526,6 +537,10 @@ __global__ __launch_bounds__(64) void np_dfs_f32_k(const double* __restrict__ V,
     unsigned long long checks = 0;
     while (top > 0) {
         if ((++step & 15u) == 0u) toi = (float)toi_load(toi_word);
+        if (step > NF_DFS_BUDGET) { // (one lane cannot finish this query in reasonable time: level order takes the call over)
+            atomicOr(&cnt->overflow, 1u);
+            break;
+        }
         const NFBox d = st[--top];
         const TIStepF s = tif_step<VF, ARITH>(q, d.lo, d.hi, ms, tol, allow_zero_toi, PQ ? qtoi : toi);
         checks += s.checked ? 1u : 0u;

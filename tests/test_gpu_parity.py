@@ -1304,6 +1304,8 @@ def test_speculative_toi_bound_is_exact_through_hits_and_misses(sccd, orc):
     below the bound is exact, a result AT the bound proves nothing and the step is redone from 1.  The mesh is stepped through
     motions that keep the TOI (bound holds), push it beyond the bound (miss), remove every impact (miss, result 1) and bring it
     back: every result is the oracle's, and both the hits and the misses really happened."""
+    if os.environ.get("SCCD_SPECULATE") == "0":
+        pytest.skip("SCCD_SPECULATE=0 switches the speculative bound off with the speculative build")
     c = sccd.Context(0)
     try:
         V0, V1, E, F = _scene("cloth_ball_small")
