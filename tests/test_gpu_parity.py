@@ -1332,3 +1332,32 @@ def test_speculative_toi_bound_is_exact_through_hits_and_misses(sccd, orc):
         mesh.close()
     finally:
         c.close()
+
+
+def test_float_build_is_bounded_on_a_query_that_explodes(sccd, ctx):
+    """Soak seed 500388 (a small cloth on a ball, scaled by 104, minimum separation 0.31): in float Condition 1 is out of reach, so
+    the queries in resting contact are bisected down to single ulps -- 182 s for the oracle's float twin on 8 cores, minutes for ONE
+    lane of the float build's depth-first kernels before they had check budgets.  With the budgets the lanes hand such queries on
+    and level order finishes the call: the oracle twin's value (recorded from that 182 s run), within seconds."""
+    import sys
+    import time
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import soak
+
+    V0, V1, E, F, kind, scale, shift, ms, allow_zero, arith, *_ = soak.scene_of(500388)
+    assert (len(F), arith, allow_zero) == (370, 0, True)
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    try:
+        ctx.set_option(sccd.OPT_ARITH, arith)
+        assert sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero) == float.fromhex("0x1.e125ec0000000p-3")  # the double build
+        ctx.set_option(sccd.OPT_SCALAR, 1)
+        t0 = time.perf_counter()
+        got = sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero)
+        dt = time.perf_counter() - t0
+        assert got == float.fromhex("0x1.bf121a0000000p-3"), got
+        assert dt < 10.0, dt
+    finally:
+        ctx.set_option(sccd.OPT_SCALAR, 0)
+        ctx.set_option(sccd.OPT_ARITH, sccd.ARITH_DEFAULT)
+        mesh.close()
