@@ -66,6 +66,19 @@ def lib_sha256():
         return hashlib.sha256(f.read()).hexdigest()
 
 
+def clock_warmup(step, seconds):
+    """Untimed: `seconds` of the workload's own steps BEFORE the W warm-up steps.  A fresh box starts a process with the GPU idle
+    (clocks down, nothing paged in): the first run of the day on the round-3 library measured 1.41 ms per step and the second, a
+    minute later on the same box, 1.30 -- W = 5 warm-up steps are 6 ms, far less than the clocks need.  Returns the steps run
+    (reported as config.clock_warmup_steps); --clock-warmup 0 switches it off."""
+    n = 0
+    t_end = time.perf_counter() + seconds
+    while time.perf_counter() < t_end:
+        step()
+        n += 1
+    return n
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +102,7 @@ def parse():
     ap.add_argument("--cliffs", action="store_true", help="cloth workloads: also time the paths that do not run on the plain fast kernel -- ccd() with the "
                     "per-query collision list (with and without a check limit), a check limit on the level-synchronous kernels, the float build "
                     "-- each as a multiple of the default step (block `cliffs` of the line)")
+    ap.add_argument("--clock-warmup", type=float, default=1.0, help="seconds of untimed steps before the W warm-up steps (GPU clocks, first touches); 0: none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="cloth side of the CPU sample (0 = auto)")
     return ap.parse_args()
@@ -191,6 +205,7 @@ def main():
         # and which class dominates.  The timed region keeps events on that one class only -- two event records
         # per class scope cost 0.15 ms of a 2.3 ms step with all classes on.
         n_prof = 2
+        n_clock = clock_warmup(step, args.clock_warmup)
         for _ in range(args.warmup):
             step()
         ctx.set_option(sccd.OPT_PROFILE, 1)
@@ -384,7 +399,7 @@ def main():
             "metric": "CCD queries/sec (broad+narrow)", "value": value, "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": dict(wl, queries_per_step=queries_per_step, toi=toi, arith=["strict", "fma"][args.arith],
+            "config": dict(wl, queries_per_step=queries_per_step, toi=toi, arith=["strict", "fma"][args.arith], clock_warmup_steps=n_clock,
                            checks_per_step=float(qq[1].item()), candidates_per_step=float(qq[2].item()),
                            parallelism=f"cell windows sharded over {world} GPU(s), one RCCL all-reduce(min) of the TOI per step",
                            rccl_ranks=rccl_ranks, backend=(backend if use_dist else "none")),
@@ -443,6 +458,13 @@ def bench_jitter(args, ctx, sccd, torch, mesh, tV0, tV1, params, wl, world):
         mesh.update_vertices(tV0.data_ptr(), variants[k % n_var].data_ptr(), on_device=True)
         return sccd.ccd_mesh(mesh, want_stats=True, **params)
 
+    kk = [0]
+
+    def one():
+        kk[0] += 1
+        step(kk[0])
+
+    clock_warmup(one, args.clock_warmup)
     for k in range(max(args.warmup, n_var)):
         step(k)
     # the update alone (pack kernel + the synchronisation that releases the caller's buffers)
@@ -507,6 +529,7 @@ def bench_boxes(args, ctx, sccd, scenes, torch):
         bp.build(dboxes)
         return bp.detect_overlaps_partial()[1]
 
+    clock_warmup(step, args.clock_warmup)
     for _ in range(args.warmup):
         step()
     ctx.set_option(sccd.OPT_PROFILE, 1)
@@ -557,6 +580,7 @@ def bench_sort(args, ctx, sccd, torch):
         torch.cuda.synchronize()
         ctx.sort_pairs_u32(keys.data_ptr(), vals.data_ptr(), n)
 
+    clock_warmup(step, args.clock_warmup)
     for _ in range(args.warmup):
         step()
     ctx.set_option(sccd.OPT_PROFILE, 1)
