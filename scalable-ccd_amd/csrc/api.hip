@@ -44,6 +44,35 @@ void merge_side_profile(sccd_ctx* c)
     }
 }
 
+// ReadBack's gather kernel (common.hpp): four waves copy every item into the pinned mailbox, then the sequence word.  Eight
+// vector registers at most (tests/test_kernel_resources.py): what a SIMD running three narrow-phase waves has left, so the
+// block is placed beside them instead of waiting for one to retire.  (Four waves: the counters of a narrow launch are 2.6 KB,
+// a dependent load -> store round per 256 bytes with one.)
+__global__ __launch_bounds__(256) void readback_gather_k(ReadBackItems it, unsigned* __restrict__ box, unsigned long long* seq_word,
+                                                        unsigned long long seq)
+{
+    const unsigned lane = threadIdx.x;
+    for (int i = 0; i < it.n; i++) {
+        const unsigned* __restrict__ src = it.src[i];
+        unsigned* dst = box + it.off_words[i];
+        const unsigned nw = it.n_words[i];
+        for (unsigned w = lane; w < nw; w += 256) __hip_atomic_store(dst + w, __builtin_nontemporal_load(src + w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // Every lane's stores have been acknowledged before the word the host polls is written.  NOT a system-scope fence: that
+    // writes back and invalidates the whole L2 (buffer_wbl2 / buffer_inv sc0 sc1) for stores that never were in it -- the
+    // mailbox is uncached on the device -- and the kernels behind this one found their vertices and pairs gone from the
+    // cache (first version: the 1M-triangle step 1.17 -> 1.26 ms).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(seq_word, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void readback_gather_launch(sccd_ctx* c, const ReadBackItems& it, unsigned long long seq)
+{
+    hipLaunchKernelGGL(readback_gather_k, dim3(1), dim3(256), 0, c->stream, it, reinterpret_cast<unsigned*>(c->mailbox_dev),
+                       reinterpret_cast<unsigned long long*>(c->mailbox_dev + SCCD_MAILBOX_BYTES), seq);
+    SCCD_HIP(hipGetLastError());
+}
+
 extern "C" {
 
 const char* sccd_version(void) { return "sccd-hip 0.2 (gfx950)"; } // 0.2: default contract fused (SCCD_OPT_ARITH = 1), option id 12 retired
@@ -73,6 +102,12 @@ int sccd_create(int device, sccd_ctx** out)
         c->scalars.ensure(4096);
         SCCD_HIP(hipMemsetAsync(c->scalars.p, 0, 4096, c->stream)); // (holds a counter that is never reset: sort.hip)
         c->h_scalars.ensure(16384);
+        // the read-back mailbox: host-coherent (fine-grained) pinned memory, written by readback_gather_k, polled by ReadBack
+        c->mailbox.ensure(SCCD_MAILBOX_BYTES + 256, hipHostMallocCoherent);
+        std::memset(c->mailbox.p, 0, SCCD_MAILBOX_BYTES + 256);
+        void* dev = nullptr;
+        SCCD_HIP(hipHostGetDevicePointer(&dev, c->mailbox.p, 0));
+        c->mailbox_dev = static_cast<char*>(dev);
     });
     if (rc != SCCD_OK) {
         g_create_error = c->err;
@@ -96,6 +131,7 @@ void sccd_destroy(sccd_ctx* c)
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->rb_event) (void)hipEventDestroy(c->rb_event);
     if (c->side_event) (void)hipEventDestroy(c->side_event);
+    if (c->side_event2) (void)hipEventDestroy(c->side_event2);
     if (c->side) sccd_destroy(c->side);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

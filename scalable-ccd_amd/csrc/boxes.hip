@@ -341,8 +341,16 @@ __global__ __launch_bounds__(SCCD_STATS_BLOCKS) void grid_setup_k(const GridStat
                              const GridStats* __restrict__ st_b, const double* __restrict__ part_b, int n_part_b,
                              int n_total, int axis, double cell_factor, int shrink, GridParams* __restrict__ g,
                              uint32_t* __restrict__ cursors /* the two list cursors of the fill pass: zeroed here */,
-                             int max_cells, int reserve_tag, uint32_t* __restrict__ zero_hist /* [SCCD_MAX_CELLS] or null */)
+                             int max_cells, int reserve_tag, uint32_t* __restrict__ zero_hist /* [SCCD_MAX_CELLS] or null */,
+                             unsigned long long* __restrict__ sweep_cnt /* the context's SweepCounters: zeroed here */, int sweep_words,
+                             unsigned long long* __restrict__ narrow_cnt /* its NarrowCounters or null: {toi, zeros} */, int narrow_words,
+                             unsigned long long toi_bits)
 {
+    // The counters of the launches BEHIND this build start here: the sweep's (a fill kernel between record pass and sweep
+    // was 8 us on the critical path of every chain) and, for ccd(), the narrow phase's (an upload there, another 7 us).
+    for (int k = threadIdx.x; k < sweep_words; k += SCCD_STATS_BLOCKS) sweep_cnt[k] = 0ull;
+    if (narrow_cnt)
+        for (int k = threadIdx.x; k < narrow_words; k += SCCD_STATS_BLOCKS) narrow_cnt[k] = k == 0 ? toi_bits : 0ull;
     if (threadIdx.x < 4) cursors[threadIdx.x] = 0u; // the two list totals, the placement cursor of a merged two-list fill, list A's extent
     if (zero_hist) // (multi-GPU: the sampled cell histogram the next launch adds to -- a memset of its own was a launch more)
         for (int k = threadIdx.x; k < SCCD_MAX_CELLS; k += SCCD_STATS_BLOCKS) zero_hist[k] = 0u;
@@ -966,9 +974,22 @@ void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a,
                        GridParams* g, uint32_t* cursors, bool reserve_tag, uint32_t* zero_hist)
 {
     const int max_cells = SCCD_DEFAULT_CELLS;
+    // (the context's counter block: SweepCounters at 0, NarrowCounters at 2048 -- build.hip / drivers.hip)
+    static_assert(offsetof(NarrowCounters, toi_bits) == 0, "grid_setup_k writes the TOI into word 0");
+    unsigned long long* const sweep_cnt = c->scalars.as<unsigned long long>();
+    const bool np_init = c->np_init_pending;
+    unsigned long long toi_bits = 0;
+    std::memcpy(&toi_bits, &c->np_init_toi, 8);
     hipLaunchKernelGGL(grid_setup_k, dim3(1), dim3(SCCD_STATS_BLOCKS), 0, c->stream, st_a, part_a, n_part_a, st_b, part_b, n_part_b,
-                       n_total, axis, cell_factor, shrink, g, cursors, max_cells, reserve_tag ? 1 : 0, zero_hist);
+                       n_total, axis, cell_factor, shrink, g, cursors, max_cells, reserve_tag ? 1 : 0, zero_hist, sweep_cnt,
+                       (int)(sizeof(SweepCounters) / 8), np_init ? sweep_cnt + 2048 / 8 : nullptr, (int)(sizeof(NarrowCounters) / 8), toi_bits);
     SCCD_HIP(hipGetLastError());
+    c->sweep_cnt_cleared = true; // (consumed by the next sweep of this context: bp_detect_partial)
+    if (np_init) {
+        c->np_init_pending = false;
+        c->np_uploaded = true; // (narrow_phase_begin: nothing to upload for a launch that starts from this TOI)
+        c->np_uploaded_toi = c->np_init_toi;
+    }
 }
 // the boxes of a list for the kernels above: the raw array, or (lazy lists) the recipe to compute them
 static BoxSrc box_src(const sccd_boxes* b)

@@ -603,7 +603,9 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
         if (B) shard_rows(c, bp->row_shard, b_lo, b_hi, &b_lo, &b_hi);
 
         if (phase == 2 && attempt == 0) goto launched; // (phase 1 enqueued this attempt)
-        SCCD_HIP(hipMemsetAsync(d_cnt, 0, sizeof(SweepCounters), c->stream)); // pairs and candidate tests of THIS attempt
+        // pairs and candidate tests of THIS attempt (the first sweep behind a build: its grid kernel zeroed them)
+        if (c->sweep_cnt_cleared && attempt == 0) c->sweep_cnt_cleared = false;
+        else SCCD_HIP(hipMemsetAsync(d_cnt, 0, sizeof(SweepCounters), c->stream));
         {
             ProfScope ps(c, SCCD_PROF_SWEEP);
             // (a speculative build: the lists' sizes are bounds, the kernels take the real counts from device memory)

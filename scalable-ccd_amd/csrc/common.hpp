@@ -73,12 +73,12 @@ struct PinnedBuf {
     {
         if (p) (void)hipHostFree(p);
     }
-    void ensure(size_t bytes)
+    void ensure(size_t bytes, unsigned flags = hipHostMallocDefault)
     {
         if (bytes <= cap) return;
         if (p) (void)hipHostFree(p);
         p = nullptr;
-        SCCD_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        SCCD_HIP(hipHostMalloc(&p, bytes, flags));
         cap = bytes;
     }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -95,6 +95,8 @@ struct LabEnv {
     bool presweep = true;              // SCCD_PRESWEEP=0: the edge-edge sweep not beside the vertex-face narrow phase
     bool narrow_beside = true;         // SCCD_NARROW_BESIDE=0: the edge-edge narrow kernel after, not beside, the vertex-face one
     bool sync_block = false;           // SCCD_SYNC=block: read-backs wait with hipStreamSynchronize instead of polling an event
+    bool narrow_order = true;          // SCCD_NARROW_ORDER=0: the vertex-face narrow kernel not ordered behind the edge-edge sweep's start
+    bool readback_copy = false;        // SCCD_READBACK=copy: read-backs as copies + a polled event instead of one gather kernel + a polled word
     bool sort_tickets = false;         // SCCD_SORT_TICKETS=1: sort tiles by atomic ticket even when every tile has its block
     long long level_budget_mb = 0;     // SCCD_LEVEL_BUDGET_MB: budget per level buffer of the level-synchronous narrow phase
     int spec_break_every = 0;          // SCCD_SPEC_BREAK=N: every N-th speculative build is declared a failed guess (measures what a miss costs)
@@ -112,10 +114,13 @@ struct LabEnv {
         presweep = num("SCCD_PRESWEEP", 1) != 0;
         narrow_beside = num("SCCD_NARROW_BESIDE", 1) != 0;
         sort_tickets = num("SCCD_SORT_TICKETS", 0) != 0;
+        narrow_order = num("SCCD_NARROW_ORDER", 1) != 0;
         level_budget_mb = num("SCCD_LEVEL_BUDGET_MB", 0);
         spec_break_every = num("SCCD_SPEC_BREAK", 0);
         const char* s = std::getenv("SCCD_SYNC");
         sync_block = s && std::string(s) == "block";
+        const char* r = std::getenv("SCCD_READBACK");
+        readback_copy = r && std::string(r) == "copy";
     }
 };
 inline const LabEnv& lab_env()
@@ -160,6 +165,11 @@ struct sccd_ctx {
     // narrow_counters_upload() already put {zeros, this TOI} into the narrow phase's counters (it rides ahead of
     // the sweep in ccd(), so that the narrow kernel can start right behind the sweep's read-back)
     bool np_uploaded = false;
+    // the next build's grid kernel also starts the narrow counters from this TOI (ccd(): drivers.hip); and: the build zeroed
+    // the sweep counters, the next sweep need not (launch_grid_setup / bp_detect_partial)
+    bool np_init_pending = false, sweep_cnt_cleared = false;
+    double np_init_toi = 0;
+    hipEvent_t side_event2 = nullptr; // ccd(): "the helper's stream has reached its sweep" (drivers.hip)
     double np_uploaded_toi = 0;
     // a narrow-phase launch of ANOTHER context that shares this one's TOI word is running on that stream: before this
     // context resets its counters (fallback paths) it waits for it
@@ -190,6 +200,11 @@ struct sccd_ctx {
     DevBuf col_pq, col_out, col_idx;
     DevBuf scalars;      // small device-side counters block
     PinnedBuf h_scalars; // pinned mirror for async read-back
+    // The read-back mailbox (ReadBack): host-coherent pinned memory the GATHER KERNEL writes -- [0, 8 KB) the items, one
+    // sequence word behind them.  mailbox_dev is the same memory as the device addresses it.
+    PinnedBuf mailbox;
+    char* mailbox_dev = nullptr;
+    unsigned long long rb_seq = 0;
     DevBuf np_scratch0, np_scratch1, np_scratch2, np_scratch3, np_scratch4, np_scratch3_ovf;
     DevBuf tmp0, tmp1, tmp2;
     struct sccd_mesh* scratch_mesh = nullptr; // the mesh behind the host-matrix drivers (api.hip: scratch_mesh_from_host)
@@ -235,8 +250,21 @@ struct ProfScope {
 
 void sccd_collect_profile(sccd_ctx* c); // api.cpp
 
-// Small device -> host reads go through the pinned mirror: with a pageable destination the
-// runtime stages the copy itself, which costs tens of microseconds per synchronisation point.
+// Small device -> host reads (counters, the grid, the TOI: a few hundred bytes, several times per step, each on the step's
+// critical path).  As copies they cost a copy kernel PER ITEM plus an event the host polls: ~14 us per read-back, and a
+// copy kernel needs more registers than a CU full of narrow-phase waves has left (168 x 3 of 512 per SIMD lane: 8 are free),
+// so a read-back issued beside the narrow phase sat in its queue until the first of those waves retired (165 us: DESIGN 5.6).
+// Now ONE single-wave kernel of <= 8 vector registers (readback_gather_k, api.hip) gathers every item into host-coherent
+// pinned memory (sccd_ctx::mailbox), fences at system scope and stores a sequence number behind the items; the host polls
+// that word.  No event, no copy engine, and the kernel fits beside resident narrow-phase waves.
+// SCCD_READBACK=copy restores copies + event (A/B); SCCD_SYNC=block waits on the stream instead of polling either way.
+constexpr size_t SCCD_MAILBOX_BYTES = 8192; // items; the sequence word sits right behind
+struct ReadBackItems { // by value into the gather kernel
+    const unsigned* src[8];
+    unsigned off_words[8], n_words[8];
+    int n;
+};
+void readback_gather_launch(sccd_ctx* c, const ReadBackItems& it, unsigned long long seq); // api.hip
 struct ReadBack {
     sccd_ctx* c;
     size_t off = 0;
@@ -245,23 +273,48 @@ struct ReadBack {
         size_t off, bytes;
     };
     Item items[8];
+    ReadBackItems dev {};
     int n = 0;
-    explicit ReadBack(sccd_ctx* ctx) : c(ctx) {}
+    bool gather;
+    explicit ReadBack(sccd_ctx* ctx) : c(ctx), gather(!lab_env().readback_copy && ctx->mailbox_dev != nullptr) {}
     void add(void* dst, const void* src_dev, size_t bytes)
     {
-        if (n >= 8 || off + bytes > 8192) throw SccdError { SCCD_E_INVALID, "ReadBack: too many items" }; // [0, 8 KB) of the mirror
-        SCCD_HIP(hipMemcpyAsync(c->h_scalars.as<char>() + off, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        if (n >= 8 || off + bytes > SCCD_MAILBOX_BYTES) throw SccdError { SCCD_E_INVALID, "ReadBack: too many items" }; // [0, 8 KB) of the mirror
+        if (gather && ((bytes & 3) || (reinterpret_cast<uintptr_t>(src_dev) & 3))) throw SccdError { SCCD_E_INVALID, "ReadBack: items are whole aligned words" };
+        if (gather) {
+            dev.src[n] = static_cast<const unsigned*>(src_dev);
+            dev.off_words[n] = (unsigned)(off / 4);
+            dev.n_words[n] = (unsigned)(bytes / 4);
+        } else {
+            SCCD_HIP(hipMemcpyAsync(c->h_scalars.as<char>() + off, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        }
         items[n++] = Item { dst, off, bytes };
         off += (bytes + 15) & ~(size_t)15;
     }
     void sync()
     {
-        // Poll an event instead of hipStreamSynchronize: the blocking wait puts the thread to sleep and the
-        // wake-up alone costs tens of microseconds -- with six of these per ccd() step that is ~10 % of it.
-        // SCCD_SYNC=block restores the blocking wait (e.g. when host cores are scarce).
-        if (lab_env().sync_block) {
+        const char* from = c->h_scalars.as<char>();
+        if (gather) {
+            from = c->mailbox.as<char>();
+            dev.n = n;
+            const unsigned long long want = ++c->rb_seq;
+            readback_gather_launch(c, dev, want);
+            const unsigned long long* const word = reinterpret_cast<const unsigned long long*>(from + SCCD_MAILBOX_BYTES);
+            if (lab_env().sync_block) SCCD_HIP(hipStreamSynchronize(c->stream));
+            // (a stream that drained -- or failed -- without the word having arrived must not hang the caller: looked at now and then)
+            for (unsigned spins = 1; __atomic_load_n(word, __ATOMIC_ACQUIRE) != want; spins++) {
+                __builtin_ia32_pause(); // (the helper's worker thread may be this core's other hardware thread)
+                if ((spins & 0xFFFFu) != 0) continue;
+                const hipError_t e = hipStreamQuery(c->stream);
+                if (e == hipErrorNotReady) continue;
+                SCCD_HIP(e);
+                if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != want) throw SccdError { SCCD_E_HIP, "ReadBack: the stream drained without the mailbox word" };
+            }
+        } else if (lab_env().sync_block) {
             SCCD_HIP(hipStreamSynchronize(c->stream));
         } else {
+            // Poll an event instead of hipStreamSynchronize: the blocking wait puts the thread to sleep and the
+            // wake-up alone costs tens of microseconds -- with six of these per ccd() step that is ~10 % of it.
             if (!c->rb_event) SCCD_HIP(hipEventCreateWithFlags(&c->rb_event, hipEventDisableTiming));
             SCCD_HIP(hipEventRecord(c->rb_event, c->stream));
             for (;;) {
@@ -270,7 +323,7 @@ struct ReadBack {
                 if (e != hipErrorNotReady) SCCD_HIP(e);
             }
         }
-        for (int i = 0; i < n; i++) std::memcpy(items[i].dst, c->h_scalars.as<char>() + items[i].off, items[i].bytes);
+        for (int i = 0; i < n; i++) std::memcpy(items[i].dst, from + items[i].off, items[i].bytes);
         n = 0;
         off = 0;
     }

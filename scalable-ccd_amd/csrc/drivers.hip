@@ -289,6 +289,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
         if (!c->side) {
             if (sccd_create(c->device, &c->side) != SCCD_OK) throw SccdError { SCCD_E_NOMEM, "ccd: cannot create the helper context" };
             SCCD_HIP(hipEventCreateWithFlags(&c->side_event, hipEventDisableTiming));
+            SCCD_HIP(hipEventCreateWithFlags(&c->side_event2, hipEventDisableTiming));
             pl->bp_ee.ctx = c->side;
             // (the helper's stream with the lowest / highest queue priority was measured in round 3: no effect)
         }
@@ -308,10 +309,14 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
         hipEvent_t const ev = c->side_event;
         sccd_broad_phase* const bp_ee = &pl->bp_ee;
         const sccd_boxes* const eb = &pl->eb;
+        const double toi_start = toi;
         pl->worker.submit([=] {
             SCCD_HIP(hipSetDevice(device));
             SCCD_HIP(hipStreamWaitEvent(sc->stream, ev, 0));
+            sc->np_init_pending = true; // (the build's grid kernel starts the counters of the edge-edge narrow launch too)
+            sc->np_init_toi = toi_start;
             bp_build(bp_ee, eb, nullptr);
+            sc->np_init_pending = false;
         });
         helper = true;
     }
@@ -328,6 +333,11 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
             // edge-edge sweep starts the moment that sweep ends -- not a host round trip later
             SCCD_HIP(hipEventRecord(c->side_event, c->stream));
             SCCD_HIP(hipStreamWaitEvent(c->side->stream, c->side_event, 0));
+            // ... and the vertex-face narrow kernel is ordered behind THAT point of the helper's stream (below): the sweep's
+            // blocks must be resident first.  Left to the race -- a host round trip against an event wait -- the narrow kernel
+            // sometimes won, filled every SIMD, and the sweep (78 KB of LDS per block) waited for its waves to retire: the
+            // step went from 1.17 to 1.25-1.30 ms the day the read-backs became 10 us faster.
+            SCCD_HIP(hipEventRecord(c->side_event2, c->side->stream));
             c->side->sweep_blocks_per_cu = 2;
             try {
                 bp_detect_partial(&pl->bp_ee, 1);
@@ -354,8 +364,10 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
             sc->scalar_f32 = c->scalar_f32;
             sc->narrow_algo = c->narrow_algo;
             sc->limit_level_order = c->limit_level_order;
+            c->np_init_pending = true; // (the counters of the vertex-face narrow launch: started by the build's grid kernel)
+            c->np_init_toi = toi;
             bp_build(&pl->bp, &pl->vb, &pl->fb);
-            narrow_counters_upload(c, narrow_counters(c), toi);
+            c->np_init_pending = false;
             // the vertex-face sweep is enqueued, the edge-edge sweep behind it (on the helper's stream, by an event), and only
             // then does the host wait for the vertex-face pairs: the narrow kernel it launches next finds the edge-edge
             // sweep's blocks resident already and takes the rest of the chip
@@ -367,13 +379,13 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
             const NarrowParams pv = narrow_params(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, 1, max_iter, tol, ms, allow_zero_toi);
             if (vf_one_chunk && narrow_uses_walk_kernel(c, pv, false)) {
                 double toi_vf = toi, toi_ee = toi;
+                if (lab_env().narrow_order) SCCD_HIP(hipStreamWaitEvent(c->stream, c->side_event2, 0)); // (start_ee_sweep)
                 narrow_phase_begin(c, pv, narrow_counters(c), &toi_vf, nullptr); // (asynchronous)
                 bp_detect_partial(&pl->bp_ee, 2);                                 // waits for the edge-edge sweep
                 if (pl->bp_ee.cursor >= pl->bp_ee.total_rows) {
                     NarrowParams pe = narrow_params(sc, m, pl->bp_ee.overlaps.as<int2>(), pl->bp_ee.n_overlaps, 0, max_iter, tol, ms, allow_zero_toi);
                     pe.toi_word = &narrow_counters(c)->toi_bits;
-                    narrow_counters_upload(sc, narrow_counters(sc), toi_ee);
-                    c->np_peer_stream = sc->stream;
+                    c->np_peer_stream = sc->stream; // (the helper's counters were started by its build: narrow_phase_begin uploads only if not)
                     try {
                         narrow_phase_begin(sc, pe, narrow_counters(sc), &toi_ee, nullptr);
                         narrow_phase_end(c, pv, narrow_counters(c), &toi_vf, nullptr);

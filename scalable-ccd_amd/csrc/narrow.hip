@@ -634,13 +634,21 @@ static void run_walk_f32(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_c
     SCCD_HIP(hipGetLastError());
 }
 
-// counters = {zeros, toi}: from the pinned mirror [12 KB, 16 KB)
+// counters = {toi, zeros}: a kernel whose arguments carry the TOI.  (It was an upload from the pinned mirror: a copy kernel that
+// reads host memory, 7 us -- and one that does not fit beside resident narrow-phase waves, so the helper's upload for the
+// edge-edge launch sat 85 us in its queue.  Eight vector registers at most: tests/test_kernel_resources.py.)
+__global__ __launch_bounds__(256) void np_counters_init_k(unsigned long long* __restrict__ cnt, int words, unsigned long long toi_bits)
+{
+    for (int k = threadIdx.x; k < words; k += 256) cnt[k] = k == 0 ? toi_bits : 0ull;
+}
 void narrow_counters_upload(sccd_ctx* c, NarrowCounters* d_cnt, double toi)
 {
-    NarrowCounters* const h_up = reinterpret_cast<NarrowCounters*>(c->h_scalars.as<char>() + 12288);
-    std::memset(h_up, 0, sizeof(NarrowCounters));
-    std::memcpy(&h_up->toi_bits, &toi, 8);
-    SCCD_HIP(hipMemcpyAsync(d_cnt, h_up, sizeof(NarrowCounters), hipMemcpyHostToDevice, c->stream));
+    static_assert(offsetof(NarrowCounters, toi_bits) == 0 && sizeof(NarrowCounters) % 8 == 0, "np_counters_init_k: the TOI is word 0");
+    unsigned long long bits;
+    std::memcpy(&bits, &toi, 8);
+    hipLaunchKernelGGL(np_counters_init_k, dim3(1), dim3(256), 0, c->stream, reinterpret_cast<unsigned long long*>(d_cnt),
+                       (int)(sizeof(NarrowCounters) / 8), bits);
+    SCCD_HIP(hipGetLastError());
     c->np_uploaded = true;
     c->np_uploaded_toi = toi;
 }

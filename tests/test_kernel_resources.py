@@ -56,3 +56,15 @@ def test_no_kernel_uses_scratch_memory(tmp_path):
                 # two four-wave blocks per CU by LDS (78 KB each): two waves per SIMD, so 256 VGPRs are the budget
                 assert r["next_free_vgpr"] <= 256, (name, r)
                 assert r["group_segment_fixed_size"] <= 80 * 1024, (name, r)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_readback_gather_kernel_fits_beside_narrow_phase_waves(tmp_path):
+    # three np_walk_k waves of 168 VGPRs leave 8 of a SIMD lane's 512: the read-back's gather kernel (api.hip) must fit into
+    # those, or a read-back issued beside the narrow phase waits for a wave to retire
+    ks = {k: v for k, v in _kernels("api", tmp_path).items() if "readback_gather_k" in k}
+    # ... and so must the kernel that starts a narrow launch's counters (the helper issues it beside the vertex-face kernel)
+    ks.update({k: v for k, v in _kernels("narrow", tmp_path).items() if "np_counters_init_k" in k})
+    assert len(ks) == 2
+    for name, r in ks.items():
+        assert r["next_free_vgpr"] <= 8 and r["group_segment_fixed_size"] == 0, (name, r)

@@ -7,7 +7,10 @@ f=sorted(glob.glob("gpurun_out/tl/*/*kernel_trace.csv"))[-1]
 rows=list(csv.DictReader(open(f)))
 ev=sorted((int(r["Start_Timestamp"]),int(r["End_Timestamp"]),r["Kernel_Name"],r.get("Queue_Id","?")) for r in rows)
 starts=[i for i,e in enumerate(ev) if "vertex_boxes_k" in e[2]]
-a,b=starts[-2],starts[-1]
+# (the run ends with steps of other kinds -- host matrices, the step without the TOI bound: take the step of median length)
+iv=sorted((ev[starts[k+1]][0]-ev[starts[k]][0],k) for k in range(len(starts)-1))
+k=iv[len(iv)//2][1]
+a,b=starts[k],starts[k+1]
 t0=ev[a][0]
 for s,e,n,q in ev[a:b]:
     n=n.replace("(anonymous namespace)::","").replace("void ","").split("(")[0][:28]
