@@ -66,17 +66,30 @@ def lib_sha256():
         return hashlib.sha256(f.read()).hexdigest()
 
 
-def clock_warmup(step, seconds):
+def clock_warmup(step, seconds, agree=None):
     """Untimed: `seconds` of the workload's own steps BEFORE the W warm-up steps.  A fresh box starts a process with the GPU idle
     (clocks down, nothing paged in): the first run of the day on the round-3 library measured 1.41 ms per step and the second, a
     minute later on the same box, 1.30 -- W = 5 warm-up steps are 6 ms, far less than the clocks need.  Returns the steps run
-    (reported as config.clock_warmup_steps); --clock-warmup 0 switches it off."""
-    n = 0
-    t_end = time.perf_counter() + seconds
-    while time.perf_counter() < t_end:
+    (reported as config.clock_warmup_steps); --clock-warmup 0 switches it off.
+    `agree` (several ranks: a step holds a collective, so every rank must run the SAME number of steps -- a loop that each rank
+    ends by its own clock leaves the ranks out of step and the job hangs): maps a rank's own count to the count all ranks run."""
+    if seconds <= 0:
+        return 0
+    if agree is None:
+        n = 0
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            step()
+            n += 1
+        return n
+    t0 = time.perf_counter()
+    for _ in range(3):
         step()
-        n += 1
-    return n
+    per = max(1e-5, (time.perf_counter() - t0) / 3)
+    n = agree(min(20000, max(0, int(seconds / per) - 3)))
+    for _ in range(n):
+        step()
+    return n + 3
 
 
 def parse():
@@ -205,7 +218,12 @@ def main():
         # and which class dominates.  The timed region keeps events on that one class only -- two event records
         # per class scope cost 0.15 ms of a 2.3 ms step with all classes on.
         n_prof = 2
-        n_clock = clock_warmup(step, args.clock_warmup)
+        def agree(n):  # the smallest of the ranks' counts
+            t = torch.tensor([n], dtype=torch.int64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item())
+
+        n_clock = clock_warmup(step, args.clock_warmup, agree if use_dist else None)
         for _ in range(args.warmup):
             step()
         ctx.set_option(sccd.OPT_PROFILE, 1)
