@@ -351,12 +351,29 @@ def main():
             step()
         ctx.set_option(sccd.OPT_PROFILE, 1)
         ctx.reset_profile()
+        st_apart = stats
         for _ in range(n_prof):
-            step()
+            _, st_apart = step()
         prof_apart = {k: v[0] / n_prof for k, v in ctx.profile().items()}
         ctx.set_option(sccd.OPT_PROFILE, 0)
         ctx.set_option(sccd.OPT_PASSES_APART, 0)
         broad_ms = prof_apart["boxes"] + prof_apart["sort"] + prof_apart["ranges"] + prof_apart["sweep"]
+        if dom.startswith("narrow") and prof_apart.get(dom, 0) > 0:
+            # `achieved` above is the contract's figure: the launch's own duration in the timed region.  Since round 4's read-back
+            # mailbox the edge-edge launch STARTS ~120 us earlier -- in the SIMD slots its sweep left, beside the
+            # vertex-face kernel, taking over as that kernel's waves retire -- so its duration now holds ~150 us in which it has
+            # a fraction of the chip: the step got shorter, the launch longer, `frac` lower.  The same launch with the chip to
+            # itself (passes apart, same process, untimed) is the kernel's own figure:
+            c_alone = float(st_apart["n_ee_checks" if dom == "narrow_ee" else "n_vf_checks"])
+            a_alone = c_alone * FLOP_PER_CHECK / (prof_apart[dom] * 1e-3) / 1e12
+            roofline["alone"] = {
+                "launch_ms": round(prof_apart[dom], 4), "checks_per_launch": c_alone, "achieved": round(a_alone, 3),
+                "frac": round(a_alone / FP64_VALU_PEAK_TFLOPS, 5),
+                "executed_frac": round(a_alone * FLOP_PER_CHECK_EXECUTED / FLOP_PER_CHECK / FP64_VALU_PEAK_TFLOPS, 5),
+                "note": "the dominant launch with nothing beside it (SCCD_OPT_PASSES_APART, %d untimed steps in this process); `frac` above "
+                        "is the same launch as it runs in the timed steps, where it shares the SIMDs with the vertex-face kernel for "
+                        "its first ~150 us (DESIGN 5.6 / 7)" % n_prof,
+            }
         # the slowest rank's device time per phase (passes apart): narrow-phase scaling is readable on its own
         mx = torch.tensor([broad_ms, prof_apart["narrow_vf"] + prof_apart["narrow_ee"]], dtype=torch.float64, device=red_dev)
         if use_dist:

@@ -7,12 +7,12 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
 for W in cloth1m boxes1m sort16m; do
   rm -rf gpurun_out/prof/ks_$W
-  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_$W --output-format csv -- python3 bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof/ks_$W.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_$W --output-format csv -- python3 bench.py --workload $W --steps 5 --warmup 2 --clock-warmup 0.2 --no-cpu-baseline > gpurun_out/prof/ks_$W.log 2>&1
   cp $(ls gpurun_out/prof/ks_$W/*/*kernel_stats.csv | tail -n 1) gpurun_out/prof/${R}_${W}_kernel_stats.csv
 done
 # (the default step overlaps two streams: each kernel's own duration, one kernel at a time on the chip, is in this trace)
 rm -rf gpurun_out/prof/ks_cloth1m_apart
-SCCD_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_cloth1m_apart --output-format csv -- python3 bench.py --workload cloth1m --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof/ks_cloth1m_apart.log 2>&1
+SCCD_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_cloth1m_apart --output-format csv -- python3 bench.py --workload cloth1m --steps 5 --warmup 2 --clock-warmup 0.2 --no-cpu-baseline > gpurun_out/prof/ks_cloth1m_apart.log 2>&1
 cp $(ls gpurun_out/prof/ks_cloth1m_apart/*/*kernel_stats.csv | tail -1) gpurun_out/prof/${R}_cloth1m_passes_apart_kernel_stats.csv
 for W in cloth1m sort16m boxes1m; do
   bash tools/pmc_traffic.sh $W > gpurun_out/prof/pmc_traffic_$W.txt 2>&1
@@ -37,8 +37,10 @@ timeout 600 python3 bench.py --workload boxes1m --boxes-n 16000000 --steps 10 2>
 for V in "thin --boxes-variant thin" "16m --boxes-n 16000000"; do
   set -- $V; T=$1; shift
   rm -rf gpurun_out/prof/ks_boxes_$T
-  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_boxes_$T --output-format csv -- python3 bench.py --workload boxes1m "$@" --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof/ks_boxes_$T.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_boxes_$T --output-format csv -- python3 bench.py --workload boxes1m "$@" --steps 5 --warmup 2 --clock-warmup 0.2 --no-cpu-baseline > gpurun_out/prof/ks_boxes_$T.log 2>&1
   cp $(ls gpurun_out/prof/ks_boxes_$T/*/*kernel_stats.csv | tail -1) gpurun_out/prof/${R}_boxes_${T}_kernel_stats.csv
 done
 timeout 600 python3 tools/boxes_variants.py > gpurun_out/prof/${R}_boxes_variants.log 2>&1
+# (the raw rocprofv3 output is not kept: gpurun merges at most 64 MiB back, and the summaries above are what is judged)
+rm -rf gpurun_out/prof/ks_* gpurun_out/pmc_* gpurun_out/pmcsq_* gpurun_out/kstats gpurun_out/kshard
 ls -la gpurun_out/prof

@@ -23,7 +23,7 @@ for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
          "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
   rm -rf gpurun_out/pmcsq_$i
-  timeout 600 rocprofv3 --pmc $G -d gpurun_out/pmcsq_$i --output-format csv -- python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmcsq_$i.log 2>&1 || tail -3 gpurun_out/pmcsq_$i.log
+  timeout 600 rocprofv3 --pmc $G -d gpurun_out/pmcsq_$i --output-format csv -- python3 bench.py --workload $W --steps 2 --warmup 1 --clock-warmup 0 --no-cpu-baseline > gpurun_out/pmcsq_$i.log 2>&1 || tail -3 gpurun_out/pmcsq_$i.log
 done
 python3 - <<PY
 import csv,glob,collections,json
