@@ -148,3 +148,75 @@ def test_bench_two_ranks_share_one_gpu_and_agree_with_one_rank():
     # (the candidates are a work metric of the cell grid, and a sharded rank sizes its grid from a sample of the edge and
     # face boxes -- it never builds them all: the same pair set from a slightly different grid)
     assert abs(b["config"]["candidates_per_step"] - a["config"]["candidates_per_step"]) < 0.25 * a["config"]["candidates_per_step"]
+
+
+def _warmup_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    import bench
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        calls = {"n": 0}
+
+        def step():  # a step holds a collective, like bench.py's; rank 1 is the slower rank
+            time.sleep(0.001 * (1 + 3 * rank))
+            t = torch.tensor([float(rank)])
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            calls["n"] += 1
+
+        def agree(n):
+            t = torch.tensor([n], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item())
+
+        n = bench.clock_warmup(step, 0.2, agree)
+        # what follows the warm-up in bench.py: more collectives, which must still pair up
+        for _ in range(5):
+            step()
+        dist.barrier()
+        q.put((rank, n, calls["n"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_clock_warmup_runs_the_same_number_of_steps_on_every_rank():
+    """bench.py warms the clocks with its own steps for a fixed TIME; with several ranks a step holds an all-reduce, so the ranks
+    must agree on a COUNT -- each rank ending the loop by its own clock left them out of step and a 2-rank job hung (round 4)."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_warmup_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, n0, c0), (_, n1, c1) = out
+    assert n0 == n1 >= 3 and c0 == c1 == n0 + 5
+
+
+def test_clock_warmup_single_rank_is_time_bound_and_can_be_switched_off():
+    sys.path.insert(0, ROOT)
+    import time
+
+    import bench
+
+    calls = {"n": 0}
+
+    def step():
+        time.sleep(0.002)
+        calls["n"] += 1
+
+    assert bench.clock_warmup(step, 0) == 0 and calls["n"] == 0
+    t0 = time.perf_counter()
+    n = bench.clock_warmup(step, 0.05)
+    assert n == calls["n"] >= 2 and time.perf_counter() - t0 < 1.0
+    assert bench.clock_warmup(step, 0.05, lambda k: 4) == 7  # three timed steps + what the ranks agreed on
