@@ -42,7 +42,7 @@ def srt(p):
 
 # Seeds whose ORACLE takes minutes (a few hundred triangles under a minimum separation larger than the scene's features: every query
 # touches and is bisected to the tolerance; the library needs 0.02 s): the oracle's TOI, computed once on the CPU
-# (tools/jobs/seed_probe.py prints the library's side).  A batch of 20 with one of them ran into CHILD_TIMEOUT.
+# (tools/jobs/slow_seed_probe.py prints the library's side).  A batch of 20 with one of them ran into CHILD_TIMEOUT.
 ORACLE_TOI = {900004: "0x1.ecf8ae0000000p-3", 900536: "0x1.e461510000000p-3"}
 BATCH = 20          # seeds per child process
 CHILD_TIMEOUT = 420  # seconds of wall clock per child
