@@ -37,22 +37,32 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # AMD's MI355X specification: 78.6 TFLOP/s FP64 ve
 BYTES_BROAD_PER_BOX = 548.0   # box build 124 + radix sort 204 + payload gather 128 + counts/scan 28 + sweep 64, + 8 B per pair
 
 
-def pmc_kernels(workload):
-    """per-kernel HBM bytes of profiles/r04_pmc_traffic_<workload>.json if that profile is of THIS build, else None"""
+def _pmc_file(name):
+    """a PMC profile (tools/pmc_traffic.sh, tools/pmc_sq.sh) if it was taken on THIS build's kernels, else None.  The files carry
+    the SHA-256 of the library they profiled and of its device code (the .hip_fatbin section: every kernel's code object); a
+    library whose HOST code changed and whose kernels did not -- the last fix of round 4 was one such line -- still runs the
+    kernels the counters were read from, so either hash admits the file."""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic_%s.json" % workload)))
-        return tj["kernels"] if tj.get("lib_sha256") == lib_sha256() else None
+        tj = json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return None
+    if tj.get("lib_sha256") == lib_sha256():
+        return tj
+    if tj.get("device_code_sha256") and tj.get("device_code_sha256") == device_code_sha256():
+        return tj
+    return None
+
+
+def pmc_kernels(workload):
+    """per-kernel HBM bytes of profiles/r04_pmc_traffic_<workload>.json if that profile is of THIS build's kernels, else None"""
+    tj = _pmc_file("r04_pmc_traffic_%s.json" % workload)
+    return tj["kernels"] if tj else None
 
 
 def pmc_sq(workload):
-    """SQ counters per kernel of profiles/r04_pmc_sq_<workload>.json (tools/pmc_sq.sh) if taken on THIS build, else None"""
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_sq_%s.json" % workload)))
-        return tj["kernels"] if tj.get("lib_sha256") == lib_sha256() else None
-    except Exception:
-        return None
+    """SQ counters per kernel of profiles/r04_pmc_sq_<workload>.json (tools/pmc_sq.sh) if taken on THIS build's kernels, else None"""
+    tj = _pmc_file("r04_pmc_sq_%s.json" % workload)
+    return tj["kernels"] if tj else None
 
 
 def lib_sha256():
@@ -64,6 +74,35 @@ def lib_sha256():
 
     with open(sccd._LIB_PATH, "rb") as f:
         return hashlib.sha256(f.read()).hexdigest()
+
+
+def device_code_sha256(path=None):
+    """SHA-256 of the .hip_fatbin section -- the code objects of every kernel -- of the libsccd_hip.so this process runs (or of
+    `path`): an ELF64 section table walked by hand, no tool needed.  None if there is no such section."""
+    import hashlib
+    import struct
+
+    if path is None:
+        import sccd
+
+        path = sccd._LIB_PATH
+    with open(path, "rb") as f:
+        b = f.read()
+    if b[:4] != b"\x7fELF" or b[4] != 2:
+        return None
+    shoff = struct.unpack_from("<Q", b, 0x28)[0]
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+
+    def section(i):
+        name, _typ, _flags, _addr, off, size = struct.unpack_from("<IIQQQQ", b, shoff + i * shentsize)
+        return name, off, size
+
+    _, stroff, _ = section(shstrndx)
+    for i in range(shnum):
+        name, off, size = section(i)
+        if b[stroff + name: b.index(b"\0", stroff + name)] == b".hip_fatbin":
+            return hashlib.sha256(b[off:off + size]).hexdigest()
+    return None
 
 
 def clock_warmup(step, seconds, agree=None):
@@ -302,13 +341,14 @@ def main():
         # THIS build of the library: the JSON carries the hash of the libsccd_hip.so it profiled
         traffic, traffic_note = None, "no PMC profile of this workload"
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic_cloth1m.json")))
-            if args.workload == "cloth1m" and args.cloth_n == 708 and world == 1:
-                if tj.get("lib_sha256") == lib_sha256():
+            if args.workload == "cloth1m" and args.cloth_n == 708 and world == 1 and os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_traffic_cloth1m.json")):
+                tj = _pmc_file("r04_pmc_traffic_cloth1m.json")
+                if tj:
                     traffic = tj["kernels"][units[dom][2]]["hbm_bytes_per_launch_corrected"]
-                    traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build (profiles/r04_pmc_traffic_cloth1m.json)"
+                    traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build's kernels (profiles/r04_pmc_traffic_cloth1m.json: "
+                                    + ("same library" if tj.get("lib_sha256") == lib_sha256() else "same device code, host code changed since") + ")")
                 else:
-                    traffic_note = "profiles/r04_pmc_traffic_cloth1m.json was taken on another build of the library: dropped"
+                    traffic_note = "profiles/r04_pmc_traffic_cloth1m.json was taken on other kernels than this library's: dropped"
         except Exception:
             pass
         checks = float(c_vf + c_ee)

@@ -642,6 +642,11 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
                 return;
             }
             chunk_hi = bp->total_rows; // (a speculative build is swept in one chunk: bp_build)
+            // ... and a re-sweep after an overflow covers the SETTLED rows, not the padded bounds the first sweep was launched
+            // for: it runs without the device-side counts, and rows behind a list's real end hold whatever an earlier build
+            // left there -- stale records at best, wild ids at worst (a fault in the narrow kernel: round 4, the memory-limit test
+            // run on a fresh context)
+            chunk_rows = chunk_hi - chunk_lo;
         }
         {
             unsigned long long cs = 0;

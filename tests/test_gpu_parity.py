@@ -231,6 +231,29 @@ def test_memory_limit_halves_the_swept_range(sccd, ctx, orc):
     assert toi == sccd.ccd(V0, V1, E, F, 0.0, -1, 1e-6, True, ctx=ctx)
 
 
+def test_overflow_behind_a_speculative_build_resweeps_the_settled_rows(sccd, orc):
+    """A step whose pair list outgrows its buffer right after a SPECULATIVE build (lists sized by the previous build's counts plus
+    a margin): the re-sweep must cover the settled rows, not the padded bounds -- rows behind a list's real end hold whatever an
+    earlier build left there.  On a context of its own (the suite's shared one has large buffers by now): the first call under a
+    1 MB memory limit leaves 65,536-pair buffers, the second call without the limit builds speculatively and overflows them.
+    Round 4: a memory fault in the vertex-face narrow kernel when test_memory_limit_halves_the_swept_range ran first in a process."""
+    V0, V1, E, F = _scene("soup_dense")
+    want, n_vf, n_ee = orc.ccd(V0, V1, E, F, 0.0, -1, 1e-6, True)
+    own = sccd.Context(0)
+    try:
+        mesh = sccd.Mesh(V0, V1, E, F, ctx=own)
+        own.set_option(sccd.OPT_MEMORY_LIMIT_MB, 1)
+        toi, st = sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True, want_stats=True)
+        assert toi == want and st["n_vf_pairs"] == n_vf and st["n_ee_pairs"] == n_ee
+        own.set_option(sccd.OPT_MEMORY_LIMIT_MB, 0)
+        for _ in range(3):  # (the first of these overflows behind a speculative build; the others find room)
+            toi, st = sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True, want_stats=True)
+            assert toi == want and st["n_vf_pairs"] == n_vf and st["n_ee_pairs"] == n_ee
+        assert own.get_option(sccd.OPT_SPEC_HITS) > 0
+    finally:
+        own.close()
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("two_lists", [False, True])
 def test_sharded_sweeps_partition_the_pair_set(sccd, ctx, orc, world, two_lists):

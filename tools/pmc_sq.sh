@@ -41,7 +41,8 @@ for d in sorted(glob.glob("gpurun_out/pmcsq_*/")):
 import hashlib,os
 lib=os.environ.get("SCCD_LIB") or "scalable-ccd_amd/sccd/libsccd_hip.so"
 sha=hashlib.sha256(open(lib,"rb").read()).hexdigest()
-json.dump({"workload":"$W","lib_sha256":sha,"note":"rocprofv3 --pmc, one pass per counter group (tools/pmc_sq.sh); per-kernel averages over the launches of a 3-step bench run","kernels":out}, open("gpurun_out/pmc_sq_$W.json","w"), indent=1, sort_keys=True)
+import sys; sys.path.insert(0, "."); from bench import device_code_sha256; dev=device_code_sha256(lib)  # (the kernels' code objects: bench.py admits a profile by either hash)
+json.dump({"workload":"$W","lib_sha256":sha,"device_code_sha256":dev,"note":"rocprofv3 --pmc, one pass per counter group (tools/pmc_sq.sh); per-kernel averages over the launches of a 3-step bench run","kernels":out}, open("gpurun_out/pmc_sq_$W.json","w"), indent=1, sort_keys=True)
 for k,v in out.items():
     print(k)
     for c,x in sorted(v.items()): print("   %-26s %.4g"%(c,x))
