@@ -41,7 +41,7 @@ def main():
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     if os.environ.get("SCCD_SOAK_CHILD") != "1":
         sys.exit(supervise(cases, first))
-    ctx = sccd.default_context()
+    shared = sccd.default_context()
     bad = steps_run = 0
     t0 = time.time()
     for seed in range(first, first + cases):
@@ -56,6 +56,13 @@ def main():
                                                 size=float(rng.uniform(0.03, 0.25)), motion=float(rng.uniform(0.0, 0.4)))
         world = int(rng.choice([1, 1, 2, 3, 8]))
         extent = float(np.ptp(V0, axis=0).max())
+        # Every third sequence runs on a context of its OWN with a small initial pair buffer: buffers of the shared context only
+        # ever grow, so the overflow paths -- the first sweep of a sequence, and a sweep BEHIND A SPECULATIVE BUILD when a jump
+        # multiplies the pairs (round 4: that one swept padded rows) -- would otherwise be met once per child process
+        own = sccd.Context(0) if seed % 3 == 1 else None
+        ctx = own if own is not None else shared
+        if own is not None:
+            own.set_option(sccd.OPT_OVERLAP_CAPACITY, int(rng.choice([1024, 4096, 65536])))
         mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
         n_steps = int(rng.integers(4, 9))
         for step in range(n_steps):
@@ -82,6 +89,8 @@ def main():
                 print(f"MISMATCH seed {seed} kind {kind} nF {len(F)} world {world} step {step} amp {amp:.3g}: toi {min(tois)!r} want {want!r}, "
                       f"pairs {pairs} want {nvf + nee}", flush=True)
         mesh.close()
+        if own is not None:
+            own.close()
     print(f"step-soak: {cases} sequences, {steps_run} steps, {bad} mismatches, {time.time() - t0:.1f} s", flush=True)
     sys.exit(1 if bad else 0)
 
