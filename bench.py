@@ -34,6 +34,7 @@ BYTES_SORT_PER_KEY_PASS = 16  # one radix pass over (u32 key, u32 index): read 8
 FLOP_PER_CHECK = 520.0        # one inclusion-function check = 8 corners x 57 FLOP + min/max/tests (the REFERENCE's form)
 FLOP_PER_CHECK_EXECUTED = 156.0  # what np_walk_k executes per check: the min/max form of ti_inclusion_mm
 FP64_VALU_PEAK_TFLOPS = 78.6  # AMD's MI355X specification: 78.6 TFLOP/s FP64 vector (= 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz)
+N_SETTLE = 3                  # untimed steps behind every change of an option, before anything is timed
 BYTES_BROAD_PER_BOX = 548.0   # box build 124 + radix sort 204 + payload gather 128 + counts/scan 28 + sweep 64, + 8 B per pair
 
 
@@ -154,6 +155,7 @@ def parse():
     ap.add_argument("--cliffs", action="store_true", help="cloth workloads: also time the paths that do not run on the plain fast kernel -- ccd() with the "
                     "per-query collision list (with and without a check limit), a check limit on the level-synchronous kernels, the float build "
                     "-- each as a multiple of the default step (block `cliffs` of the line)")
+    ap.add_argument("--scout", type=int, default=None, help="SCCD_OPT_SCOUT: sample queries per lane of ccd()'s scout kernel (0: no scout; default: the library's)")
     ap.add_argument("--clock-warmup", type=float, default=1.0, help="seconds of untimed steps before the W warm-up steps (GPU clocks, first touches); 0: none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="cloth side of the CPU sample (0 = auto)")
@@ -199,6 +201,8 @@ def main():
     ctx.set_option(sccd.OPT_SWEEP_ALGO, args.sweep_algo)
     ctx.set_option(sccd.OPT_SHARD_RANK, rank)
     ctx.set_option(sccd.OPT_SHARD_COUNT, world)
+    if args.scout is not None:
+        ctx.set_option(sccd.OPT_SCOUT, args.scout)
 
     def barrier():
         ctx.synchronize()
@@ -262,6 +266,10 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return int(t.item())
 
+        # THE HEADLINE STARTS EVERY CALL FROM toi = 1 (ccd.cu:125): SCCD_OPT_TOI_GUESS = 0 for warm-up, profile and timed steps.  The
+        # speculative bound (a step starts from 1.125 x the previous step's TOI on the same mesh) is timed afterwards, in its own
+        # block -- on this frozen mesh every step would hand itself its own answer (VERDICT r04 / ADVICE r04).
+        ctx.set_option(sccd.OPT_TOI_GUESS, 0)
         n_clock = clock_warmup(step, args.clock_warmup, agree if use_dist else None)
         for _ in range(args.warmup):
             step()
@@ -276,15 +284,22 @@ def main():
         dom = max(prof_all, key=lambda k: prof_all[k][0] / max(1, prof_all[k][1]))
         class_id = {"boxes": 0, "sort": 1, "ranges": 2, "sweep": 3, "narrow_vf": 4, "narrow_ee": 5}  # SCCD_PROF_*
         ctx.set_option(sccd.OPT_PROFILE, (1 << class_id[dom]) << 1)
+        # settling steps AFTER the last option change and BEFORE t0 (round 4 timed the steps right behind three option writes and a
+        # profile reset: the driver's 20-step window came out 10 % above the 100-step lines of the same library); the profile of
+        # the timed region is reset behind them
+        for _ in range(N_SETTLE):
+            step()
         ctx.reset_profile()
-        ctx.set_option(sccd.OPT_TOI_GUESS_HITS, 0)
         barrier()
         t0 = time.perf_counter()
         q_local = 0
         stats = {}
         toi = 1.0
+        step_ms = []
         for _ in range(args.steps):
+            ts = time.perf_counter()
             toi, stats = step()
+            step_ms.append((time.perf_counter() - ts) * 1e3)  # (a step ends with its TOI on the host: the host clock sees all of it)
             q_local += stats["n_vf_pairs"] + stats["n_ee_pairs"]
         barrier()
         dt = time.perf_counter() - t0
@@ -293,19 +308,21 @@ def main():
         prof = ctx.profile()
         ctx.set_option(sccd.OPT_PROFILE, 0)
         # the speculative TOI bound (a step of a mesh whose previous step found an impact at T starts from 1.125 T, verified):
-        # how often it held over the timed steps, and the same step WITHOUT it (20 untimed steps, every call from toi = 1 as ccd.cu:125)
-        guess = {"hits": ctx.get_option(sccd.OPT_TOI_GUESS_HITS), "misses": ctx.get_option(sccd.OPT_TOI_GUESS_MISSES)}
-        ctx.set_option(sccd.OPT_TOI_GUESS, 0)
-        for _ in range(3):
+        # the same steps WITH it, 20 of them behind settling steps -- hits, misses, ms per step
+        ctx.set_option(sccd.OPT_TOI_GUESS, 1)
+        for _ in range(N_SETTLE):
             step()
+        ctx.set_option(sccd.OPT_TOI_GUESS_HITS, 0)
         barrier()
         tg = time.perf_counter()
         for _ in range(20):
             step()
         barrier()
-        guess["ms_per_step_without"] = round((time.perf_counter() - tg) / 20 * 1e3, 4)
-        ctx.set_option(sccd.OPT_TOI_GUESS, 1)
-        step()  # (learn the bound again for what follows)
+        guess = {"ms_per_step_with": round((time.perf_counter() - tg) / 20 * 1e3, 4),
+                 "hits": ctx.get_option(sccd.OPT_TOI_GUESS_HITS), "misses": ctx.get_option(sccd.OPT_TOI_GUESS_MISSES)}
+        ctx.set_option(sccd.OPT_TOI_GUESS, 0)
+        for _ in range(N_SETTLE):
+            step()
         # max over ranks of the elapsed time, sum over ranks of the queries
         tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         qq = torch.tensor([float(q_local), float(stats["n_vf_checks"] + stats["n_ee_checks"]),
@@ -477,17 +494,27 @@ def main():
             "config": dict(wl, queries_per_step=queries_per_step, toi=toi, arith=["strict", "fma"][args.arith], clock_warmup_steps=n_clock,
                            checks_per_step=float(qq[1].item()), candidates_per_step=float(qq[2].item()),
                            parallelism=f"cell windows sharded over {world} GPU(s), one RCCL all-reduce(min) of the TOI per step",
-                           rccl_ranks=rccl_ranks, backend=(backend if use_dist else "none")),
+                           rccl_ranks=rccl_ranks, backend=(backend if use_dist else "none"), scout_per_lane=ctx.get_option(sccd.OPT_SCOUT)),
             # schema 2 (round 4): min_toi_latency_ms is ONE thing again -- the step's latency on a device-resident mesh, = ms_per_step,
             # as in rounds 1-2 and for any number of ranks; the reference-shaped call from host matrices is host_path_ms only
-            "schema": 2,
+            # schema 3 (round 5): value / ms_per_step are steps that start from toi = 1 (SCCD_OPT_TOI_GUESS = 0, as ccd.cu:125); every
+            # timed step is also clocked on its own (ms_per_step_p50 / p99 / min / max: host clock around a step, which ends with its TOI
+            # on the host); the speculative TOI bound has its own block (toi_guess.ms_per_step_with)
+            "schema": 3,
+            "ms_per_step_p50": round(sorted(step_ms)[len(step_ms) // 2], 4),
+            "ms_per_step_p99": round(sorted(step_ms)[min(len(step_ms) - 1, int(len(step_ms) * 0.99))], 4),
+            "ms_per_step_min": round(min(step_ms), 4), "ms_per_step_max": round(max(step_ms), 4),
+            "ms_first_steps": [round(x, 4) for x in step_ms[:5]],
             "min_toi_latency_ms": dt / args.steps * 1e3,
             "host_path_ms": host_ms,
             "host_path_note": "sccd_ccd() from pageable host matrices, upload and packing inside the call (best of 5; the reference's ccd() uploads inside the call too, ccd.cu:103-106); one rank only",
             "max_iter": args.max_iter,
             "broad_phase": broad,
-            "toi_guess": dict(guess, note="speculative TOI bound: a step starts from 1.125 x the previous step's TOI on the same mesh and is redone from 1 "
-                              "if nothing is found below the bound (exact either way); `--jitter` lines show it on a mesh that moves"),
+            "toi_guess": dict(guess, ms_per_step_without=round(dt / args.steps * 1e3, 4),
+                              note="speculative TOI bound (SCCD_OPT_TOI_GUESS = 1, the library's default; OFF in value / ms_per_step): a step starts from "
+                                   "1.125 x the previous step's TOI on the same mesh and is redone from 1 if nothing is found below the bound (exact "
+                                   "either way).  On this FROZEN mesh every bound is the step's own previous answer: ms_per_step_with is an upper bound "
+                                   "on what the prior can buy, not a headline; `--jitter` lines show it on a mesh that moves"),
             "cliffs": cliffs,
             "rank_max": rank_max,
             "roofline": roofline,

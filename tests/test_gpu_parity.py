@@ -1357,6 +1357,42 @@ def test_speculative_toi_bound_is_exact_through_hits_and_misses(sccd, orc):
         c.close()
 
 
+@pytest.mark.parametrize("path", ["default", "passes_apart", "narrow_algo_1", "cutoff"])
+def test_speculative_toi_bound_is_exact_in_the_float_build(sccd, orc, path):
+    """the bound is 1.125 x a float TOI -- not a float -- and the float build's run_narrow() paths (passes apart, the
+    level-order algorithm, chunked sweeps) round the TOI they start from to float: the bound has to BE that rounded value, or a call
+    in which nothing is accepted below it returns the rounded bound as if it were a hit.  Stepped through holds, misses and
+    no-impact steps on every such path, against the oracle's float twin."""
+    if os.environ.get("SCCD_SPECULATE") == "0":
+        pytest.skip("SCCD_SPECULATE=0 switches the speculative bound off with the speculative build")
+    c = sccd.Context(0)
+    try:
+        c.set_option(sccd.OPT_SCALAR, 1)
+        if path == "passes_apart":
+            c.set_option(sccd.OPT_PASSES_APART, 1)
+        elif path == "narrow_algo_1":
+            c.set_option(sccd.OPT_NARROW_ALGO, 1)
+        elif path == "cutoff":
+            c.set_option(sccd.OPT_MAX_OVERLAP_CUTOFF, 700)
+        V0, V1, E, F = _scene("cloth_ball_small")
+        mesh = sccd.Mesh(V0, V1, E, F, ctx=c)
+        # (scales chosen so that 1.125 x TOI is not float-representable; 0.55 / 0.05 push the impact beyond the bound / away)
+        scales = [1.0, 1.0, 0.9, 0.55, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.05, 0.05, 0.77, 0.77, 0.3, 0.3, 0.3, 0.3, 0.3, 0.77]
+        seen = []
+        for s in scales:
+            W1 = V0 + s * (V1 - V0)
+            mesh.update_vertices(V0, W1)
+            want = orc.ccd(V0, W1, E, F, 0.0, -1, 1e-6, True, nthreads=8, scalar="f32")[0]
+            got = sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True)
+            assert got == want, (path, s, got, want)
+            seen.append(want)
+        hits, misses = c.get_option(sccd.OPT_TOI_GUESS_HITS), c.get_option(sccd.OPT_TOI_GUESS_MISSES)
+        assert hits >= 2 and misses >= 1, (hits, misses, seen)
+        mesh.close()
+    finally:
+        c.close()
+
+
 def test_float_build_is_bounded_on_a_query_that_explodes(sccd, ctx):
     """Soak seed 500388 (a small cloth on a ball, scaled by 104, minimum separation 0.31): in float Condition 1 is out of reach, so
     the queries in resting contact are bisected down to single ulps -- 182 s for the oracle's float twin on 8 cores, minutes for ONE
