@@ -105,10 +105,6 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        * redone from 1); 0: always from 1, as ccd.cu:125 */
 #define SCCD_OPT_TOI_GUESS_HITS 20    /* read: calls whose bound held / broke (redone); setting either resets both */
 #define SCCD_OPT_TOI_GUESS_MISSES 21
-#define SCCD_OPT_SCOUT 22             /* sccd_ccd_mesh / sccd_ccd: sample queries per lane of the SCOUT (default 3; 0: no scout) -- a lean kernel behind the
-                                       * vertex-face sweep that bisects a strided sample of the pairs and lowers the running TOI to the first accepted
-                                       * domain it finds, so that the passes prune from their start (ccd.cu:125 starts them from 1).  Every value it
-                                       * publishes is a domain the reference's bisection accepts: the result is unchanged */
 #define SCCD_OPT_SPEC_HITS 15   /* read: speculative builds (sort, records and sweep enqueued for the previous build's entry counts) whose */
 #define SCCD_OPT_SPEC_MISSES 16 /* guess held / broke and were redone, since the context was made; setting either resets both counters */
 int sccd_set_option(sccd_ctx* ctx, int option, int64_t value);

@@ -132,12 +132,6 @@ void sccd_destroy(sccd_ctx* c)
     if (c->rb_event) (void)hipEventDestroy(c->rb_event);
     if (c->side_event) (void)hipEventDestroy(c->side_event);
     if (c->side_event2) (void)hipEventDestroy(c->side_event2);
-    if (c->scout_stream) {
-        (void)hipStreamSynchronize(c->scout_stream);
-        (void)hipStreamDestroy(c->scout_stream);
-        (void)hipEventDestroy(c->scout_go);
-        (void)hipEventDestroy(c->scout_done);
-    }
     if (c->side) sccd_destroy(c->side);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -197,10 +191,6 @@ int sccd_set_option(sccd_ctx* c, int opt, int64_t v)
     case SCCD_OPT_PASSES_APART: c->passes_apart = v ? 1 : 0; break;
     case SCCD_OPT_CELL_FACTOR_MILLI: c->cell_factor_milli = (int)v; break;
     case SCCD_OPT_BUILD_SCAN: c->build_scan = v ? 1 : 0; break;
-    case SCCD_OPT_SCOUT:
-        if (v < 0 || v > 64) return SCCD_E_INVALID;
-        c->scout_per_lane = (int)v;
-        break;
     case SCCD_OPT_TOI_GUESS:
         c->toi_guess_on = v ? 1 : 0;
         c->toi_guess = 1.0; // (forget what was learnt)
@@ -237,7 +227,6 @@ int64_t sccd_get_option(const sccd_ctx* c, int opt)
     case SCCD_OPT_PASSES_APART: return c->passes_apart;
     case SCCD_OPT_CELL_FACTOR_MILLI: return c->cell_factor_milli;
     case SCCD_OPT_BUILD_SCAN: return c->build_scan;
-    case SCCD_OPT_SCOUT: return c->scout_per_lane;
     case SCCD_OPT_TOI_GUESS: return c->toi_guess_on;
     case SCCD_OPT_TOI_GUESS_HITS: return c->toi_guess_hits;
     case SCCD_OPT_TOI_GUESS_MISSES: return c->toi_guess_misses;

@@ -544,7 +544,6 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
     sccd_ctx* c = bp->ctx;
     if (!bp->built) throw SccdError { SCCD_E_NOT_BUILT, "Must initialize build broad phase before detecting overlaps!" };
     bp->n_overlaps = 0;
-    if (phase != 2) bp->sweep_enqueued = false;
     if (bp->speculative && phase != 2 && (c->max_overlap_cutoff > 0 || c->sweep_algo == 1)) {
         // the options were changed between build and sweep to ones a speculative sweep does not serve (chunks of rows, the
         // plain sweep): read what was built now, and go on with real sizes -- or build again
@@ -621,10 +620,7 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
                 launch_sweep_two(c, A, B, gp, a_lo, a_hi, b_lo, b_hi, bp->overlaps.as<int2>(), bp->capacity, d_cnt, d_tot, bp->guess.key_bits);
             }
         }
-        if (phase == 1) {
-            bp->sweep_enqueued = true;
-            return;
-        }
+        if (phase == 1) return;
     launched:
         SweepCounters h;
         GridReadBack built; // (speculative build: the grid and the entry counts it really had)
@@ -639,7 +635,6 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
         if (bp->speculative) {
             if (!speculation_settle(bp, built, hwin)) {
                 // build again, the slow way (the guess is gone: bp_build waits for the counts), and sweep that
-                scout_join_host(c); // (a scout may still be reading the pairs of the sweep that is about to be repeated)
                 const int64_t done = bp->candidates_done;
                 bp_build(bp, bp->A, bp->B);
                 bp->candidates_done = done;
@@ -666,7 +661,6 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
             break;
         }
         SCCD_REQUIRE(attempt < 64, "broad phase: overlap buffer keeps overflowing");
-        scout_join_host(c); // (the pair list is about to be reallocated and swept again)
         const int64_t want = (int64_t)h.n_pairs + (int64_t)h.n_pairs / 16 + 1024;
         bool grown = false;
         if (want <= limit_pairs) {

@@ -160,14 +160,6 @@ struct sccd_ctx {
     int toi_guess_n[3] = { 0, 0, 0 };
     int64_t toi_guess_hits = 0, toi_guess_misses = 0;
     int toi_guess_rest = 0, toi_guess_backoff = 4; // steps without a bound after a miss (doubling up to 64, halved by a hit)
-    // THE SCOUT (narrow_scout.inc, drivers.hip): ccd() on a mesh launches a lean kernel on a stream of its own right behind the
-    // vertex-face sweep; it walks a strided sample of the pairs (scout_per_lane queries per lane of one wave per SIMD) and publishes
-    // a first bound on the TOI into the narrow phase's running TOI.  SCCD_OPT_SCOUT (0: off).
-    int scout_per_lane = 3;
-    hipStream_t scout_stream = nullptr;
-    hipEvent_t scout_go = nullptr, scout_done = nullptr;
-    bool scout_pending = false; // a scout is (or may be) running: joined on the device before the narrow phase's result is read,
-                                // on the host before its pair list is re-swept or reallocated
     int cell_factor_milli = 0; // SCCD_OPT_CELL_FACTOR_MILLI: grid cell size in thousandths of the mean box extent (0: the default, 4000; < 0: one cell)
     int build_scan = 0;        // SCCD_OPT_BUILD_SCAN: 1 = count -> device-wide scan -> fill (entries in box order) instead of the one-pass append
     // narrow_counters_upload() already put {zeros, this TOI} into the narrow phase's counters (it rides ahead of
@@ -258,19 +250,6 @@ struct ProfScope {
 
 void sccd_collect_profile(sccd_ctx* c); // api.cpp
 
-// the scout's joins (see sccd_ctx::scout_pending)
-inline void scout_join_device(sccd_ctx* c) // the context's stream goes on only behind the scout
-{
-    if (!c->scout_pending) return;
-    c->scout_pending = false;
-    SCCD_HIP(hipStreamWaitEvent(c->stream, c->scout_done, 0));
-}
-inline void scout_join_host(sccd_ctx* c) // the scout has ended when this returns (its pair list may be freed or rewritten)
-{
-    if (!c->scout_pending) return;
-    c->scout_pending = false;
-    SCCD_HIP(hipEventSynchronize(c->scout_done));
-}
 
 // Small device -> host reads (counters, the grid, the TOI: a few hundred bytes, several times per step, each on the step's
 // critical path).  As copies they cost a copy kernel PER ITEM plus an event the host polls: ~14 us per read-back, and a

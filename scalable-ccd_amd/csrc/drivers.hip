@@ -168,19 +168,6 @@ extern "C" int sccd_narrow_phase(sccd_ctx* c, const sccd_mesh* m, const int32_t*
 // ------------------------------------------------------------------------------------------
 // drivers
 
-// THE SCOUT of a pass (narrow_scout.inc): enqueued on c->stream right behind the sweep that bp_detect_partial(bp, 1) has just put
-// there, IN ORDER -- the chip is the scout's alone for its ~35 us, and whatever is ordered behind that point of the stream (the
-// read-back of the pair count, the other pass's sweep on the helper's stream) finds the running TOI lowered to a first bound.
-// (Round 5 tried it on a stream of its own, beside the other kernels: resident behind the vertex-face sweep it kept the second
-// block of the edge-edge sweep off every CU -- 224 + 224 + 166 vector registers per SIMD lane do not fit, and that sweep deals its
-// tiles statically: the step +130 us; beside the walk kernel its waves were placed late and its chain ran 300 us: +20 us and no
-// bound in time.)  The counters it publishes into were started for this pass already (the build's grid kernel, or
-// narrow_counters_upload ahead of the sweep).
-static void scout_start(sccd_ctx* c, const NarrowParams& p, const sccd_broad_phase* bp)
-{
-    const SweepCounters* const sw = c->scalars.as<SweepCounters>(); // (bp_detect_partial: the sweep's counters)
-    narrow_scout_launch(c, c->stream, p, &sw->n_pairs, (long long)bp->capacity, narrow_counters(c), (unsigned)c->scout_per_lane);
-}
 // partial_ccd<run_vf> (ccd.cu:14-78): build, then alternate detect_overlaps_partial / narrow_phase
 // (bp may belong to the helper context: its sweeps then run on that context's stream; every sweep ends with a host
 // round trip, so the narrow phase on c->stream starts after the pairs are complete either way)
@@ -194,15 +181,7 @@ static void ccd_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, sccd_broad_p
     bool started = swept; // (... and the first sweep enqueued as well: bp_detect_partial(bp, 1))
     while (bp->cursor < bp->total_rows) {
         narrow_counters_upload(c, narrow_counters(c), *toi); // ahead of the sweep: one copy less between sweep and narrow phase
-        if (!started && vf && bp->ctx == c && c->scout_per_lane > 0 && *toi > 0 && !c->scalar_f32) {
-            // (the vertex-face pass starts without a bound: its scout rides behind the sweep -- see scout_start)
-            bp_detect_partial(bp, 1);
-            const NarrowParams ps = narrow_params(c, m, bp->overlaps.as<int2>(), 0, 1, max_iter, tol, ms, allow_zero_toi);
-            if (bp->sweep_enqueued && narrow_uses_walk_kernel(c, ps, false) && max_iter < 0) scout_start(c, ps, bp);
-            bp_detect_partial(bp, 2);
-        } else {
-            bp_detect_partial(bp, started ? 2 : 0);
-        }
+        bp_detect_partial(bp, started ? 2 : 0);
         started = false;
         if (before_narrow && *before_narrow) {
             (*before_narrow)();
@@ -397,11 +376,6 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
             // then does the host wait for the vertex-face pairs: the narrow kernel it launches next finds the edge-edge
             // sweep's blocks resident already and takes the rest of the chip
             bp_detect_partial(&pl->bp, 1);
-            // the scout: only where the walk kernel will serve the pass (double build, no check limit) from a TOI above 0
-            if (c->scout_per_lane > 0 && pl->bp.sweep_enqueued && toi > 0 && !c->scalar_f32) {
-                const NarrowParams ps = narrow_params(c, m, pl->bp.overlaps.as<int2>(), 0, 1, max_iter, tol, ms, allow_zero_toi);
-                if (narrow_uses_walk_kernel(c, ps, false)) scout_start(c, ps, &pl->bp);
-            }
             start_ee_sweep();
             start_ee_sweep = nullptr;
             bp_detect_partial(&pl->bp, 2);
@@ -475,13 +449,8 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
             }
             (void)hipStreamSynchronize(c->side->stream);
         }
-        if (c->scout_pending) { // (nothing of this call may outlive it)
-            c->scout_pending = false;
-            (void)hipStreamSynchronize(c->scout_stream);
-        }
         throw;
     }
-    scout_join_device(c); // (every path above has read the pass's result behind the scout already: narrow_phase_end)
     if (both_done) {
         // (both passes are behind us; each pair list was swept in one chunk and is still on the device)
         if (lists_resident) *lists_resident = true;

@@ -98,7 +98,6 @@ struct sccd_broad_phase {
         double cell_factor = 0;
         uint32_t total[2] = { 0, 0 };
     } guess;
-    bool sweep_enqueued = false;           // bp_detect_partial(bp, 1) launched a sweep (its counters and pairs are this build's)
     bool one_class = false;                // a two-list build whose sweep runs list B's rows only (api.hip bp_build)
     bool speculative = false;              // la.m / lb.m are BOUNDS until bp_detect_partial has checked the guess
     bool spec_window = false;              // ... of a rank's cell window, dealt out on the device
@@ -255,10 +254,6 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
 void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
                       double* d_per_query_toi);
 bool narrow_uses_walk_kernel(const sccd_ctx* c, const NarrowParams& p, bool per_query); // (else: level-synchronous kernels)
-// the scout (narrow_scout.inc): a first bound on the TOI from a strided sample of the pairs a sweep is about to have written
-// (count read from *d_n_pairs on the device), on stream s; publishes into p.toi_word / d_cnt->toi_bits, adds its checks to d_cnt
-void narrow_scout_launch(sccd_ctx* c, hipStream_t s, const NarrowParams& p, const unsigned long long* d_n_pairs, long long capacity,
-                         NarrowCounters* d_cnt, unsigned per_lane);
 // ti_census.cpp (host): ONE query bisected alone in the reference's level order with the check limit
 double ti_census_level_order(const double v[8][3], int is_vf, int arith, double ms, double tol, int max_iter, int allow_zero_toi,
                              double toi_init, long long max_live, bool* gave_up);

@@ -381,7 +381,6 @@ __global__ void np_reset_selected_k(double* __restrict__ per_query, const int* _
 } // namespace
 
 #include "narrow_walk.inc"
-#include "narrow_scout.inc"
 
 // ------------------------------------------------------------------------------------------
 // The FLOAT build (SCCD_OPT_SCALAR = 1, the reference's SCALABLE_CCD_USE_DOUBLE = OFF) depth first: one lane = one query at a
@@ -760,7 +759,6 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
 {
     NarrowCounters h;
     const long long n = p.n_pairs;
-    scout_join_device(c); // (a scout of this pass publishes into the same counters: they are read behind it)
     {
         // (a launch that kept its running TOI in another launch's word: that word is its result so far -- read in the same
         // round trip; a second, blocking copy here was 25 us at the end of every ccd() step)
