@@ -577,16 +577,21 @@ def bench_jitter(args, ctx, sccd, torch, mesh, tV0, tV1, params, wl, world):
     ctx.set_option(sccd.OPT_SPEC_HITS, 0)
     ctx.set_option(sccd.OPT_TOI_GUESS_HITS, 0)
     steps = max(args.steps, 200)
-    times, missed, tois, queries = [], [], [], 0
+    times, missed, tois, queries, allocs, toi_missed, qs = [], [], [], 0, [], [], []
     ctx.synchronize()
     t0 = time.perf_counter()
     for k in range(steps):
         m0 = ctx.get_option(sccd.OPT_SPEC_MISSES)
+        a0 = ctx.get_option(sccd.OPT_ALLOC_COUNT)
+        g0 = ctx.get_option(sccd.OPT_TOI_GUESS_MISSES)
         ts = time.perf_counter()
         toi, st = step(k + 1)
         times.append((time.perf_counter() - ts) * 1e3)
         missed.append(ctx.get_option(sccd.OPT_SPEC_MISSES) - m0)
+        allocs.append(ctx.get_option(sccd.OPT_ALLOC_COUNT) - a0)
+        toi_missed.append(ctx.get_option(sccd.OPT_TOI_GUESS_MISSES) - g0)
         tois.append(toi)
+        qs.append(st["n_vf_pairs"] + st["n_ee_pairs"])
         queries += st["n_vf_pairs"] + st["n_ee_pairs"]
     ctx.synchronize()
     dt = time.perf_counter() - t0
@@ -610,6 +615,14 @@ def bench_jitter(args, ctx, sccd, torch, mesh, tV0, tV1, params, wl, world):
         "steps_with_a_miss": len(miss_t), "median_ms_hit": med(hit_t), "median_ms_miss": med(miss_t),
         "miss_over_hit": (round(med(miss_t) / med(hit_t), 3) if miss_t and hit_t else None),
         "toi_min": min(tois), "toi_max": max(tois), "queries_per_step": queries / steps,
+        # what a miss of the speculative TOI bound costs (the narrow phases redone from 1), and the slow steps attributed
+        "median_ms_toi_hit": med([t for t, g in zip(times, toi_missed) if g == 0]),
+        "median_ms_toi_miss": med([t for t, g in zip(times, toi_missed) if g > 0]),
+        "steps_with_a_toi_miss": sum(1 for g in toi_missed if g > 0),
+        "steps_that_allocated": sum(1 for a in allocs if a > 0),
+        "median_ms_alloc_step": med([t for t, a in zip(times, allocs) if a > 0]),
+        "slowest_steps": [{"step": i, "ms": round(times[i], 3), "allocs": allocs[i], "spec_miss": missed[i], "toi_miss": toi_missed[i], "queries": qs[i]}
+                          for i in sorted(range(len(times)), key=lambda i: -times[i])[:8]],
     }
 
 

@@ -105,6 +105,8 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        * redone from 1); 0: always from 1, as ccd.cu:125 */
 #define SCCD_OPT_TOI_GUESS_HITS 20    /* read: calls whose bound held / broke (redone); setting either resets both */
 #define SCCD_OPT_TOI_GUESS_MISSES 21
+#define SCCD_OPT_ALLOC_COUNT 23       /* read: device allocations the library's grow-only buffers have made since it was loaded (all contexts): a call
+                                       * during which the count rises has grown a buffer -- hipFree + hipMalloc, milliseconds */
 #define SCCD_OPT_SPEC_HITS 15   /* read: speculative builds (sort, records and sweep enqueued for the previous build's entry counts) whose */
 #define SCCD_OPT_SPEC_MISSES 16 /* guess held / broke and were redone, since the context was made; setting either resets both counters */
 int sccd_set_option(sccd_ctx* ctx, int option, int64_t value);

@@ -227,6 +227,7 @@ int64_t sccd_get_option(const sccd_ctx* c, int opt)
     case SCCD_OPT_PASSES_APART: return c->passes_apart;
     case SCCD_OPT_CELL_FACTOR_MILLI: return c->cell_factor_milli;
     case SCCD_OPT_BUILD_SCAN: return c->build_scan;
+    case SCCD_OPT_ALLOC_COUNT: return devbuf_alloc_count();
     case SCCD_OPT_TOI_GUESS: return c->toi_guess_on;
     case SCCD_OPT_TOI_GUESS_HITS: return c->toi_guess_hits;
     case SCCD_OPT_TOI_GUESS_MISSES: return c->toi_guess_misses;

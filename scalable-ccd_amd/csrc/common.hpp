@@ -40,6 +40,13 @@ struct SccdError {
     } while (0)
 
 // ------------------------------------------------------------------------------------------
+// device allocations made by DevBuf::ensure since the library was loaded (SCCD_OPT_ALLOC_COUNT: a step that allocates is a slow
+// step -- hipFree + hipMalloc are milliseconds -- and a caller, or bench.py --jitter, can tell such steps from the others)
+inline long long& devbuf_alloc_count()
+{
+    static long long n = 0; // (diagnostic: plain increments, contexts on several threads may lose a count)
+    return n;
+}
 // grow-only device buffer (no hipMalloc in the steady state of repeated ccd() calls)
 struct DevBuf {
     void* p = nullptr;
@@ -60,6 +67,7 @@ struct DevBuf {
         if (bytes <= cap) return;
         release();
         size_t want = bytes + bytes / 8 + 256;
+        devbuf_alloc_count() += 1;
         SCCD_HIP(hipMalloc(&p, want));
         cap = want;
     }

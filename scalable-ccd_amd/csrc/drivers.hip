@@ -342,7 +342,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
             // sometimes won, filled every SIMD, and the sweep (78 KB of LDS per block) waited for its waves to retire: the
             // step went from 1.17 to 1.25-1.30 ms the day the read-backs became 10 us faster.
             SCCD_HIP(hipEventRecord(c->side_event2, c->side->stream));
-            c->side->sweep_blocks_per_cu = 2;
+            c->side->sweep_blocks_per_cu = 0; // (the sweep kernel's own choice: a full CU)
             try {
                 bp_detect_partial(&pl->bp_ee, 1);
             } catch (...) {
