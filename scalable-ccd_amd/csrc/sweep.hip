@@ -46,22 +46,7 @@ constexpr int SW_WIN = 128;   // column slots of a wave's window (slot = column 
 constexpr int SW_SEG = 32;    // columns per staging segment = steps per filter block
 constexpr int SW_MIR = SW_SEG; // the filter's arrays repeat their first segment behind the last: a run of 32 steps never wraps
 constexpr int SW_QCAP = 256;  // candidate queue entries per wave
-#ifndef SW_OCAP_
-#define SW_OCAP_ 1024
-#endif
-constexpr int SW_OCAP = SW_OCAP_; // staged output pairs per wave
-#ifndef SW_GROUP
-#define SW_GROUP 8 // filter steps whose LDS reads are in flight together
-#endif
-#ifndef SW_AHEAD
-#define SW_AHEAD 4 // segments of the NEXT tile's window asked for during a tile's last block
-#endif
-#ifndef SW_STAGGER
-#define SW_STAGGER 1 // the waves' first flushes at different fill levels (sweep_band_body: Emitter)
-#endif
-#ifndef SW_OCC
-#define SW_OCC 2 // waves per SIMD = blocks per CU
-#endif
+constexpr int SW_OCAP = 1024; // staged output pairs per wave (smaller: the reservations on the one pair counter become the bottleneck -- 512: +40 %)
 
 struct SweepLds { // per wave: 19,584 bytes; four waves per block, two blocks per CU
     double2 a[SW_WIN + SW_MIR]; // {min, max} on minor axis a
@@ -90,21 +75,13 @@ struct Emitter {
     int2* out;       // global
     long long capacity;
     unsigned long long* n_pairs;
-#ifdef SW_NOATOMIC
-    unsigned long long priv = 0;
-#endif
 
     __device__ __forceinline__ void flush()
     {
         if (ocount == 0) return;
         unsigned long long base = 0;
-#ifdef SW_NOATOMIC // MEASUREMENT ONLY (wrong output): what the sweep costs without its reservations
-        base = (unsigned long long)(blockIdx.x * SW_WAVES + (threadIdx.x >> 6)) * 16384ull + priv;
-        priv += (unsigned long long)ocount;
-#else
         if (lane_id() == 0) base = atomicAdd(n_pairs, (unsigned long long)ocount);
         base = __shfl(base, 0, 64);
-#endif
         wave_lds_fence();
         for (int k = lane_id(); k < ocount; k += 64) {
             const unsigned long long dst = base + (unsigned long long)k;
@@ -375,15 +352,11 @@ __device__ __forceinline__ void sweep_band_body(SweepLds* lds_s, unsigned long l
     SweepLds& L = lds_s[w];
     const int xb = gp->xb, Sb = max(gp->Sb, 1);
     // Tiles are dealt statically and cost about the same, so the waves of a launch fill their staging areas in step and would all
-    // reserve space at the same moments: ~2,000 returning atomics on ONE word, served one after the other (~10 ns each), every wave
-    // waiting through the whole round -- measured by the staging size: 1024 / 512 / 256 pairs -> 0.238 / 0.334 / 0.575 ms on 1M boxes,
-    // 10.5 ns per reservation, additive.  The first flush of a wave therefore comes after a share of the staging area that differs
-    // from wave to wave (1/14 ... 14/14): from then on the waves' reservations are spread over the filling period.
-#if SW_STAGGER
+    // reserve space at the same moments: ~2,000 returning atomics on ONE word, served one after the other (~10 ns each).  The first
+    // flush of a wave therefore comes after a share of the staging area that differs from wave to wave (1/15 ... 15/15): from then
+    // on the waves' reservations are spread over the filling period (1M boxes: 0.2375 -> 0.2326 ms; with no reservation at all,
+    // waves writing to private slices, 0.229: the emit's atomic is 2 % of the sweep -- profiles/r05_ab/sweep_experiments.txt).
     const int first_thr = 64 * (1 + (int)(((block * SW_WAVES + (unsigned)w) * 5u) % (unsigned)(SW_OCAP / 64 - 1)));
-#else
-    const int first_thr = SW_OCAP - 64;
-#endif
     Emitter em { L.o, 0, min(first_thr, SW_OCAP - 64), out, capacity, &cnt->n_pairs };
     const Stager st(L, C);
     int qcount = 0;               // queued candidates (wave-uniform)
@@ -520,15 +493,15 @@ __device__ __forceinline__ void sweep_band_body(SweepLds* lds_s, unsigned long l
             // more registers than a lane has.  A block ends with the longest lane's run.)
             bool inside = true; // the lane's last tested column was still inside its key range (keys ascend: once out, out)
 #pragma unroll 1
-            for (int c8 = 0; c8 < SW_SEG; c8 += SW_GROUP) {
+            for (int c8 = 0; c8 < SW_SEG; c8 += 8) {
                 if (__ballot(inside && avail > c8) == 0) break; // the block ends with the longest run
                 ++d_groups;
                 const unsigned at = s0 + (unsigned)c8;
-                uint32_t k[SW_GROUP];
-                double2 ca[SW_GROUP], cb[SW_GROUP];
-                int4 cv[SW_GROUP];
+                uint32_t k[8];
+                double2 ca[8], cb[8];
+                int4 cv[8];
 #pragma unroll
-                for (int i = 0; i < SW_GROUP; i++) {
+                for (int i = 0; i < 8; i++) {
                     k[i] = L.key[at + i];
                     ca[i] = L.a[at + i];
                     cb[i] = L.b[at + i];
@@ -550,15 +523,13 @@ __device__ __forceinline__ void sweep_band_body(SweepLds* lds_s, unsigned long l
                 filter_step<2u, KIND>(m8, km8, k[1], kmax, ca[1], cb[1], me.a, me.b, me.id, cv[1]);
                 filter_step<4u, KIND>(m8, km8, k[2], kmax, ca[2], cb[2], me.a, me.b, me.id, cv[2]);
                 filter_step<8u, KIND>(m8, km8, k[3], kmax, ca[3], cb[3], me.a, me.b, me.id, cv[3]);
-#if SW_GROUP == 8
                 filter_step<16u, KIND>(m8, km8, k[4], kmax, ca[4], cb[4], me.a, me.b, me.id, cv[4]);
                 filter_step<32u, KIND>(m8, km8, k[5], kmax, ca[5], cb[5], me.a, me.b, me.id, cv[5]);
                 filter_step<64u, KIND>(m8, km8, k[6], kmax, ca[6], cb[6], me.a, me.b, me.id, cv[6]);
                 filter_step<128u, KIND>(m8, km8, k[7], kmax, ca[7], cb[7], me.a, me.b, me.id, cv[7]);
-#endif
                 m |= m8 << c8;
                 km |= km8 << c8;
-                inside = (km8 & (1u << (SW_GROUP - 1))) != 0;
+                inside = (km8 & 0x80u) != 0;
             }
             const unsigned amask = avail >= 32 ? 0xFFFFFFFFu : ((1u << avail) - 1u);
             m &= amask;
@@ -600,18 +571,14 @@ __device__ __forceinline__ void sweep_band_body(SweepLds* lds_s, unsigned long l
                         seg1 = st.load(from_n + 1u * SW_SEG);
                         ahead = 2;
                     }
-#if SW_AHEAD >= 3
                     if (from_n + 2u * SW_SEG < need_n) {
                         seg2 = st.load(from_n + 2u * SW_SEG);
                         ahead = 3;
                     }
-#endif
-#if SW_AHEAD >= 4
                     if (from_n + 3u * SW_SEG < need_n) {
                         seg3 = st.load(from_n + 3u * SW_SEG);
                         ahead = 4;
                     }
-#endif
                 }
             }
             if (__ballot(m != 0) == 0) continue;
@@ -668,7 +635,7 @@ __device__ __forceinline__ void sweep_band_body(SweepLds* lds_s, unsigned long l
 }
 
 template <bool ONE, int KIND>
-__global__ __launch_bounds__(SW_THREADS, SW_OCC) void sweep_band_k(SweepRecs R, int row_begin, int row_end, SweepRecs C, int n_cols,
+__global__ __launch_bounds__(SW_THREADS, 2) void sweep_band_k(SweepRecs R, int row_begin, int row_end, SweepRecs C, int n_cols,
                                                               const GridParams* __restrict__ gp, int emit, int chunk,
                                                               int2* __restrict__ out, long long capacity,
                                                               SweepCounters* __restrict__ cnt, int diag,
@@ -693,7 +660,7 @@ __global__ __launch_bounds__(SW_THREADS, SW_OCC) void sweep_band_k(SweepRecs R, 
 // path of every vertex-face pass.  (Splitting the BLOCKS between the classes by their numbers of tiles was measured:
 // a vertex row and a face row do not cost the same, the lighter class's blocks idle: 135 us against 111 for two launches.)
 template <int KIND_A, int KIND_B>
-__global__ __launch_bounds__(SW_THREADS, SW_OCC) void sweep_band2_k(SweepRecs A, int a_begin, int a_end, int n_a, SweepRecs B, int b_begin,
+__global__ __launch_bounds__(SW_THREADS, 2) void sweep_band2_k(SweepRecs A, int a_begin, int a_end, int n_a, SweepRecs B, int b_begin,
                                                                int b_end, int n_b, const GridParams* __restrict__ gp, int chunk_a,
                                                                int chunk_b, int2* __restrict__ out, long long capacity,
                                                                SweepCounters* __restrict__ cnt, int diag,
@@ -772,7 +739,7 @@ void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, c
         const int num_tiles = (row_end - row_begin + 63) / 64;
         // RESIDENT blocks only: tiles are dealt statically over the grid, so a block that has to wait
         // for a slot doubles the tail.  78 KB of LDS per block -> 2 blocks per CU; a multiple of 8 blocks (the XCD-aware deal).
-        const int per_cu = c->sweep_blocks_per_cu > 0 ? c->sweep_blocks_per_cu : SW_OCC;
+        const int per_cu = c->sweep_blocks_per_cu > 0 ? c->sweep_blocks_per_cu : 2;
         int grid = std::min((num_tiles + SW_WAVES - 1) / SW_WAVES, c->num_cus * per_cu);
         grid = std::max(8, (grid + 7) / 8 * 8);
         // consecutive tiles per wave and deal (measured on 1M random boxes and the 1M-triangle cloth: a wave has only ~12
@@ -810,7 +777,7 @@ void launch_sweep_two(sccd_ctx* c, const SortedList* A, const SortedList* B, con
         launch_sweep(c, B, A, gp, b_begin, b_end, EMIT_ROWS_B, out, capacity, d_cnt, d_tot ? d_tot + 1 : nullptr, d_tot, expect_bits);
         return;
     }
-    const int per_cu = c->sweep_blocks_per_cu > 0 ? c->sweep_blocks_per_cu : SW_OCC;
+    const int per_cu = c->sweep_blocks_per_cu > 0 ? c->sweep_blocks_per_cu : 2;
     const int tiles = std::max(tiles_a, tiles_b);
     int grid = std::min((tiles + SW_WAVES - 1) / SW_WAVES, c->num_cus * per_cu);
     grid = std::max(8, (grid + 7) / 8 * 8);
