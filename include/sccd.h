@@ -105,6 +105,12 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        * redone from 1); 0: always from 1, as ccd.cu:125 */
 #define SCCD_OPT_TOI_GUESS_HITS 20    /* read: calls whose bound held / broke (redone); setting either resets both */
 #define SCCD_OPT_TOI_GUESS_MISSES 21
+#define SCCD_OPT_CULL 24              /* sccd_ccd / sccd_ccd_mesh / sccd_ccd_mesh_pass (double build, no check limit): 1 (default) the overlap pairs of a pass
+                                       * go through the PROJECTION CULL before the bisection -- a pair is dropped if some direction d puts the eight
+                                       * corner values of d . F (F: the collision function, affine in each of t, u, v) all beyond the reach of any
+                                       * domain the reference's bisection could accept (csrc/narrow_cull.inc): the result is unchanged, the narrow
+                                       * phase bisects a fraction of the pairs; 0: every pair is bisected, as root_finder.cu:372-457 does.
+                                       * sccd_narrow_phase and the collision-list / per-query drivers never cull. */
 #define SCCD_OPT_ALLOC_COUNT 23       /* read: device allocations the library's grow-only buffers have made since it was loaded (all contexts): a call
                                        * during which the count rises has grown a buffer -- hipFree + hipMalloc, milliseconds */
 #define SCCD_OPT_SPEC_HITS 15   /* read: speculative builds (sort, records and sweep enqueued for the previous build's entry counts) whose */
@@ -208,6 +214,9 @@ typedef struct sccd_stats {
     int64_t n_vf_candidates, n_ee_candidates; /* sort-axis candidate tests                    */
     int64_t n_vf_checks, n_ee_checks;         /* inclusion-function evaluations               */
     double ms_boxes, ms_sort, ms_sweep, ms_narrow, ms_total; /* device time, SCCD_OPT_PROFILE */
+    int64_t n_vf_culled, n_ee_culled;         /* (0.3) of those overlaps: dropped by the projection cull before the bisection
+                                               * (SCCD_OPT_CULL: pairs whose collision function is provably never within reach of the
+                                               * origin -- no domain of theirs can be accepted, so they cannot change the result) */
 } sccd_stats;
 
 /* ccd(V0,V1,E,F,min_distance,max_iterations,tolerance,allow_zero_toi,memory_limit_GB):

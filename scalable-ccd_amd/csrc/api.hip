@@ -75,7 +75,7 @@ void readback_gather_launch(sccd_ctx* c, const ReadBackItems& it, unsigned long 
 
 extern "C" {
 
-const char* sccd_version(void) { return "sccd-hip 0.2 (gfx950)"; } // 0.2: default contract fused (SCCD_OPT_ARITH = 1), option id 12 retired
+const char* sccd_version(void) { return "sccd-hip 0.3 (gfx950)"; } // 0.3: sccd_stats grew (n_*_culled), SCCD_OPT_CULL; 0.2: default contract fused, option id 12 retired
 
 int sccd_create(int device, sccd_ctx** out)
 {
@@ -191,6 +191,7 @@ int sccd_set_option(sccd_ctx* c, int opt, int64_t v)
     case SCCD_OPT_PASSES_APART: c->passes_apart = v ? 1 : 0; break;
     case SCCD_OPT_CELL_FACTOR_MILLI: c->cell_factor_milli = (int)v; break;
     case SCCD_OPT_BUILD_SCAN: c->build_scan = v ? 1 : 0; break;
+    case SCCD_OPT_CULL: c->cull_on = v ? 1 : 0; break;
     case SCCD_OPT_TOI_GUESS:
         c->toi_guess_on = v ? 1 : 0;
         c->toi_guess = 1.0; // (forget what was learnt)
@@ -227,6 +228,7 @@ int64_t sccd_get_option(const sccd_ctx* c, int opt)
     case SCCD_OPT_PASSES_APART: return c->passes_apart;
     case SCCD_OPT_CELL_FACTOR_MILLI: return c->cell_factor_milli;
     case SCCD_OPT_BUILD_SCAN: return c->build_scan;
+    case SCCD_OPT_CULL: return c->cull_on;
     case SCCD_OPT_ALLOC_COUNT: return devbuf_alloc_count();
     case SCCD_OPT_TOI_GUESS: return c->toi_guess_on;
     case SCCD_OPT_TOI_GUESS_HITS: return c->toi_guess_hits;

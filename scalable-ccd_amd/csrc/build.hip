@@ -194,6 +194,7 @@ void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes* B)
     bp->built = true;
     bp->cursor = 0;
     bp->n_overlaps = 0;
+    bp->n_kept = 0;
     bp->candidates = 0;
     bp->candidates_done = 0;
     bp->la.m = bp->lb.m = 0;
@@ -544,6 +545,7 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
     sccd_ctx* c = bp->ctx;
     if (!bp->built) throw SccdError { SCCD_E_NOT_BUILT, "Must initialize build broad phase before detecting overlaps!" };
     bp->n_overlaps = 0;
+    bp->n_kept = 0;
     if (bp->speculative && phase != 2 && (c->max_overlap_cutoff > 0 || c->sweep_algo == 1)) {
         // the options were changed between build and sweep to ones a speculative sweep does not serve (chunks of rows, the
         // plain sweep): read what was built now, and go on with real sizes -- or build again
@@ -620,6 +622,19 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
                 launch_sweep_two(c, A, B, gp, a_lo, a_hi, b_lo, b_hi, bp->overlaps.as<int2>(), bp->capacity, d_cnt, d_tot, bp->guess.key_bits);
             }
         }
+        if (bp->cull.on) { // (behind EVERY sweep of this pass, first attempts and reruns alike)
+            ProfScope ps(c, bp->cull.is_vf ? SCCD_PROF_NARROW_VF : SCCD_PROF_NARROW_EE);
+            bp->kept.ensure(sizeof(int2) * (size_t)bp->capacity);
+            NarrowParams p {};
+            p.V = bp->cull.mesh->V.as<double>();
+            p.E = bp->cull.mesh->E.as<int2>();
+            p.F = bp->cull.mesh->F.as<int4>();
+            p.pairs = bp->overlaps.as<int2>();
+            p.is_vf = bp->cull.is_vf;
+            p.ms = bp->cull.ms;
+            p.tol = bp->cull.tol;
+            narrow_cull_launch(c, p, &d_cnt->n_pairs, (long long)bp->capacity, bp->kept.as<int2>(), &d_cnt->n_kept);
+        }
         if (phase == 1) return;
     launched:
         SweepCounters h;
@@ -658,6 +673,7 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
         }
         if ((int64_t)h.n_pairs <= bp->capacity) {
             bp->n_overlaps = (int64_t)h.n_pairs;
+            bp->n_kept = bp->cull.on ? (int64_t)h.n_kept : bp->n_overlaps;
             break;
         }
         SCCD_REQUIRE(attempt < 64, "broad phase: overlap buffer keeps overflowing");

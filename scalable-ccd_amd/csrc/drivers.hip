@@ -13,6 +13,20 @@ struct NarrowResult {
     unsigned long long n_checks;
 };
 
+// the list a pass's narrow phase runs on: what the projection cull kept (narrow_cull.inc, bp_detect_partial) or every overlap
+static const int2* pass_pairs(const sccd_broad_phase* bp) { return bp->cull.on ? bp->kept.as<int2>() : bp->overlaps.as<int2>(); }
+static int64_t pass_count(const sccd_broad_phase* bp) { return bp->cull.on ? bp->n_kept : bp->n_overlaps; }
+// ... and whether a pass of ccd() culls at all: the double build's walk kernel without a check limit (the certificate of a limit,
+// the level-order kernels and the float build keep the reference's own list: their counts and fallbacks are defined on it)
+static void pass_cull_setup(sccd_ctx* c, sccd_broad_phase* bp, const sccd_mesh* m, bool vf, double ms, int max_iter, double tol)
+{
+    bp->cull.on = c->cull_on && !c->scalar_f32 && max_iter < 0 && c->narrow_algo != 1 && std::isfinite(tol) && tol > 0 && ms >= 0;
+    bp->cull.mesh = m;
+    bp->cull.is_vf = vf ? 1 : 0;
+    bp->cull.ms = ms;
+    bp->cull.tol = tol;
+}
+
 static NarrowParams narrow_params(sccd_ctx* c, const sccd_mesh* m, const int2* d_pairs, int64_t n, int is_vf, int max_iter,
                                   double tol, double ms, int allow_zero_toi)
 {
@@ -175,6 +189,7 @@ static void ccd_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, sccd_broad_p
                      double tol, int allow_zero_toi, double* toi, sccd_stats* st, bool built = false, bool swept = false,
                      std::function<void()>* before_narrow = nullptr)
 {
+    if (!swept) pass_cull_setup(c, bp, m, vf, ms, max_iter, tol); // (a sweep that is enqueued already was set up by its caller)
     if (built) {} // (ccd() had the lists built already, by the helper)
     else if (vf) bp_build(bp, &pl->vb, &pl->fb);
     else bp_build(bp, &pl->eb, nullptr);
@@ -187,10 +202,11 @@ static void ccd_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, sccd_broad_p
             (*before_narrow)();
             *before_narrow = nullptr; // once
         }
-        const NarrowResult r = run_narrow(c, m, bp->overlaps.as<int2>(), bp->n_overlaps, vf ? 1 : 0, max_iter, tol, ms,
+        const NarrowResult r = run_narrow(c, m, pass_pairs(bp), pass_count(bp), vf ? 1 : 0, max_iter, tol, ms,
                                           allow_zero_toi, toi, nullptr);
         if (st) {
             (vf ? st->n_vf_pairs : st->n_ee_pairs) += bp->n_overlaps;
+            (vf ? st->n_vf_culled : st->n_ee_culled) += bp->n_overlaps - pass_count(bp);
             (vf ? st->n_vf_checks : st->n_ee_checks) += (int64_t)r.n_checks;
         }
     }
@@ -239,8 +255,8 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
                 // both pair lists are still on the device, each swept in one chunk: only the narrow phases again (ccd.cu:125-143)
                 Pipeline* const pl = pipeline_of(c);
                 toi = 1.0;
-                const NarrowResult rv = run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, 1, max_iter, tol, ms, allow_zero_toi, &toi, nullptr);
-                const NarrowResult re = run_narrow(c, m, pl->bp_ee.overlaps.as<int2>(), pl->bp_ee.n_overlaps, 0, max_iter, tol, ms, allow_zero_toi, &toi, nullptr);
+                const NarrowResult rv = run_narrow(c, m, pass_pairs(&pl->bp), pass_count(&pl->bp), 1, max_iter, tol, ms, allow_zero_toi, &toi, nullptr);
+                const NarrowResult re = run_narrow(c, m, pass_pairs(&pl->bp_ee), pass_count(&pl->bp_ee), 0, max_iter, tol, ms, allow_zero_toi, &toi, nullptr);
                 if (st) {
                     st->n_vf_checks += (int64_t)rv.n_checks;
                     st->n_ee_checks += (int64_t)re.n_checks;
@@ -343,6 +359,10 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
             // step went from 1.17 to 1.25-1.30 ms the day the read-backs became 10 us faster.
             SCCD_HIP(hipEventRecord(c->side_event2, c->side->stream));
             c->side->sweep_blocks_per_cu = 0; // (the sweep kernel's own choice: a full CU)
+            c->side->cull_on = c->cull_on;
+            c->side->scalar_f32 = c->scalar_f32;
+            c->side->narrow_algo = c->narrow_algo;
+            pass_cull_setup(c->side, &pl->bp_ee, m, false, ms, max_iter, tol);
             try {
                 bp_detect_partial(&pl->bp_ee, 1);
             } catch (...) {
@@ -370,6 +390,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
             sc->limit_level_order = c->limit_level_order;
             c->np_init_pending = true; // (the counters of the vertex-face narrow launch: started by the build's grid kernel)
             c->np_init_toi = toi;
+            pass_cull_setup(c, &pl->bp, m, true, ms, max_iter, tol);
             bp_build(&pl->bp, &pl->vb, &pl->fb);
             c->np_init_pending = false;
             // the vertex-face sweep is enqueued, the edge-edge sweep behind it (on the helper's stream, by an event), and only
@@ -380,14 +401,14 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
             start_ee_sweep = nullptr;
             bp_detect_partial(&pl->bp, 2);
             const bool vf_one_chunk = pl->bp.cursor >= pl->bp.total_rows;
-            const NarrowParams pv = narrow_params(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, 1, max_iter, tol, ms, allow_zero_toi);
+            const NarrowParams pv = narrow_params(c, m, pass_pairs(&pl->bp), pass_count(&pl->bp), 1, max_iter, tol, ms, allow_zero_toi);
             if (vf_one_chunk && narrow_uses_walk_kernel(c, pv, false)) {
                 double toi_vf = toi, toi_ee = toi;
                 if (lab_env().narrow_order) SCCD_HIP(hipStreamWaitEvent(c->stream, c->side_event2, 0)); // (start_ee_sweep)
                 narrow_phase_begin(c, pv, narrow_counters(c), &toi_vf, nullptr); // (asynchronous)
                 bp_detect_partial(&pl->bp_ee, 2);                                 // waits for the edge-edge sweep
                 if (pl->bp_ee.cursor >= pl->bp_ee.total_rows) {
-                    NarrowParams pe = narrow_params(sc, m, pl->bp_ee.overlaps.as<int2>(), pl->bp_ee.n_overlaps, 0, max_iter, tol, ms, allow_zero_toi);
+                    NarrowParams pe = narrow_params(sc, m, pass_pairs(&pl->bp_ee), pass_count(&pl->bp_ee), 0, max_iter, tol, ms, allow_zero_toi);
                     pe.toi_word = &narrow_counters(c)->toi_bits;
                     c->np_peer_stream = sc->stream; // (the helper's counters were started by its build: narrow_phase_begin uploads only if not)
                     try {
@@ -404,9 +425,11 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
                     toi = std::min(toi_vf, toi_ee);
                     if (st) {
                         st->n_vf_pairs += pl->bp.n_overlaps;
+                        st->n_vf_culled += pl->bp.n_overlaps - pass_count(&pl->bp);
                         st->n_vf_checks += (int64_t)rv.n_checks;
                         st->n_vf_candidates = pl->bp.candidates;
                         st->n_ee_pairs += pl->bp_ee.n_overlaps;
+                        st->n_ee_culled += pl->bp_ee.n_overlaps - pass_count(&pl->bp_ee);
                         st->n_ee_checks += (int64_t)re.n_checks;
                         st->n_ee_candidates = pl->bp_ee.candidates;
                     }
@@ -417,23 +440,26 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
                     toi = toi_vf;
                     if (st) {
                         st->n_vf_pairs += pl->bp.n_overlaps;
+                        st->n_vf_culled += pl->bp.n_overlaps - pass_count(&pl->bp);
                         st->n_vf_checks += (int64_t)rv.n_checks;
                         st->n_vf_candidates = pl->bp.candidates;
                     }
                     // the first edge-edge chunk is swept already: its narrow phase, then the rest of the loop
-                    const NarrowResult re = run_narrow(c, m, pl->bp_ee.overlaps.as<int2>(), pl->bp_ee.n_overlaps, 0, max_iter, tol, ms,
+                    const NarrowResult re = run_narrow(c, m, pass_pairs(&pl->bp_ee), pass_count(&pl->bp_ee), 0, max_iter, tol, ms,
                                                        allow_zero_toi, &toi, nullptr);
                     if (st) {
                         st->n_ee_pairs += pl->bp_ee.n_overlaps;
+                        st->n_ee_culled += pl->bp_ee.n_overlaps - pass_count(&pl->bp_ee);
                         st->n_ee_checks += (int64_t)re.n_checks;
                     }
                     presweep_done = false; // (consumed)
                 }
             } else { // not this time: the vertex-face pass as usual (its lists are built and its first chunk swept)
-                const NarrowResult rv = run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, 1, max_iter, tol, ms,
+                const NarrowResult rv = run_narrow(c, m, pass_pairs(&pl->bp), pass_count(&pl->bp), 1, max_iter, tol, ms,
                                                    allow_zero_toi, &toi, nullptr);
                 if (st) {
                     st->n_vf_pairs += pl->bp.n_overlaps;
+                    st->n_vf_culled += pl->bp.n_overlaps - pass_count(&pl->bp);
                     st->n_vf_checks += (int64_t)rv.n_checks;
                 }
                 ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true);
@@ -556,6 +582,7 @@ extern "C" int sccd_ccd(sccd_ctx* c, const double* V0, const double* V1, int nV,
 static void ccd_pass_collisions(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, bool vf, double ms, int max_iter, double tol,
                                 int allow_zero_toi, double* toi, std::vector<sccd_collision>& acc)
 {
+    pl->bp.cull.on = false; // (per-query output: every pair keeps its place in the list)
     if (vf) bp_build(&pl->bp, &pl->vb, &pl->fb);
     else bp_build(&pl->bp, &pl->eb, nullptr);
     DevBuf& pq = c->col_pq;
@@ -601,6 +628,7 @@ extern "C" int sccd_ccd_collisions(sccd_ctx* c, const double* V0, const double* 
 static void ipc_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, bool vf, double ms, int max_iter, double tol,
                      double* earliest)
 {
+    pl->bp.cull.on = false; // (check limits: the reference's own list)
     if (vf) bp_build(&pl->bp, &pl->vb, &pl->fb);
     else bp_build(&pl->bp, &pl->eb, nullptr);
     while (pl->bp.cursor < pl->bp.total_rows) {

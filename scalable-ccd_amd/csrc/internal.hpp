@@ -98,6 +98,17 @@ struct sccd_broad_phase {
         double cell_factor = 0;
         uint32_t total[2] = { 0, 0 };
     } guess;
+    // THE PROJECTION CULL of ccd() (narrow_cull.inc): with cull.on every sweep bp_detect_partial launches is followed, on the same
+    // stream, by a kernel that drops the pairs whose Tight-Inclusion bisection provably accepts nothing and compacts the others
+    // into `kept`; the count comes back with the sweep's counters (n_kept).  `overlaps` / n_overlaps stay the full list.
+    struct Cull {
+        bool on = false;
+        const sccd_mesh* mesh = nullptr;
+        int is_vf = 0;
+        double ms = 0, tol = 0;
+    } cull;
+    DevBuf kept;         // int2[capacity]
+    int64_t n_kept = 0;
     bool one_class = false;                // a two-list build whose sweep runs list B's rows only (api.hip bp_build)
     bool speculative = false;              // la.m / lb.m are BOUNDS until bp_detect_partial has checked the guess
     bool spec_window = false;              // ... of a rank's cell window, dealt out on the device
@@ -180,7 +191,8 @@ struct SweepCounters { // lives in device memory (ctx->scalars)
     unsigned int pad;
     unsigned long long cand_parts[32]; // candidate columns tested (key range on the sort axis), summed over the rows; spread to avoid one hot word
     unsigned long long diag[4];        // SCCD_SWEEP_DIAG=1: filter blocks, filter groups of 8 steps, confirm rounds, segments staged (summed over waves)
-    unsigned long long pad2[25];       // 512 bytes: hipMemsetAsync clears an aligned size with ONE fill kernel (280 B took two)
+    unsigned long long n_kept;         // ccd(): pairs the projection cull behind this sweep kept (narrow_cull.inc); cleared with the rest
+    unsigned long long pad2[24];       // 512 bytes: hipMemsetAsync clears an aligned size with ONE fill kernel (280 B took two)
 };
 static_assert(sizeof(SweepCounters) == 512, "SweepCounters: keep the size a multiple of 256 bytes");
 // rows [row_begin, row_end) of `rows` against the columns of `cols` (rows == cols: one list)
@@ -254,6 +266,10 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
 void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
                       double* d_per_query_toi);
 bool narrow_uses_walk_kernel(const sccd_ctx* c, const NarrowParams& p, bool per_query); // (else: level-synchronous kernels)
+// the projection cull (narrow_cull.inc): pairs[0 .. min(*d_n_pairs, capacity)) -> the pairs that may have an impact, compacted
+// into d_kept[0 .. *d_n_kept) (any order; *d_n_kept must be 0); on c->stream.  Only p's mesh pointers, pairs, is_vf, ms, tol are used.
+void narrow_cull_launch(sccd_ctx* c, const NarrowParams& p, const unsigned long long* d_n_pairs, long long capacity, int2* d_kept,
+                        unsigned long long* d_n_kept);
 // ti_census.cpp (host): ONE query bisected alone in the reference's level order with the check limit
 double ti_census_level_order(const double v[8][3], int is_vf, int arith, double ms, double tol, int max_iter, int allow_zero_toi,
                              double toi_init, long long max_live, bool* gave_up);

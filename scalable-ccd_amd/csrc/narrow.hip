@@ -381,6 +381,7 @@ __global__ void np_reset_selected_k(double* __restrict__ per_query, const int* _
 } // namespace
 
 #include "narrow_walk.inc"
+#include "narrow_cull.inc"
 
 // ------------------------------------------------------------------------------------------
 // The FLOAT build (SCCD_OPT_SCALAR = 1, the reference's SCALABLE_CCD_USE_DOUBLE = OFF) depth first: one lane = one query at a

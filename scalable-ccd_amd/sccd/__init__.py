@@ -42,6 +42,7 @@ OPT_SCALAR = 11  # 1: the reference's float build (SCALABLE_CCD_USE_DOUBLE=OFF)
 OPT_PASSES_APART = 13  # 1: ccd() runs its two passes one after the other (measurements)
 OPT_CELL_FACTOR_MILLI, OPT_BUILD_SCAN = 17, 18  # grid cell size (thousandths of the mean extent); count -> scan -> fill build
 OPT_TOI_GUESS, OPT_TOI_GUESS_HITS, OPT_TOI_GUESS_MISSES = 19, 20, 21  # the speculative TOI bound of ccd() on a mesh (see sccd.h)
+OPT_CULL = 24  # 1 (default): ccd()'s passes drop pairs that provably have no impact before the bisection (csrc/narrow_cull.inc)
 OPT_ALLOC_COUNT = 23  # read-only: device allocations made by the library's grow-only buffers (a step that allocates is a slow step)
 OPT_SPEC_HITS, OPT_SPEC_MISSES = 15, 16  # read-only counters of the speculative build (set: reset)
 OPT_LIMIT_LEVEL_ORDER = 14  # 1: check limits always on the level-synchronous kernels; default: fast kernel + certificate (same result)
@@ -70,6 +71,7 @@ class Stats(C.Structure):
         ("n_vf_checks", C.c_int64), ("n_ee_checks", C.c_int64),
         ("ms_boxes", C.c_double), ("ms_sort", C.c_double), ("ms_sweep", C.c_double),
         ("ms_narrow", C.c_double), ("ms_total", C.c_double),
+        ("n_vf_culled", C.c_int64), ("n_ee_culled", C.c_int64),  # (0.3) overlaps the projection cull dropped before the bisection
     ]
 
     def as_dict(self):
