@@ -219,6 +219,14 @@ typedef struct sccd_stats {
                                                * origin -- no domain of theirs can be accepted, so they cannot change the result) */
 } sccd_stats;
 
+/* The projection cull on its own (csrc/narrow_cull.inc; what sccd_ccd / sccd_ccd_mesh run between a pass's sweep and its bisection under
+ * SCCD_OPT_CULL): of the n overlap pairs (host int32[2n]; vertex-face: (vertex, face), edge-edge: (edge, edge)) those that MAY have an
+ * impact are copied to kept (host int32[2n], any order), *n_kept of them.  Every pair that is left out provably has no domain the
+ * reference's bisection (root_finder.cu:277-370) could accept under the given minimum separation and tolerance.  No reference
+ * counterpart; exported so that the claim can be tested against the oracle's per-query output (tests/test_gpu_parity.py). */
+int sccd_query_cull(sccd_ctx* ctx, const sccd_mesh* mesh, const int32_t* pairs, int64_t n, int is_vf, double min_distance, double tolerance,
+                    int32_t* kept, int64_t* n_kept);
+
 /* ccd(V0,V1,E,F,min_distance,max_iterations,tolerance,allow_zero_toi,memory_limit_GB):
  * src/scalable_ccd/cuda/ccd.cuh:26-38 / ccd.cu:80-146.  Host matrices in, earliest TOI out.
  * (The matrices go into a mesh the context owns and refills call after call; an index out of range is reported when the

@@ -179,6 +179,43 @@ extern "C" int sccd_narrow_phase(sccd_ctx* c, const sccd_mesh* m, const int32_t*
     });
 }
 
+extern "C" int sccd_query_cull(sccd_ctx* c, const sccd_mesh* m, const int32_t* pairs, int64_t n, int is_vf, double ms, double tol,
+                               int32_t* kept, int64_t* n_kept)
+{
+    if (!c || !m || !n_kept) return SCCD_E_INVALID;
+    *n_kept = 0;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(n >= 0 && (n == 0 || (pairs && kept)), "query_cull: bad pair list");
+        SCCD_REQUIRE(tol > 0 && std::isfinite(tol) && ms >= 0 && std::isfinite(ms), "query_cull: tolerance must be positive and finite, minimum separation >= 0");
+        if (n == 0) return;
+        const int na = is_vf ? m->nV : m->nE, nb = is_vf ? m->nF : m->nE;
+        for (int64_t i = 0; i < n; i++)
+            SCCD_REQUIRE(pairs[2 * i] >= 0 && pairs[2 * i] < na && pairs[2 * i + 1] >= 0 && pairs[2 * i + 1] < nb, "query_cull: pair index out of range");
+        DevBuf d_in, d_out, d_cnt;
+        d_in.ensure(sizeof(int2) * (size_t)n);
+        d_out.ensure(sizeof(int2) * (size_t)n);
+        d_cnt.ensure(16);
+        const unsigned long long h_cnt[2] = { (unsigned long long)n, 0ull }; // {pairs in, pairs kept}
+        copy_in(c, d_in.p, pairs, sizeof(int2) * (size_t)n, 0);
+        copy_in(c, d_cnt.p, h_cnt, sizeof h_cnt, 0);
+        NarrowParams p {};
+        p.V = m->V.as<double>();
+        p.E = m->E.as<int2>();
+        p.F = m->F.as<int4>();
+        p.pairs = d_in.as<int2>();
+        p.is_vf = is_vf;
+        p.ms = ms;
+        p.tol = tol;
+        narrow_cull_launch(c, p, d_cnt.as<unsigned long long>(), (long long)n, d_out.as<int2>(), d_cnt.as<unsigned long long>() + 1);
+        unsigned long long k = 0;
+        SCCD_HIP(hipMemcpyAsync(&k, d_cnt.as<unsigned long long>() + 1, sizeof k, hipMemcpyDeviceToHost, c->stream));
+        SCCD_HIP(hipStreamSynchronize(c->stream));
+        SCCD_REQUIRE((int64_t)k <= n, "query_cull: kept more than it was given");
+        if (k) SCCD_HIP(hipMemcpy(kept, d_out.p, sizeof(int2) * (size_t)k, hipMemcpyDeviceToHost));
+        *n_kept = (int64_t)k;
+    });
+}
+
 // ------------------------------------------------------------------------------------------
 // drivers
 

@@ -60,7 +60,7 @@ ABI_SYMBOLS = [
     "sccd_ccd_mesh", "sccd_ccd_mesh_prepare", "sccd_ccd_mesh_pass", "sccd_ipc_ccd_strategy", "sccd_get_profile", "sccd_reset_profile", "sccd_sort_pairs_u32",
     "sccd_shard_bounds", "sccd_boxes_variance_axis", "sccd_selftest_lds_gather",
     "sccd_dev_alloc", "sccd_dev_free", "sccd_dev_upload", "sccd_dev_download", "sccd_dev_copy", "sccd_ccd_collisions",
-    "sccd_ccd_mesh_dev", "sccd_get_stream",
+    "sccd_ccd_mesh_dev", "sccd_get_stream", "sccd_query_cull",
 ]
 
 
@@ -457,6 +457,18 @@ def narrow_phase(mesh, overlaps, is_vf, max_iter=-1, tol=1e-6, ms=0.0, allow_zer
         col = np.zeros(0, COLLISION_DTYPE)
     lib().sccd_free(cp)
     return t.value, col
+
+
+def query_cull(mesh, overlaps, is_vf, ms=0.0, tol=1e-6):
+    """The projection cull on its own (sccd_query_cull): the pairs of `overlaps` (int32[n,2]) that MAY have an impact, in any order;
+    the others provably have no domain the reference's bisection could accept (csrc/narrow_cull.inc)."""
+    ctx = mesh.ctx
+    ov = np.ascontiguousarray(overlaps, dtype=np.int32).reshape(-1, 2)
+    kept = np.zeros_like(ov)
+    k = C.c_int64()
+    ctx._check(lib().sccd_query_cull(ctx._h, mesh._h, _ptr(ov), C.c_int64(len(ov)), C.c_int(int(is_vf)), C.c_double(ms), C.c_double(tol),
+                                     _ptr(kept), C.byref(k)))
+    return kept[: k.value].copy()
 
 
 def ccd(V0, V1, E, F, min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow_zero_toi=True, memory_limit_GB=0, ctx=None,

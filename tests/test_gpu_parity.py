@@ -1393,6 +1393,82 @@ def test_speculative_toi_bound_is_exact_in_the_float_build(sccd, orc, path):
         c.close()
 
 
+# ---- the projection cull (csrc/narrow_cull.inc) -----------------------------------------------------------------------------
+def _cull_scenes():
+    """(name, V0, V1, E, F, ms): ordinary scenes and the regimes the cull's bound has to get right -- slow and static pairs (the
+    reference's edge-edge tolerances come from the wrong pairing there: Condition 1 accepts domains with large images), large and
+    shifted coordinates (the numerical-error bound grows with the cube of the magnitude), minimum separations, resting contact."""
+    out = []
+    V0, V1, E, F = scenes.cloth_ball(24, 1, seed=3)
+    out.append(("cloth_ball", V0, V1, E, F, 0.0))
+    out.append(("cloth_ball_ms", V0, V1, E, F, 2e-3))
+    out.append(("slow", V0, V0 + 1e-7 * (V1 - V0), E, F, 0.0))
+    out.append(("very_slow_ms", V0, V0 + 1e-9 * (V1 - V0), E, F, 1e-3))
+    out.append(("static", V0, V0.copy(), E, F, 0.0))
+    out.append(("scaled_1e3", 1e3 * V0 + 500.0, 1e3 * V1 + 500.0, E, F, 0.0))
+    out.append(("shifted_1e5", V0 + 1e5, V1 + 1e5, E, F, 0.0))
+    Vs0, Vs1, Es, Fs = scenes.triangle_soup(700, seed=11, size=0.1, motion=0.3)
+    out.append(("soup", Vs0, Vs1, Es, Fs, 1e-4))
+    Vf0, Vf1, Ef, Ff = scenes.folded_cloth(60)
+    out.append(("folded", Vf0, Vf1, Ef, Ff, 0.0))
+    # a mesh pressed flat onto itself: every nearby pair is in (resting) contact
+    Vc0, Vc1, Ec, Fc = scenes.folded_cloth(30)
+    Vc1 = Vc0.copy()
+    Vc1[:, 2] *= 0.0
+    out.append(("flattened", Vc0, Vc1, Ec, Fc, 0.0))
+    return out
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_projection_cull_changes_no_result(sccd, orc, case):
+    """ccd() with the cull (the default) and without it, against the oracle: the same TOI bit for bit, on every scene, both zero-TOI
+    policies -- and on the ordinary scenes the cull really removes pairs."""
+    name, V0, V1, E, F, ms = _cull_scenes()[case]
+    c = sccd.Context(0)
+    try:
+        c.set_option(sccd.OPT_TOI_GUESS, 0)
+        mesh = sccd.Mesh(V0, V1, E, F, ctx=c)
+        for allow_zero in (True, False):
+            want = orc.ccd(V0, V1, E, F, ms, -1, 1e-6, allow_zero, nthreads=8)[0]
+            c.set_option(sccd.OPT_CULL, 1)
+            got, st = sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero, want_stats=True)
+            c.set_option(sccd.OPT_CULL, 0)
+            plain, st0 = sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero, want_stats=True)
+            assert got == want and plain == want, (name, allow_zero, got, plain, want)
+            assert st0["n_vf_culled"] == 0 and st0["n_ee_culled"] == 0
+            assert (st["n_vf_pairs"], st["n_ee_pairs"]) == (st0["n_vf_pairs"], st0["n_ee_pairs"])  # every overlap still counts as a query
+            if name in ("cloth_ball", "soup", "folded"):
+                assert st["n_vf_culled"] + st["n_ee_culled"] > 0.3 * (st["n_vf_pairs"] + st["n_ee_pairs"]), (name, st)
+        mesh.close()
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_culled_queries_have_no_impact_in_the_oracle(sccd, ctx, orc, case):
+    """The claim itself: a pair the cull drops has NO accepted domain in the reference's bisection -- the oracle's per-query output
+    (every query bisected on its own, pruned by nothing but its own earliest impact, root_finder.cu:297) reports no impact for it,
+    under either zero-TOI policy.  And the kept pairs are a subset of the list, each once."""
+    name, V0, V1, E, F, ms = _cull_scenes()[case]
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F, ms)
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    for is_vf, pairs in ((True, orc.sort_and_sweep(vb, fb, nthreads=8)[0]), (False, orc.sort_and_sweep(eb, nthreads=8)[0])):
+        pairs = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+        if len(pairs) == 0:
+            continue
+        kept = sccd.query_cull(mesh, pairs, is_vf, ms, 1e-6)
+        key = lambda p: p[:, 0].astype(np.int64) << 32 | p[:, 1].astype(np.int64)  # noqa: E731
+        kk, ka = np.sort(key(kept)), np.sort(key(pairs))
+        assert len(np.unique(kk)) == len(kk) and np.isin(kk, ka).all(), name
+        culled = pairs[~np.isin(key(pairs), kk)]
+        if len(culled) == 0:
+            continue
+        for allow_zero, arith in ((True, 1), (False, 1), (True, 0)):
+            _, per_query, _ = orc.narrow_phase(V0, V1, E, F, culled, is_vf, ms=ms, allow_zero_toi=allow_zero, per_query=True, arith=arith)
+            assert np.all(np.isinf(per_query)), (name, is_vf, allow_zero, arith, int(np.isfinite(per_query).sum()), len(culled))
+    mesh.close()
+
+
 def test_float_build_is_bounded_on_a_query_that_explodes(sccd, ctx):
     """Soak seed 500388 (a small cloth on a ball, scaled by 104, minimum separation 0.31): in float Condition 1 is out of reach, so
     the queries in resting contact are bisected down to single ulps -- 182 s for the oracle's float twin on 8 cores, minutes for ONE
