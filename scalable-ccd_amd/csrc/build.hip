@@ -622,6 +622,11 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
                 launch_sweep_two(c, A, B, gp, a_lo, a_hi, b_lo, b_hi, bp->overlaps.as<int2>(), bp->capacity, d_cnt, d_tot, bp->guess.key_bits);
             }
         }
+        if (bp->after_sweep) {
+            const std::function<void()> h = std::move(bp->after_sweep);
+            bp->after_sweep = nullptr;
+            h();
+        }
         if (bp->cull.on) { // (behind EVERY sweep of this pass, first attempts and reruns alike)
             ProfScope ps(c, bp->cull.is_vf ? SCCD_PROF_NARROW_VF : SCCD_PROF_NARROW_EE);
             bp->kept.ensure(sizeof(int2) * (size_t)bp->capacity);

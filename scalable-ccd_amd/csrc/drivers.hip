@@ -433,8 +433,19 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
             // the vertex-face sweep is enqueued, the edge-edge sweep behind it (on the helper's stream, by an event), and only
             // then does the host wait for the vertex-face pairs: the narrow kernel it launches next finds the edge-edge
             // sweep's blocks resident already and takes the rest of the chip
-            bp_detect_partial(&pl->bp, 1);
-            start_ee_sweep();
+            // (the edge-edge sweep is released by the END OF THE VERTEX-FACE SWEEP, not of its cull: the event goes into the
+            // stream between the two -- 20 us of the step's critical path)
+            pl->bp.after_sweep = [&] { start_ee_sweep(); };
+            try {
+                bp_detect_partial(&pl->bp, 1);
+            } catch (...) {
+                pl->bp.after_sweep = nullptr;
+                throw;
+            }
+            if (pl->bp.after_sweep) { // (no sweep was launched -- nothing to sweep in the vertex-face lists)
+                pl->bp.after_sweep = nullptr;
+                start_ee_sweep();
+            }
             start_ee_sweep = nullptr;
             bp_detect_partial(&pl->bp, 2);
             const bool vf_one_chunk = pl->bp.cursor >= pl->bp.total_rows;

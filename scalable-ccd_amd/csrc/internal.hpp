@@ -1,6 +1,7 @@
 // internal.hpp -- object layouts in HBM and the launcher functions each .hip file exports.
 #pragma once
 #include "common.hpp"
+#include <functional>
 #include "grid.hpp"
 
 // ------------------------------------------------------------------------------------------
@@ -107,6 +108,9 @@ struct sccd_broad_phase {
         int is_vf = 0;
         double ms = 0, tol = 0;
     } cull;
+    // called ONCE, between the launch of the next sweep and the launch of its cull (bp_detect_partial): ccd() puts the event that
+    // releases the OTHER pass's sweep there -- that sweep waits for this one, not for this one's cull
+    std::function<void()> after_sweep;
     DevBuf kept;         // int2[capacity]
     int64_t n_kept = 0;
     bool one_class = false;                // a two-list build whose sweep runs list B's rows only (api.hip bp_build)
