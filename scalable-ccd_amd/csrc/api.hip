@@ -132,6 +132,7 @@ void sccd_destroy(sccd_ctx* c)
     if (c->rb_event) (void)hipEventDestroy(c->rb_event);
     if (c->side_event) (void)hipEventDestroy(c->side_event);
     if (c->side_event2) (void)hipEventDestroy(c->side_event2);
+    if (c->side_event3) (void)hipEventDestroy(c->side_event3);
     if (c->side) sccd_destroy(c->side);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

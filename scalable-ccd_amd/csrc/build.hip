@@ -546,6 +546,7 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
     if (!bp->built) throw SccdError { SCCD_E_NOT_BUILT, "Must initialize build broad phase before detecting overlaps!" };
     bp->n_overlaps = 0;
     bp->n_kept = 0;
+    if (phase != 2) bp->sweeps_in_call = 0;
     if (bp->speculative && phase != 2 && (c->max_overlap_cutoff > 0 || c->sweep_algo == 1)) {
         // the options were changed between build and sweep to ones a speculative sweep does not serve (chunks of rows, the
         // plain sweep): read what was built now, and go on with real sizes -- or build again
@@ -622,6 +623,7 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
                 launch_sweep_two(c, A, B, gp, a_lo, a_hi, b_lo, b_hi, bp->overlaps.as<int2>(), bp->capacity, d_cnt, d_tot, bp->guess.key_bits);
             }
         }
+        bp->sweeps_in_call += 1;
         if (bp->after_sweep) {
             const std::function<void()> h = std::move(bp->after_sweep);
             bp->after_sweep = nullptr;
@@ -646,7 +648,10 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
         GridReadBack built; // (speculative build: the grid and the entry counts it really had)
         ShardWindow hwin {}; // (... of a rank of a multi-GPU job: the cell window it was dealt on the device)
         {
-            ReadBack rb(c);
+            sccd_ctx* const rc = (bp->rb_ctx && attempt == 0) ? bp->rb_ctx : c; // (see sccd_broad_phase::rb_ctx)
+            if (rc != c) SCCD_HIP(hipStreamWaitEvent(rc->stream, bp->rb_after, 0));
+            bp->rb_ctx = nullptr;
+            ReadBack rb(rc);
             rb.add(&h, d_cnt, sizeof h);
             if (bp->speculative) rb.add(&built, bp->grid.as<char>() + 512, sizeof built);
             if (bp->speculative && bp->spec_window) rb.add(&hwin, bp->grid.as<char>() + 1024, sizeof hwin);
@@ -659,6 +664,7 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
                 bp_build(bp, bp->A, bp->B);
                 bp->candidates_done = done;
                 bp_detect_partial(bp, 0);
+                bp->sweeps_in_call += 1; // (the sweep of the failed guess counts: the first attempt did NOT stand)
                 return;
             }
             chunk_hi = bp->total_rows; // (a speculative build is swept in one chunk: bp_build)

@@ -107,6 +107,8 @@ struct LabEnv {
     bool readback_copy = false;        // SCCD_READBACK=copy: read-backs as copies + a polled event instead of one gather kernel + a polled word
     bool sort_tickets = false;         // SCCD_SORT_TICKETS=1: sort tiles by atomic ticket even when every tile has its block
     long long level_budget_mb = 0;     // SCCD_LEVEL_BUDGET_MB: budget per level buffer of the level-synchronous narrow phase
+    bool ee_early = true;              // SCCD_EE_EARLY=0: ccd()'s edge-edge walk kernel launched by the host once it has the pair count (round 4)
+                                       // instead of right behind its sweep and cull with the count read on the device
     int spec_break_every = 0;          // SCCD_SPEC_BREAK=N: every N-th speculative build is declared a failed guess (measures what a miss costs)
     static int num(const char* name, int dflt)
     {
@@ -125,6 +127,7 @@ struct LabEnv {
         narrow_order = num("SCCD_NARROW_ORDER", 1) != 0;
         level_budget_mb = num("SCCD_LEVEL_BUDGET_MB", 0);
         spec_break_every = num("SCCD_SPEC_BREAK", 0);
+        ee_early = num("SCCD_EE_EARLY", 1) != 0;
         const char* s = std::getenv("SCCD_SYNC");
         sync_block = s && std::string(s) == "block";
         const char* r = std::getenv("SCCD_READBACK");
@@ -179,6 +182,7 @@ struct sccd_ctx {
     bool np_init_pending = false, sweep_cnt_cleared = false;
     double np_init_toi = 0;
     hipEvent_t side_event2 = nullptr; // ccd(): "the helper's stream has reached its sweep" (drivers.hip)
+    hipEvent_t side_event3 = nullptr; // ccd(): "the helper's sweep and cull are done" (their counters are read through this context's stream)
     double np_uploaded_toi = 0;
     // a narrow-phase launch of ANOTHER context that shares this one's TOI word is running on that stream: before this
     // context resets its counters (fallback paths) it waits for it

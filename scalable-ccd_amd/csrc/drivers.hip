@@ -347,6 +347,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
             if (sccd_create(c->device, &c->side) != SCCD_OK) throw SccdError { SCCD_E_NOMEM, "ccd: cannot create the helper context" };
             SCCD_HIP(hipEventCreateWithFlags(&c->side_event, hipEventDisableTiming));
             SCCD_HIP(hipEventCreateWithFlags(&c->side_event2, hipEventDisableTiming));
+            SCCD_HIP(hipEventCreateWithFlags(&c->side_event3, hipEventDisableTiming));
             pl->bp_ee.ctx = c->side;
             // (the helper's stream with the lowest / highest queue priority was measured in round 3: no effect)
         }
@@ -407,6 +408,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
                 throw;
             }
             c->side->sweep_blocks_per_cu = 0;
+            SCCD_HIP(hipEventRecord(c->side_event3, c->side->stream)); // (sweep and cull are complete behind this point)
             presweep_done = true;
         };
     // ... and the edge-edge NARROW kernel starts on the helper's stream the moment that sweep is done, beside the tail of
@@ -454,13 +456,48 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
                 double toi_vf = toi, toi_ee = toi;
                 if (lab_env().narrow_order) SCCD_HIP(hipStreamWaitEvent(c->stream, c->side_event2, 0)); // (start_ee_sweep)
                 narrow_phase_begin(c, pv, narrow_counters(c), &toi_vf, nullptr); // (asynchronous)
-                bp_detect_partial(&pl->bp_ee, 2);                                 // waits for the edge-edge sweep
+                // THE EDGE-EDGE WALK KERNEL GOES INTO ITS STREAM NOW, right behind the pass's sweep and cull, before the host
+                // knows how long their list is: the kernel reads the length on the device and derives its deal there (np_walk_k,
+                // walk_deal).  Waiting for the count first left the chip idle for 20-30 us between the cull's end and the
+                // kernel's start -- on the step's critical path, at its end.  The host reads the sweep's counters behind the
+                // kernel (same stream): if the first attempt did not stand after all (the pair buffer overflowed, the
+                // speculative build's guess broke), the kernel has run on a prefix of the true list or on nothing -- whatever it
+                // put into the running TOI is an accepted domain of a true pair -- and the pass is done again as before.
+                NarrowParams pe = narrow_params(sc, m, pass_pairs(&pl->bp_ee), 0, 0, max_iter, tol, ms, allow_zero_toi);
+                pe.toi_word = &narrow_counters(c)->toi_bits;
+                bool early = false;
+                if (lab_env().ee_early && presweep_done && pl->bp_ee.sweeps_in_call == 1 && toi_ee > 0 && !sc->scalar_f32 && narrow_uses_walk_kernel(sc, pe, false)) {
+                    const SweepCounters* const sw = sc->scalars.as<SweepCounters>();
+                    c->np_peer_stream = sc->stream;
+                    try {
+                        narrow_phase_begin(sc, pe, narrow_counters(sc), &toi_ee, nullptr, pl->bp_ee.cull.on ? &sw->n_kept : &sw->n_pairs,
+                                           (long long)pl->bp_ee.capacity);
+                    } catch (...) {
+                        c->np_peer_stream = nullptr;
+                        throw;
+                    }
+                    early = true;
+                    // (the sweep's counters come back through THIS context's stream, behind the vertex-face kernel, while the
+                    // edge-edge kernel runs: queued in the helper's stream they would come when that kernel has ended -- three
+                    // read-backs in a row at the end of the step instead of one)
+                    pl->bp_ee.rb_ctx = c;
+                    pl->bp_ee.rb_after = c->side_event3;
+                }
+                try {
+                    bp_detect_partial(&pl->bp_ee, 2); // waits for the edge-edge sweep and its cull
+                } catch (...) {
+                    pl->bp_ee.rb_ctx = nullptr;
+                    c->np_peer_stream = nullptr;
+                    throw;
+                }
+                pl->bp_ee.rb_ctx = nullptr;
+                const bool early_stands = early && pl->bp_ee.sweeps_in_call == 1;
                 if (pl->bp_ee.cursor >= pl->bp_ee.total_rows) {
-                    NarrowParams pe = narrow_params(sc, m, pass_pairs(&pl->bp_ee), pass_count(&pl->bp_ee), 0, max_iter, tol, ms, allow_zero_toi);
-                    pe.toi_word = &narrow_counters(c)->toi_bits;
+                    pe.pairs = pass_pairs(&pl->bp_ee);
+                    pe.n_pairs = pass_count(&pl->bp_ee);
                     c->np_peer_stream = sc->stream; // (the helper's counters were started by its build: narrow_phase_begin uploads only if not)
                     try {
-                        narrow_phase_begin(sc, pe, narrow_counters(sc), &toi_ee, nullptr);
+                        if (!early_stands) narrow_phase_begin(sc, pe, narrow_counters(sc), &toi_ee, nullptr);
                         narrow_phase_end(c, pv, narrow_counters(c), &toi_vf, nullptr);
                     } catch (...) {
                         c->np_peer_stream = nullptr;
@@ -483,6 +520,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
                     }
                     both_done = true;
                 } else { // (the edge-edge overlaps come in chunks: finish the vertex-face pass, then chunk by chunk as usual)
+                    c->np_peer_stream = nullptr;
                     narrow_phase_end(c, pv, narrow_counters(c), &toi_vf, nullptr);
                     const NarrowResult rv = narrow_result(c);
                     toi = toi_vf;

@@ -111,6 +111,12 @@ struct sccd_broad_phase {
     // called ONCE, between the launch of the next sweep and the launch of its cull (bp_detect_partial): ccd() puts the event that
     // releases the OTHER pass's sweep there -- that sweep waits for this one, not for this one's cull
     std::function<void()> after_sweep;
+    int sweeps_in_call = 0; // sweeps launched since the last bp_detect_partial(bp, 0 / 1) started (1: the first attempt stands)
+    // bp_detect_partial(bp, 2) reads the first attempt's counters back through ANOTHER context's stream and mailbox, behind this
+    // event (recorded on this object's stream behind the sweep and its cull): ccd() has put the pass's walk kernel into this
+    // object's stream already, and a read-back queued behind that kernel would come at the very end of the step.  Used once.
+    sccd_ctx* rb_ctx = nullptr;
+    hipEvent_t rb_after = nullptr;
     DevBuf kept;         // int2[capacity]
     int64_t n_kept = 0;
     bool one_class = false;                // a two-list build whose sweep runs list B's rows only (api.hip bp_build)
@@ -264,7 +270,7 @@ static_assert(sizeof(NarrowCounters) <= 2048, "NarrowCounters must fit its slot 
 constexpr int SCCD_QUEUE_MIN_MAX_ITER = 4096; // smaller check limits are served by the level-synchronous kernel
 // runs the narrow phase on the stream; *toi in/out lives in d_cnt->toi_bits
 void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, const double* h_toi_inout,
-                        double* d_per_query_toi);
+                        double* d_per_query_toi, const unsigned long long* d_n = nullptr, long long capacity = 0);
 void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
                       double* d_per_query_toi);
 void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,

@@ -670,8 +670,11 @@ bool narrow_uses_walk_kernel(const sccd_ctx* c, const NarrowParams& p, bool per_
              || (p.max_iter >= 0 && (c->limit_level_order || (!per_query && p.max_iter < SCCD_QUEUE_MIN_MAX_ITER))));
 }
 
+// d_n / capacity: the list's length is still being made on the device when this is called (ccd(): the launch goes into the stream
+// right behind the pass's sweep and cull) -- p.n_pairs is ignored, the walk kernel takes min(*d_n, capacity); plain launches of
+// the double build only (no check limit, no per-query output), the caller's business
 void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, const double* h_toi_inout,
-                        double* d_per_query_toi)
+                        double* d_per_query_toi, const unsigned long long* d_n, long long capacity)
 {
     // toi is in/out and must be >= 0 (narrow_phase.cu:126)
     SCCD_REQUIRE(*h_toi_inout >= 0, "narrow_phase: toi must be >= 0");
@@ -684,6 +687,15 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
     // per-query build the guard is absent (:138)
     const bool run = (*h_toi_inout > 0) || d_per_query_toi != nullptr;
     const long long n = p.n_pairs;
+    if (d_n) {
+        SCCD_REQUIRE(!d_per_query_toi && p.max_iter < 0 && !c->scalar_f32 && narrow_uses_walk_kernel(c, p, false),
+                     "narrow_phase: a list whose length is on the device is served by the plain walk kernel only");
+        if (run) {
+            ProfScope ps(c, p.is_vf ? SCCD_PROF_NARROW_VF : SCCD_PROF_NARROW_EE);
+            run_walk(c, p, d_cnt, 0, nullptr, nullptr, 0, d_n, capacity);
+        }
+        return;
+    }
     if (run && n > 0) {
         ProfScope ps(c, p.is_vf ? SCCD_PROF_NARROW_VF : SCCD_PROF_NARROW_EE);
         // A check limit (max_iter >= 0: the IPC Toolkit passes 10^7) is defined in the reference's LEVEL ORDER: it counts the
