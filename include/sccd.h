@@ -87,8 +87,9 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
 #define SCCD_OPT_MEMORY_LIMIT_MB 10 /* memory budget of the overlap list in MiB (0 = none; MemoryHandler::memory_limit_GB)  */
 #define SCCD_OPT_SCALAR 11          /* 0 double (default, SCALABLE_CCD_USE_DOUBLE=ON); 1 float (=OFF, scalar.hpp:13-21): vertices are
                                        cast to float first, boxes / tolerances / inclusion function / TOI are float arithmetic
-                                       (values travel widened in the same double-typed interfaces); narrow phase on the
-                                       level-synchronous kernels (bit-equal to the oracle's float twin on the GPU, tests/test_gpu_parity.py) */
+                                       (values travel widened in the same double-typed interfaces); narrow phase on a depth-first
+                                       kernel of its own (np_walk_f32_k; check limits on the level-synchronous kernels), bit-equal to the
+                                       oracle's float twin on the GPU (tests/test_gpu_parity.py) */
 #define SCCD_OPT_PASSES_APART 13      /* ccd(): 1 = the vertex-face and the edge-edge pass one after the other on one stream (what
                                        * SCCD_OVERLAP=0 does for the whole process): measurements of the passes' own durations */
 /* id 12 is RETIRED (it was SCCD_OPT_MAX_ITER_FAST in 0.1 with the opposite sense: setting it now fails with SCCD_E_INVALID) */

@@ -1,10 +1,11 @@
 """Multi-GPU CCD: one process per GPU, grid cells shard naturally, one min-reduce of the TOI.
 
 The reference has no working multi-GPU path (its _multigpu prototype is not compiled,
-src/scalable_ccd/cuda/broad_phase/CMakeLists.txt:21).  Here every rank builds the (cheap) boxes
-and the cell grid redundantly, then takes a contiguous window of grid cells holding an equal
-share of the sort entries (csrc/api.hip bp_build / shard_bounds): it sorts, sweeps and narrows
-only that window.  A pair is reported from exactly one cell, hence by exactly one rank, and the
+src/scalable_ccd/cuda/broad_phase/CMakeLists.txt:21).  Here every rank builds the vertex boxes and
+derives the same cell grid (from statistics every rank samples alike), is dealt a contiguous window
+of grid cells holding an equal share of the sort entries ON THE DEVICE (csrc/build.hip bp_build,
+boxes.hip shard_window_k), builds the edge and face boxes of that window only, and sorts, sweeps,
+culls and narrows only that window.  A pair is reported from exactly one cell, hence by exactly one rank, and the
 ranks exchange exactly one scalar per pass: an all-reduce(min) of the time of impact over
 RCCL/xGMI (or gloo on CPU in the tests).
 """
