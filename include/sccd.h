@@ -59,6 +59,9 @@ typedef struct sccd_collision {
 /* ------------------------------------------------------------------------------------------ */
 /* context                                                                                    */
 
+/* (Contexts are independent and may be used from different host threads.  One performance note: while more than two contexts are
+ *  alive in the process -- a context and the helper context its ccd() makes are two -- the radix sort's passes take their tiles by
+ *  atomic ticket instead of by block index, ~2 us per pass slower: the block-index form is only argued for two concurrent sorts.) */
 int sccd_create(int device, sccd_ctx** out);
 void sccd_destroy(sccd_ctx* ctx);
 const char* sccd_last_error(const sccd_ctx* ctx);

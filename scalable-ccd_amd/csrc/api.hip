@@ -114,6 +114,7 @@ int sccd_create(int device, sccd_ctx** out)
         delete c;
         return rc;
     }
+    __atomic_add_fetch(&live_context_count(), 1, __ATOMIC_RELAXED);
     *out = c;
     return SCCD_OK;
 }
@@ -135,6 +136,7 @@ void sccd_destroy(sccd_ctx* c)
     if (c->side_event3) (void)hipEventDestroy(c->side_event3);
     if (c->side) sccd_destroy(c->side);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    __atomic_sub_fetch(&live_context_count(), 1, __ATOMIC_RELAXED);
     delete c;
 }
 

@@ -47,6 +47,14 @@ inline long long& devbuf_alloc_count()
     static long long n = 0; // (diagnostic: plain increments, contexts on several threads may lose a count)
     return n;
 }
+// live contexts of this process (sccd_create / sccd_destroy; a context's helper counts).  The sort's block-index tiles
+// (sort.hip os_pass_k) are argued for TWO concurrent sorts -- a ccd() step's two streams; with more contexts than one call's pair
+// alive, the passes go back to atomic tickets, which need no argument about dispatch order.
+inline int& live_context_count()
+{
+    static int n = 0; // (guarded by the callers' own serialisation of create / destroy per thread; a stale read only picks the safe path later)
+    return n;
+}
 // grow-only device buffer (no hipMalloc in the steady state of repeated ccd() calls)
 struct DevBuf {
     void* p = nullptr;

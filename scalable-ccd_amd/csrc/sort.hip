@@ -443,7 +443,9 @@ bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
     hipLaunchKernelGGL(os_bases_k, dim3(4), dim3(1024), 0, c->stream, partial, hist_blocks, bases);
     for (int pass = 0; pass < passes; pass++) {
         constexpr int pass_blocks = 3; // resident blocks per CU (41 KB of LDS each)
-        const bool force_tickets = lab_env().sort_tickets;
+        // (tiles by block index only while at most one ccd() call's two contexts are alive: the argument for it is about two
+        // concurrent sorts -- common.hpp live_context_count)
+        const bool force_tickets = lab_env().sort_tickets || __atomic_load_n(&live_context_count(), __ATOMIC_RELAXED) > 2;
         const int blocks = std::min(num_tiles, c->num_cus * pass_blocks);
         // (a block per tile: tiles by block index, no ticket word -- os_pass_k)
         uint32_t* const tk = (blocks == num_tiles && !force_tickets) ? nullptr : tickets + pass * 32;
