@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W [--workload cloth1m|clothball10k|boxes1m|sort16m]
 
 A step = one full pass of the hot path over one batch of synthetic input already resident in
-HBM: box build -> radix sort -> candidate ranges -> STQ sweep -> Tight-Inclusion narrow phase,
+HBM: box build -> radix sort -> STQ sweep -> projection cull -> Tight-Inclusion bisection,
 for the VF list pair then the EE list (scalable_ccd::cuda::ccd(), ccd.cu:80-146).  With N > 1
 (one process per GPU, launched by torch.distributed.run) every rank builds, sorts, sweeps and
 narrows its window of grid cells; the only exchange is one all-reduce(min) of the time of impact
@@ -55,14 +55,14 @@ def _pmc_file(name):
 
 
 def pmc_kernels(workload):
-    """per-kernel HBM bytes of profiles/r04_pmc_traffic_<workload>.json if that profile is of THIS build's kernels, else None"""
-    tj = _pmc_file("r04_pmc_traffic_%s.json" % workload)
+    """per-kernel HBM bytes of profiles/r05_pmc_traffic_<workload>.json if that profile is of THIS build's kernels, else None"""
+    tj = _pmc_file("r05_pmc_traffic_%s.json" % workload)
     return tj["kernels"] if tj else None
 
 
 def pmc_sq(workload):
-    """SQ counters per kernel of profiles/r04_pmc_sq_<workload>.json (tools/pmc_sq.sh) if taken on THIS build's kernels, else None"""
-    tj = _pmc_file("r04_pmc_sq_%s.json" % workload)
+    """SQ counters per kernel of profiles/r05_pmc_sq_<workload>.json (tools/pmc_sq.sh) if taken on THIS build's kernels, else None"""
+    tj = _pmc_file("r05_pmc_sq_%s.json" % workload)
     return tj["kernels"] if tj else None
 
 
@@ -273,16 +273,33 @@ def main():
         n_clock = clock_warmup(step, args.clock_warmup, agree if use_dist else None)
         for _ in range(args.warmup):
             step()
+        # ---- the passes apart (untimed steps, SCCD_OPT_PASSES_APART): each class's own duration with nothing beside it -- the
+        # figures that need one kernel at a time on the chip (broad_phase, rank_max, roofline.alone), and the choice of the DOMINANT
+        # kernel: the class with the longest launch when it has the chip to itself.  (In the default step the launches overlap on two
+        # streams and a launch's own span says little: the vertex-face walk kernel is enqueued while the edge-edge sweep holds every CU
+        # and "runs" for 250 us of which it works for 100.)
+        ctx.set_option(sccd.OPT_PASSES_APART, 1)
+        for _ in range(2):
+            step()
+        ctx.set_option(sccd.OPT_PROFILE, 1)
+        ctx.reset_profile()
+        st_apart = {}
+        for _ in range(n_prof):
+            _, st_apart = step()
+        prof_apart_raw = ctx.profile()
+        prof_apart = {k: v[0] / n_prof for k, v in prof_apart_raw.items()}
+        ctx.set_option(sccd.OPT_PROFILE, 0)
+        ctx.set_option(sccd.OPT_PASSES_APART, 0)
+        for _ in range(N_SETTLE):
+            step()
         ctx.set_option(sccd.OPT_PROFILE, 1)
         ctx.reset_profile()
         for _ in range(n_prof):
             step()
         prof_all = ctx.profile()
-        # the dominant KERNEL: the class with the longest launch.  (By class totals the three sweeps of a step -- one of them
-        # running throttled beside the vertex-face narrow kernel, for the sake of the overlap -- can add up to more than the one
-        # edge-edge narrow launch they overlap with, and the choice would flip from run to run.)
-        dom = max(prof_all, key=lambda k: prof_all[k][0] / max(1, prof_all[k][1]))
-        class_id = {"boxes": 0, "sort": 1, "ranges": 2, "sweep": 3, "narrow_vf": 4, "narrow_ee": 5}  # SCCD_PROF_*
+        # the dominant KERNEL: the class with the longest launch, each alone on the chip (above)
+        dom = max(prof_apart_raw, key=lambda k: prof_apart_raw[k][0] / max(1, prof_apart_raw[k][1]))
+        class_id = {"boxes": 0, "sort": 1, "cull": 2, "sweep": 3, "narrow_vf": 4, "narrow_ee": 5}  # SCCD_PROF_*
         ctx.set_option(sccd.OPT_PROFILE, (1 << class_id[dom]) << 1)
         # settling steps AFTER the last option change and BEFORE t0 (round 4 timed the steps right behind three option writes and a
         # profile reset: the driver's 20-step window came out 10 % above the 100-step lines of the same library); the profile of
@@ -348,7 +365,7 @@ def main():
             "sweep": (BYTES_SWEEP_PER_BOX * n_boxes + 8.0 * (q_vf + q_ee), "sweep_band_k / sweep_band2_k (2 launches per step)", "sweep_band_k"),
             "sort": (BYTES_SORT_PER_KEY_PASS * 4 * n_boxes, "onesweep radix sort + scans", "os_pass_k"),
             "boxes": (124.0 * n_boxes, "box build, cell fill, sorted records", "entry_record_k"),
-            "ranges": (28.0 * n_boxes, "ranges_k", "ranges_k"),
+            "cull": (BYTES_PER_QUERY * (q_vf + q_ee), "np_cull_k (the projection cull: 2 launches per step)", "np_cull_k"),
         }
         ms_dom, launches = prof[dom]  # live, over the timed region
         per_launch_ms = ms_dom / max(1, launches)
@@ -358,18 +375,18 @@ def main():
         # THIS build of the library: the JSON carries the hash of the libsccd_hip.so it profiled
         traffic, traffic_note = None, "no PMC profile of this workload"
         try:
-            if args.workload == "cloth1m" and args.cloth_n == 708 and world == 1 and os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_traffic_cloth1m.json")):
-                tj = _pmc_file("r04_pmc_traffic_cloth1m.json")
+            if args.workload == "cloth1m" and args.cloth_n == 708 and world == 1 and os.path.exists(os.path.join(ROOT, "profiles", "r05_pmc_traffic_cloth1m.json")):
+                tj = _pmc_file("r05_pmc_traffic_cloth1m.json")
                 if tj:
                     traffic = tj["kernels"][units[dom][2]]["hbm_bytes_per_launch_corrected"]
-                    traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build's kernels (profiles/r04_pmc_traffic_cloth1m.json: "
+                    traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build's kernels (profiles/r05_pmc_traffic_cloth1m.json: "
                                     + ("same library" if tj.get("lib_sha256") == lib_sha256() else "same device code, host code changed since") + ")")
                 else:
-                    traffic_note = "profiles/r04_pmc_traffic_cloth1m.json was taken on other kernels than this library's: dropped"
+                    traffic_note = "profiles/r05_pmc_traffic_cloth1m.json was taken on other kernels than this library's: dropped"
         except Exception:
             pass
         checks = float(c_vf + c_ee)
-        narrow_ms = (prof_all["narrow_vf"][0] + prof_all["narrow_ee"][0]) / n_prof
+        narrow_ms = (prof_all["narrow_vf"][0] + prof_all["narrow_ee"][0] + prof_all["cull"][0]) / n_prof
         if dom.startswith("narrow"):
             dom_checks = float(c_ee if dom == "narrow_ee" else c_vf)
             achieved = dom_checks * FLOP_PER_CHECK / launches_per_step / (per_launch_ms * 1e-3) / 1e12 if ms_dom > 0 else 0.0
@@ -401,20 +418,8 @@ def main():
             "narrow_phase": {"checks_per_step": checks, "launch_ms_sum": round(narrow_ms, 4),
                              "note": "the two narrow launches overlap in the default configuration: launch_ms_sum is not their wall span (broad_phase.passes_apart has each launch alone)"},
         })
-        # ---- the passes apart (two untimed steps, SCCD_OPT_PASSES_APART): each class's own duration with nothing beside it,
-        # and the broad phase against SURVEY 8d's formula (548 B per box + 8 B per pair)
-        ctx.set_option(sccd.OPT_PASSES_APART, 1)
-        for _ in range(2):
-            step()
-        ctx.set_option(sccd.OPT_PROFILE, 1)
-        ctx.reset_profile()
-        st_apart = stats
-        for _ in range(n_prof):
-            _, st_apart = step()
-        prof_apart = {k: v[0] / n_prof for k, v in ctx.profile().items()}
-        ctx.set_option(sccd.OPT_PROFILE, 0)
-        ctx.set_option(sccd.OPT_PASSES_APART, 0)
-        broad_ms = prof_apart["boxes"] + prof_apart["sort"] + prof_apart["ranges"] + prof_apart["sweep"]
+        # ---- the broad phase against SURVEY 8d's formula (548 B per box + 8 B per pair), passes apart (measured before the timed region)
+        broad_ms = prof_apart["boxes"] + prof_apart["sort"] + prof_apart["sweep"]
         if dom.startswith("narrow") and prof_apart.get(dom, 0) > 0:
             # `achieved` above is the contract's figure: the launch's own duration in the timed region.  Since round 4's read-back
             # mailbox the edge-edge launch STARTS ~120 us earlier -- in the SIMD slots its sweep left, beside the
@@ -432,7 +437,7 @@ def main():
                         "its first ~150 us (DESIGN 5.6 / 7)" % n_prof,
             }
         # the slowest rank's device time per phase (passes apart): narrow-phase scaling is readable on its own
-        mx = torch.tensor([broad_ms, prof_apart["narrow_vf"] + prof_apart["narrow_ee"]], dtype=torch.float64, device=red_dev)
+        mx = torch.tensor([broad_ms, prof_apart["narrow_vf"] + prof_apart["narrow_ee"] + prof_apart["cull"]], dtype=torch.float64, device=red_dev)
         if use_dist:
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         rank_max = {"broad_ms": round(float(mx[0].item()), 4), "narrow_ms": round(float(mx[1].item()), 4),

@@ -275,7 +275,8 @@ int sccd_ipc_ccd_strategy(sccd_ctx* ctx, const double* V0, const double* V1, int
 
 #define SCCD_PROF_BOXES 0
 #define SCCD_PROF_SORT 1
-#define SCCD_PROF_RANGES 2
+#define SCCD_PROF_CULL 2   /* (0.3) np_cull_k launches: the projection cull in front of a pass's bisection (0.2: SCCD_PROF_RANGES, a kernel that is gone) */
+#define SCCD_PROF_RANGES 2 /* (the old name of slot 2) */
 #define SCCD_PROF_SWEEP 3
 #define SCCD_PROF_NARROW_VF 4 /* np_walk_k<true> / np_level_k<true> launches  */
 #define SCCD_PROF_NARROW_EE 5 /* np_walk_k<false> / np_level_k<false> launches */

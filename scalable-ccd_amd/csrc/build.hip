@@ -630,7 +630,7 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
             h();
         }
         if (bp->cull.on) { // (behind EVERY sweep of this pass, first attempts and reruns alike)
-            ProfScope ps(c, bp->cull.is_vf ? SCCD_PROF_NARROW_VF : SCCD_PROF_NARROW_EE);
+            ProfScope ps(c, SCCD_PROF_CULL);
             bp->kept.ensure(sizeof(int2) * (size_t)bp->capacity);
             NarrowParams p {};
             p.V = bp->cull.mesh->V.as<double>();
