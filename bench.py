@@ -156,6 +156,7 @@ def parse():
                     "per-query collision list (with and without a check limit), a check limit on the level-synchronous kernels, the float build "
                     "-- each as a multiple of the default step (block `cliffs` of the line)")
     ap.add_argument("--cull", type=int, default=None, help="SCCD_OPT_CULL: 1 (library default) the projection cull in front of the bisection, 0: every pair is bisected")
+    ap.add_argument("--two-halves", type=int, default=None, help="SCCD_OPT_TWO_HALVES: 1 (library default) plain narrow launches from a TOI above 0.5 run as two launches over the halves of time, 0: one launch")
     ap.add_argument("--clock-warmup", type=float, default=1.0, help="seconds of untimed steps before the W warm-up steps (GPU clocks, first touches); 0: none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="cloth side of the CPU sample (0 = auto)")
@@ -203,6 +204,8 @@ def main():
     ctx.set_option(sccd.OPT_SHARD_COUNT, world)
     if args.cull is not None:
         ctx.set_option(sccd.OPT_CULL, args.cull)
+    if args.two_halves is not None:
+        ctx.set_option(sccd.OPT_TWO_HALVES, args.two_halves)
 
     def barrier():
         ctx.synchronize()
@@ -500,7 +503,7 @@ def main():
                            checks_per_step=float(qq[1].item()), candidates_per_step=float(qq[2].item()),
                            parallelism=f"cell windows sharded over {world} GPU(s), one RCCL all-reduce(min) of the TOI per step",
                            rccl_ranks=rccl_ranks, backend=(backend if use_dist else "none"),
-                           projection_cull=int(ctx.get_option(sccd.OPT_CULL)), culled_per_step=int(stats.get("n_vf_culled", 0) + stats.get("n_ee_culled", 0)),
+                           projection_cull=int(ctx.get_option(sccd.OPT_CULL)), two_halves_of_time=int(ctx.get_option(sccd.OPT_TWO_HALVES)), culled_per_step=int(stats.get("n_vf_culled", 0) + stats.get("n_ee_culled", 0)),
                            culled_note="overlap pairs the projection cull (csrc/narrow_cull.inc) dropped before the bisection: provably no impact; they count as answered queries"),
             # schema 2 (round 4): min_toi_latency_ms is ONE thing again -- the step's latency on a device-resident mesh, = ms_per_step,
             # as in rounds 1-2 and for any number of ranks; the reference-shaped call from host matrices is host_path_ms only

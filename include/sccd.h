@@ -115,6 +115,11 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        * domain the reference's bisection could accept (csrc/narrow_cull.inc): the result is unchanged, the narrow
                                        * phase bisects a fraction of the pairs; 0: every pair is bisected, as root_finder.cu:372-457 does.
                                        * sccd_narrow_phase and the collision-list / per-query drivers never cull. */
+#define SCCD_OPT_TWO_HALVES 25        /* 1 (default): a narrow-phase launch of the plain walk kernel (double build, no check limit, no per-query output) that
+                                       * starts from a TOI above 0.5 runs as two launches over the halves of time: the first from the bound 0.5; if it
+                                       * accepts nothing, the second bisects what lies at or beyond 0.5, from the caller's TOI (csrc/narrow_walk.inc).
+                                       * The same accepted domains as one launch (root_finder.cu:277-370), hence the same result; a call whose earliest
+                                       * impact lies before 0.5 never explores the later halves of its first time splits.  0: one launch */
 #define SCCD_OPT_ALLOC_COUNT 23       /* read: device allocations the library's grow-only buffers have made since it was loaded (all contexts): a call
                                        * during which the count rises has grown a buffer -- hipFree + hipMalloc, milliseconds */
 #define SCCD_OPT_SPEC_HITS 15   /* read: speculative builds (sort, records and sweep enqueued for the previous build's entry counts) whose */

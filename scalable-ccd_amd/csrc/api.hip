@@ -195,6 +195,7 @@ int sccd_set_option(sccd_ctx* c, int opt, int64_t v)
     case SCCD_OPT_CELL_FACTOR_MILLI: c->cell_factor_milli = (int)v; break;
     case SCCD_OPT_BUILD_SCAN: c->build_scan = v ? 1 : 0; break;
     case SCCD_OPT_CULL: c->cull_on = v ? 1 : 0; break;
+    case SCCD_OPT_TWO_HALVES: c->two_halves = v ? 1 : 0; break;
     case SCCD_OPT_TOI_GUESS:
         c->toi_guess_on = v ? 1 : 0;
         c->toi_guess = 1.0; // (forget what was learnt)
@@ -232,6 +233,7 @@ int64_t sccd_get_option(const sccd_ctx* c, int opt)
     case SCCD_OPT_CELL_FACTOR_MILLI: return c->cell_factor_milli;
     case SCCD_OPT_BUILD_SCAN: return c->build_scan;
     case SCCD_OPT_CULL: return c->cull_on;
+    case SCCD_OPT_TWO_HALVES: return c->two_halves;
     case SCCD_OPT_ALLOC_COUNT: return devbuf_alloc_count();
     case SCCD_OPT_TOI_GUESS: return c->toi_guess_on;
     case SCCD_OPT_TOI_GUESS_HITS: return c->toi_guess_hits;

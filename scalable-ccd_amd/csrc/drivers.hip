@@ -232,7 +232,12 @@ static void ccd_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, sccd_broad_p
     else bp_build(bp, &pl->eb, nullptr);
     bool started = swept; // (... and the first sweep enqueued as well: bp_detect_partial(bp, 1))
     while (bp->cursor < bp->total_rows) {
-        narrow_counters_upload(c, narrow_counters(c), *toi); // ahead of the sweep: one copy less between sweep and narrow phase
+        {
+            // ahead of the sweep: one copy less between sweep and narrow phase (from the TOI the launch will start from:
+            // narrow_start_toi -- 0.5 where the walk kernel runs its two halves of time)
+            const NarrowParams p0 = narrow_params(c, m, nullptr, 0, vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi);
+            narrow_counters_upload(c, narrow_counters(c), narrow_start_toi(c, p0, *toi, false));
+        }
         bp_detect_partial(bp, started ? 2 : 0);
         started = false;
         if (before_narrow && *before_narrow) {
@@ -367,7 +372,11 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
         hipEvent_t const ev = c->side_event;
         sccd_broad_phase* const bp_ee = &pl->bp_ee;
         const sccd_boxes* const eb = &pl->eb;
-        const double toi_start = toi;
+        sc->arith = c->arith;
+        sc->scalar_f32 = c->scalar_f32;
+        sc->narrow_algo = c->narrow_algo;
+        sc->two_halves = c->two_halves;
+        const double toi_start = narrow_start_toi(sc, narrow_params(sc, m, nullptr, 0, 0, max_iter, tol, ms, allow_zero_toi), toi, false);
         pl->worker.submit([=] {
             SCCD_HIP(hipSetDevice(device));
             SCCD_HIP(hipStreamWaitEvent(sc->stream, ev, 0));
@@ -428,7 +437,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
             sc->narrow_algo = c->narrow_algo;
             sc->limit_level_order = c->limit_level_order;
             c->np_init_pending = true; // (the counters of the vertex-face narrow launch: started by the build's grid kernel)
-            c->np_init_toi = toi;
+            c->np_init_toi = narrow_start_toi(c, narrow_params(c, m, nullptr, 0, 1, max_iter, tol, ms, allow_zero_toi), toi, false);
             pass_cull_setup(c, &pl->bp, m, true, ms, max_iter, tol);
             bp_build(&pl->bp, &pl->vb, &pl->fb);
             c->np_init_pending = false;
@@ -464,7 +473,10 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
                 // speculative build's guess broke), the kernel has run on a prefix of the true list or on nothing -- whatever it
                 // put into the running TOI is an accepted domain of a true pair -- and the pass is done again as before.
                 NarrowParams pe = narrow_params(sc, m, pass_pairs(&pl->bp_ee), 0, 0, max_iter, tol, ms, allow_zero_toi);
-                pe.toi_word = &narrow_counters(c)->toi_bits;
+                // (the two kernels share ONE running TOI -- unless a pass runs its two halves of time: its word then holds the bound
+                // 0.5 for a while, which the other pass must not prune by; each keeps its own word, the minimum is taken below)
+                if (narrow_start_toi(c, pv, toi_vf, false) == toi_vf && narrow_start_toi(sc, pe, toi_ee, false) == toi_ee)
+                    pe.toi_word = &narrow_counters(c)->toi_bits;
                 bool early = false;
                 if (lab_env().ee_early && presweep_done && pl->bp_ee.sweeps_in_call == 1 && toi_ee > 0 && !sc->scalar_f32 && narrow_uses_walk_kernel(sc, pe, false)) {
                     const SweepCounters* const sw = sc->scalars.as<SweepCounters>();

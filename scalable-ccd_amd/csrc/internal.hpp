@@ -244,7 +244,7 @@ struct NarrowCounters {
     unsigned int n_ovf; // queries np_walk_k handed to the level-synchronous path (entries of its overflow list)
     unsigned long long toi_level; // level-synchronous kernels with a check limit: the TOI as of the start of the level
     unsigned int n_arg;           // np_walk_k with a check limit: (query, time) records of the lanes that lowered the TOI (narrow.hip: the certificate)
-    unsigned int pad_arg;
+    unsigned int second_go;       // "two halves of time" (narrow_walk.inc): 1 = the second launch has work (np_second_half_k)
     unsigned long long pad3[12];
     // occupancy diagnostics of np_walk_k (SCCD_NP_DIAG=1 prints them)
     unsigned long long wave_steps;   // check steps executed by waves
@@ -276,6 +276,9 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
 void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
                       double* d_per_query_toi);
 bool narrow_uses_walk_kernel(const sccd_ctx* c, const NarrowParams& p, bool per_query); // (else: level-synchronous kernels)
+// the TOI a pass's counters are STARTED from: the caller's, or 0.5 where the pass will be served by the walk kernel's two launches
+// over the halves of time (narrow_walk.inc; plain launches of the double build from a TOI above 0.5, SCCD_OPT_TWO_HALVES)
+double narrow_start_toi(const sccd_ctx* c, const NarrowParams& p, double toi, bool per_query);
 // the projection cull (narrow_cull.inc): pairs[0 .. min(*d_n_pairs, capacity)) -> the pairs that may have an impact, compacted
 // into d_kept[0 .. *d_n_kept) (any order; *d_n_kept must be 0); on c->stream.  Only p's mesh pointers, pairs, is_vf, ms, tol are used.
 void narrow_cull_launch(sccd_ctx* c, const NarrowParams& p, const unsigned long long* d_n_pairs, long long capacity, int2* d_kept,

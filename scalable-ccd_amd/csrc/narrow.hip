@@ -670,6 +670,13 @@ bool narrow_uses_walk_kernel(const sccd_ctx* c, const NarrowParams& p, bool per_
              || (p.max_iter >= 0 && (c->limit_level_order || (!per_query && p.max_iter < SCCD_QUEUE_MIN_MAX_ITER))));
 }
 
+double narrow_start_toi(const sccd_ctx* c, const NarrowParams& p, double toi, bool per_query)
+{
+    // (exactly the launches narrow_phase_begin serves with the plain walk kernel; diagnostics builds count one launch)
+    const bool two = c->two_halves && !per_query && p.max_iter < 0 && !c->scalar_f32 && c->narrow_algo != 1 && lab_env().np_diag == 0 && toi > 0.5;
+    return two ? 0.5 : toi;
+}
+
 // d_n / capacity: the list's length is still being made on the device when this is called (ccd(): the launch goes into the stream
 // right behind the pass's sweep and cull) -- p.n_pairs is ignored, the walk kernel takes min(*d_n, capacity); plain launches of
 // the double build only (no check limit, no per-query output), the caller's business
@@ -681,7 +688,10 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
     c->np_limit_fast = false; // (context-sticky between begin and end: a begin whose end never came must not leave it set)
     c->np_pq_limit = false;
     // pinned mirror: [8 KB, 12 KB) the counters handed to the caller, [12 KB, 16 KB) the upload source
-    if (!(c->np_uploaded && std::memcmp(&c->np_uploaded_toi, h_toi_inout, 8) == 0)) narrow_counters_upload(c, d_cnt, *h_toi_inout);
+    // (two halves of time, narrow_walk.inc: the counters start from 0.5, the walk kernel's second launch goes on from the caller's TOI)
+    const double start_toi = narrow_start_toi(c, p, *h_toi_inout, d_per_query_toi != nullptr);
+    const double two_halves_from = start_toi != *h_toi_inout ? *h_toi_inout : 0.0;
+    if (!(c->np_uploaded && std::memcmp(&c->np_uploaded_toi, &start_toi, 8) == 0)) narrow_counters_upload(c, d_cnt, start_toi);
     c->np_uploaded = false;
     // the reference's outer loop runs only while toi > 0 (narrow_phase.cu:136); in the
     // per-query build the guard is absent (:138)
@@ -692,11 +702,13 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
                      "narrow_phase: a list whose length is on the device is served by the plain walk kernel only");
         if (run) {
             ProfScope ps(c, p.is_vf ? SCCD_PROF_NARROW_VF : SCCD_PROF_NARROW_EE);
-            run_walk(c, p, d_cnt, 0, nullptr, nullptr, 0, d_n, capacity);
+            run_walk(c, p, d_cnt, 0, nullptr, nullptr, 0, d_n, capacity, two_halves_from);
         }
         return;
     }
-    if (run && n > 0) {
+    // (counters that were started from 0.5 for the two halves of time get their launches even for an empty list: the kernel
+    // between the two puts the caller's TOI back)
+    if (run && (n > 0 || two_halves_from > 0.5)) {
         ProfScope ps(c, p.is_vf ? SCCD_PROF_NARROW_VF : SCCD_PROF_NARROW_EE);
         // A check limit (max_iter >= 0: the IPC Toolkit passes 10^7) is defined in the reference's LEVEL ORDER: it counts the
         // domains of a query as the breadth-first launches pop them (root_finder.cu:287-305), several times what a
@@ -761,7 +773,7 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
                 c->np_scratch3_ovf.ensure(sizeof(int) * (size_t)cap);
                 run_walk(c, p, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi), c->np_scratch3_ovf.as<int>(), cap);
             } else {
-                run_walk(c, p, d_cnt, n, nullptr);
+                run_walk(c, p, d_cnt, n, nullptr, nullptr, 0, nullptr, 0, two_halves_from);
             }
         }
     }

@@ -793,9 +793,11 @@ __device__ __forceinline__ void nw_bounds(unsigned k, unsigned d, double& lo, do
     w = ldexp(1.0, e);
     hi = lo + w;
 }
+// t_floor: a domain that ends at or before it is dead -- the SECOND of two launches over one list (narrow_walk.inc, "two halves of
+// time") only bisects what the first, pruned at t_floor, did not reach; 0: no floor (every domain ends after 0)
 template <bool VF, int ARITH>
 __device__ __forceinline__ NQStep nw_step(const NWQuery& q, const NQDom& dm, double ms, double co_domain_tol,
-                                          bool allow_zero_toi, double prune_toi)
+                                          bool allow_zero_toi, double prune_toi, double t_floor = 0.0)
 {
     NQStep r;
     r.accept = false;
@@ -810,7 +812,7 @@ __device__ __forceinline__ NQStep nw_step(const NWQuery& q, const NQDom& dm, dou
     const double min_t = lo[0];
     r.min_t = min_t;
     // (straight-line on purpose: the lanes of a wave run this in lockstep; the reference's early exits are the masks below)
-    const bool live = !(min_t >= prune_toi); // :295
+    const bool live = !(min_t >= prune_toi) & !(hi[0] <= t_floor); // :295
     double true_tol;
     bool box_in;
     const bool in = ti_inclusion_mm<VF, ARITH>(q.v, lo, hi, q.err, ms, true_tol, box_in);

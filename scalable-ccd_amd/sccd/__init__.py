@@ -43,6 +43,7 @@ OPT_PASSES_APART = 13  # 1: ccd() runs its two passes one after the other (measu
 OPT_CELL_FACTOR_MILLI, OPT_BUILD_SCAN = 17, 18  # grid cell size (thousandths of the mean extent); count -> scan -> fill build
 OPT_TOI_GUESS, OPT_TOI_GUESS_HITS, OPT_TOI_GUESS_MISSES = 19, 20, 21  # the speculative TOI bound of ccd() on a mesh (see sccd.h)
 OPT_CULL = 24  # 1 (default): ccd()'s passes drop pairs that provably have no impact before the bisection (csrc/narrow_cull.inc)
+OPT_TWO_HALVES = 25  # 1 (default): plain narrow launches from a TOI above 0.5 run as two launches over the halves of time (see sccd.h)
 OPT_ALLOC_COUNT = 23  # read-only: device allocations made by the library's grow-only buffers (a step that allocates is a slow step)
 OPT_SPEC_HITS, OPT_SPEC_MISSES = 15, 16  # read-only counters of the speculative build (set: reset)
 OPT_LIMIT_LEVEL_ORDER = 14  # 1: check limits always on the level-synchronous kernels; default: fast kernel + certificate (same result)

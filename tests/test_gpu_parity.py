@@ -1393,6 +1393,50 @@ def test_speculative_toi_bound_is_exact_in_the_float_build(sccd, orc, path):
         c.close()
 
 
+# ---- two halves of time (csrc/narrow_walk.inc) ----------------------------------------------------------------------------
+@pytest.mark.parametrize("scene", ["cloth_ball_small", "soup_dense", "folded_120"])
+def test_two_halves_of_time_change_no_result(sccd, orc, scene):
+    """A plain narrow launch from a TOI above 0.5 runs as two launches (the first from the bound 0.5, the second -- only if the first
+    accepted nothing -- over what lies at or beyond 0.5).  The motion is scaled so that the earliest impact falls before 0.5 (the first
+    launch decides), between 0.5 and 1 (the second one does), nowhere (both run, result 1), with and without the cull, both zero-TOI
+    policies: every result is the oracle's, and the option switched off gives the same."""
+    V0, V1, E, F = _scene(scene)
+    c = sccd.Context(0)
+    try:
+        c.set_option(sccd.OPT_TOI_GUESS, 0)
+        mesh = sccd.Mesh(V0, V1, E, F, ctx=c)
+        seen = []
+        for s in (3.0, 1.0, 0.8, 0.62, 0.5, 0.41, 0.3, 0.2, 0.1, 0.02):
+            W1 = V0 + s * (V1 - V0)
+            mesh.update_vertices(V0, W1)
+            for allow_zero in (True, False):
+                want = orc.ccd(V0, W1, E, F, 0.0, -1, 1e-6, allow_zero, nthreads=8)[0]
+                for cull in (1, 0):
+                    c.set_option(sccd.OPT_CULL, cull)
+                    c.set_option(sccd.OPT_TWO_HALVES, 1)
+                    two = sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, allow_zero)
+                    c.set_option(sccd.OPT_TWO_HALVES, 0)
+                    one = sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, allow_zero)
+                    assert two == want and one == want, (scene, s, allow_zero, cull, two, one, want)
+            seen.append(want)
+        if scene == "cloth_ball_small":  # (the soup collides at once whatever the scale, the small folded cloth never: covered, not counted)
+            assert min(seen) < 0.5 and any(0.5 <= t < 1.0 for t in seen) and max(seen) == 1.0, seen  # either launch got to decide, and neither
+        # the pass-by-pass API (a rank of a multi-GPU job) and a start from a caller's TOI between 0.5 and 1
+        c.set_option(sccd.OPT_CULL, 1)
+        c.set_option(sccd.OPT_TWO_HALVES, 1)
+        mesh.update_vertices(V0, V1)
+        sccd.ccd_mesh_prepare(mesh, 0.0)
+        want = orc.ccd(V0, V1, E, F, 0.0, -1, 1e-6, True, nthreads=8)[0]
+        for t0 in (1.0, 0.75, 0.5, 0.3):
+            t = t0
+            for is_vf in (True, False):
+                t, _ = sccd.ccd_mesh_pass(mesh, is_vf, t)
+            assert t == min(t0, want), (scene, t0, t, want)
+        mesh.close()
+    finally:
+        c.close()
+
+
 # ---- the projection cull (csrc/narrow_cull.inc) -----------------------------------------------------------------------------
 def _cull_scenes():
     """(name, V0, V1, E, F, ms): ordinary scenes and the regimes the cull's bound has to get right -- slow and static pairs (the
