@@ -235,6 +235,12 @@ typedef struct sccd_stats {
  * counterpart; exported so that the claim can be tested against the oracle's per-query output (tests/test_gpu_parity.py). */
 int sccd_query_cull(sccd_ctx* ctx, const sccd_mesh* mesh, const int32_t* pairs, int64_t n, int is_vf, double min_distance, double tolerance,
                     int32_t* kept, int64_t* n_kept);
+/* ... for one SLAB OF TIME, as ccd() runs it (narrow_cull.inc, "slabs of time"): a narrow launch that starts from the bound b only
+ * accepts domains that begin before b, the second launch of the "two halves of time" (SCCD_OPT_TWO_HALVES) only domains that end
+ * after 0.5.  kept = the pairs that may have an accepted domain meeting t in [t_lo, t_hi], 0 <= t_lo < t_hi <= 1 ((0, 1):
+ * sccd_query_cull).  Against the oracle's per-query output: a pair that is left out has no earliest impact in [t_lo, t_hi). */
+int sccd_query_cull_slab(sccd_ctx* ctx, const sccd_mesh* mesh, const int32_t* pairs, int64_t n, int is_vf, double min_distance,
+                         double tolerance, double t_lo, double t_hi, int32_t* kept, int64_t* n_kept);
 
 /* ccd(V0,V1,E,F,min_distance,max_iterations,tolerance,allow_zero_toi,memory_limit_GB):
  * src/scalable_ccd/cuda/ccd.cuh:26-38 / ccd.cu:80-146.  Host matrices in, earliest TOI out.

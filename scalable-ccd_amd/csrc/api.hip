@@ -510,8 +510,11 @@ extern "C" int sccd_boxes_create(sccd_ctx* c, const sccd_aabb* boxes, int n, int
 constexpr int LAZY_STATS_STRIDE = 8; // a lazy list's grid statistics look at every 8th element
 // lazy_ef: the edge and face lists are only DESCRIBED (multi-GPU ccd(): a rank builds the boxes of its window of cells, in
 // the fill pass -- internal.hpp sccd_boxes::lazy); their grid statistics come from a sample every rank takes alike
+// after_vertices (the step's two streams): recorded behind the vertex boxes; the EDGE boxes are then left to the caller's helper
+// stream (edge_boxes_on) -- the face boxes here and the edge boxes there run side by side, and each build chain starts when
+// its own list is done, not when both are
 void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline* pl, bool want_v, bool want_e,
-                            bool want_f, bool lazy_ef)
+                            bool want_f, bool lazy_ef, hipEvent_t after_vertices)
 {
     (void)want_v;
     ProfScope ps(c, SCCD_PROF_BOXES);
@@ -527,6 +530,7 @@ void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline* pl, bo
     pl->vb.n_part = launch_vertex_boxes(c, m->V.as<double>(), m->nV, r, pl->vb.raw.as<sccd_aabb>(), pl->vb.stats_head(),
                                         pl->vb.stats_part());
     pl->vb.have_stats = true;
+    if (after_vertices) SCCD_HIP(hipEventRecord(after_vertices, c->stream));
     if (want_e) {
         pl->eb.n = m->nE;
         pl->eb.kind = BOX_EDGE;
@@ -551,6 +555,7 @@ void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline* pl, bo
         }
         return;
     }
+    if (after_vertices) want_e = false; // (edge_boxes_on: the buffers are ready, the launch is the helper's)
     if (want_e && want_f && m->nE > 0 && m->nF > 0) { // both in one launch
         launch_edge_face_boxes(c, pl->vb.raw.as<sccd_aabb>(), m->E.as<int2>(), m->nE, pl->eb.raw.as<sccd_aabb>(), pl->eb.stats_head(),
                                pl->eb.stats_part(), &pl->eb.n_part, m->F.as<int4>(), m->nF, pl->fb.raw.as<sccd_aabb>(),
@@ -568,6 +573,14 @@ void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline* pl, bo
                                           pl->fb.raw.as<sccd_aabb>(), pl->fb.stats_head(), pl->fb.stats_part());
         pl->fb.have_stats = true;
     }
+}
+
+void edge_boxes_on(sccd_ctx* sc, const sccd_mesh* m, Pipeline* pl)
+{
+    ProfScope ps(sc, SCCD_PROF_BOXES);
+    pl->eb.n_part = launch_edge_boxes(sc, pl->vb.raw.as<sccd_aabb>(), m->E.as<int2>(), m->nE, pl->eb.raw.as<sccd_aabb>(),
+                                      pl->eb.stats_head(), pl->eb.stats_part());
+    pl->eb.have_stats = true;
 }
 
 // statistics of a list that was uploaded rather than built here: one pass, cached in the object

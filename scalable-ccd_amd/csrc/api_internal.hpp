@@ -117,7 +117,9 @@ void copy_in(sccd_ctx* c, void* dst, const void* src, size_t bytes, int src_on_d
 sccd_mesh* scratch_mesh_from_host(sccd_ctx* c, const double* V0, const double* V1, int nV, const int32_t* E, int nE, const int32_t* F,
                                   int nF, bool defer_verdict = false);
 void mesh_deferred_verdict(sccd_ctx* c);
-void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline* pl, bool want_v, bool want_e, bool want_f, bool lazy_ef = false);
+void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline* pl, bool want_v, bool want_e, bool want_f, bool lazy_ef = false,
+                     hipEvent_t after_vertices = nullptr);
+void edge_boxes_on(sccd_ctx* sc, const sccd_mesh* m, Pipeline* pl);
 void ensure_stats(sccd_ctx* c, const sccd_boxes* b);
 // build.hip
 void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes* B);

@@ -640,7 +640,10 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
             p.is_vf = bp->cull.is_vf;
             p.ms = bp->cull.ms;
             p.tol = bp->cull.tol;
-            narrow_cull_launch(c, p, &d_cnt->n_pairs, (long long)bp->capacity, bp->kept.as<int2>(), &d_cnt->n_kept);
+            // (the first slab of the pass's time; the second half's list is made between the walk kernel's two launches, if at all)
+            if (bp->cull.slabs.two) bp->kept_b.ensure(sizeof(int2) * (size_t)bp->capacity);
+            narrow_cull_launch(c, p, &d_cnt->n_pairs, (long long)bp->capacity, bp->kept.as<int2>(), &d_cnt->n_kept, 0.0,
+                               bp->cull.slabs.two ? bp->cull.slabs.t_mid : bp->cull.slabs.t_end);
         }
         if (phase == 1) return;
     launched:

@@ -115,6 +115,8 @@ struct LabEnv {
     bool readback_copy = false;        // SCCD_READBACK=copy: read-backs as copies + a polled event instead of one gather kernel + a polled word
     bool sort_tickets = false;         // SCCD_SORT_TICKETS=1: sort tiles by atomic ticket even when every tile has its block
     long long level_budget_mb = 0;     // SCCD_LEVEL_BUDGET_MB: budget per level buffer of the level-synchronous narrow phase
+    bool split_boxes = true;           // SCCD_SPLIT_BOXES=0: ccd()'s edge and face boxes in one launch on the caller's stream (round 4)
+    bool cull_slabs = true;            // SCCD_CULL_SLABS=0: the projection cull looks at the whole step whatever the launches ask (round 5's first cull)
     bool ee_early = true;              // SCCD_EE_EARLY=0: ccd()'s edge-edge walk kernel launched by the host once it has the pair count (round 4)
                                        // instead of right behind its sweep and cull with the count read on the device
     int spec_break_every = 0;          // SCCD_SPEC_BREAK=N: every N-th speculative build is declared a failed guess (measures what a miss costs)
@@ -136,6 +138,8 @@ struct LabEnv {
         level_budget_mb = num("SCCD_LEVEL_BUDGET_MB", 0);
         spec_break_every = num("SCCD_SPEC_BREAK", 0);
         ee_early = num("SCCD_EE_EARLY", 1) != 0;
+        cull_slabs = num("SCCD_CULL_SLABS", 1) != 0;
+        split_boxes = num("SCCD_SPLIT_BOXES", 1) != 0;
         const char* s = std::getenv("SCCD_SYNC");
         sync_block = s && std::string(s) == "block";
         const char* r = std::getenv("SCCD_READBACK");

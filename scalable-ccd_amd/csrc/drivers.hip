@@ -13,18 +13,75 @@ struct NarrowResult {
     unsigned long long n_checks;
 };
 
-// the list a pass's narrow phase runs on: what the projection cull kept (narrow_cull.inc, bp_detect_partial) or every overlap
+// the list(s) a pass's narrow phase runs on: what the projection cull kept (narrow_cull.inc, bp_detect_partial) -- one list, or one
+// per half of time -- or every overlap
 static const int2* pass_pairs(const sccd_broad_phase* bp) { return bp->cull.on ? bp->kept.as<int2>() : bp->overlaps.as<int2>(); }
 static int64_t pass_count(const sccd_broad_phase* bp) { return bp->cull.on ? bp->n_kept : bp->n_overlaps; }
+static void pass_lists(const sccd_broad_phase* bp, NarrowParams* p)
+{
+    p->pairs = pass_pairs(bp);
+    p->n_pairs = pass_count(bp);
+    p->second = NarrowParams::SecondHalf();
+    // (the second half of the pass's time: its own list, made when it is asked for -- run_walk; a pass whose lists gave no sweep at
+    // all has no overlaps, and no counters of its own on the device either)
+    if (bp->cull.on && bp->cull.slabs.two && bp->sweeps_in_call > 0) {
+        SweepCounters* const sw = bp->ctx->scalars.as<SweepCounters>();
+        p->second.src = bp->overlaps.as<int2>();
+        p->second.d_n_src = &sw->n_pairs;
+        p->second.capacity = (long long)bp->capacity;
+        p->second.kept = bp->kept_b.as<int2>();
+        p->second.d_n_kept = &sw->n_kept_b;
+        p->second.t_lo = bp->cull.slabs.t_mid;
+        p->second.t_hi = bp->cull.slabs.t_end;
+    }
+}
 // ... and whether a pass of ccd() culls at all: the double build's walk kernel without a check limit (the certificate of a limit,
-// the level-order kernels and the float build keep the reference's own list: their counts and fallbacks are defined on it)
-static void pass_cull_setup(sccd_ctx* c, sccd_broad_phase* bp, const sccd_mesh* m, bool vf, double ms, int max_iter, double tol)
+// the level-order kernels and the float build keep the reference's own list: their counts and fallbacks are defined on it).
+// toi: the pass's narrow launches start from this TOI at most -- the slabs of time the cull looks at (narrow_cull_slabs)
+static NarrowParams narrow_params(sccd_ctx* c, const sccd_mesh* m, const int2* d_pairs, int64_t n, int is_vf, int max_iter,
+                                  double tol, double ms, int allow_zero_toi);
+static void pass_cull_setup(sccd_ctx* c, sccd_broad_phase* bp, const sccd_mesh* m, bool vf, double ms, int max_iter, double tol, double toi)
 {
     bp->cull.on = c->cull_on && !c->scalar_f32 && max_iter < 0 && c->narrow_algo != 1 && std::isfinite(tol) && tol > 0 && ms >= 0;
     bp->cull.mesh = m;
     bp->cull.is_vf = vf ? 1 : 0;
     bp->cull.ms = ms;
     bp->cull.tol = tol;
+    bp->cull.slabs = CullSlabs();
+    if (bp->cull.on) bp->cull.slabs = narrow_cull_slabs(c, narrow_params(c, m, nullptr, 0, vf ? 1 : 0, max_iter, tol, ms, 1), toi);
+}
+// The lists of a pass were made for launches that start at or below cull.slabs.t_end; a start ABOVE it (a speculative bound that did
+// not hold: the step is redone from 1 on the pair lists that are still on the device) culls the pass's overlaps again, on the
+// pass's own stream; the host waits for the counts.
+static void pass_recull(sccd_ctx* c, sccd_broad_phase* bp, double toi, int max_iter)
+{
+    if (!bp->cull.on || toi <= bp->cull.slabs.t_end) return;
+    sccd_ctx* const bc = bp->ctx;
+    SweepCounters* const d_cnt = bc->scalars.as<SweepCounters>();
+    bp->cull.slabs = narrow_cull_slabs(c, narrow_params(c, bp->cull.mesh, nullptr, 0, bp->cull.is_vf, max_iter, bp->cull.tol, bp->cull.ms, 1), toi);
+    SweepCounters h {};
+    h.n_pairs = (unsigned long long)bp->n_overlaps;
+    copy_in(bc, &d_cnt->n_pairs, &h.n_pairs, sizeof h.n_pairs, 0);
+    copy_in(bc, &d_cnt->n_kept, &h.n_kept, sizeof h.n_kept, 0);
+    {
+        ProfScope ps(bc, SCCD_PROF_CULL);
+        NarrowParams p {};
+        p.V = bp->cull.mesh->V.as<double>();
+        p.E = bp->cull.mesh->E.as<int2>();
+        p.F = bp->cull.mesh->F.as<int4>();
+        p.pairs = bp->overlaps.as<int2>();
+        p.is_vf = bp->cull.is_vf;
+        p.ms = bp->cull.ms;
+        p.tol = bp->cull.tol;
+        bp->kept.ensure(sizeof(int2) * (size_t)std::max<int64_t>(bp->capacity, 1));
+        if (bp->cull.slabs.two) bp->kept_b.ensure(sizeof(int2) * (size_t)std::max<int64_t>(bp->capacity, 1));
+        narrow_cull_launch(bc, p, &d_cnt->n_pairs, (long long)bp->n_overlaps, bp->kept.as<int2>(), &d_cnt->n_kept, 0.0,
+                           bp->cull.slabs.two ? bp->cull.slabs.t_mid : bp->cull.slabs.t_end);
+    }
+    ReadBack rb(bc);
+    rb.add(&h, d_cnt, sizeof h);
+    rb.sync();
+    bp->n_kept = (int64_t)h.n_kept;
 }
 
 static NarrowParams narrow_params(sccd_ctx* c, const sccd_mesh* m, const int2* d_pairs, int64_t n, int is_vf, int max_iter,
@@ -64,6 +121,18 @@ static NarrowResult run_narrow(sccd_ctx* c, const sccd_mesh* m, const int2* d_pa
     const NarrowParams p = narrow_params(c, m, d_pairs, n, is_vf, max_iter, tol, ms, allow_zero_toi);
     if (c->scalar_f32) *toi = (double)(float)*toi;
     narrow_phase_run(c, p, narrow_counters(c), toi, d_per_query);
+    return narrow_result(c);
+}
+
+// ... of a pass of ccd(): on the cull's list(s)
+static NarrowResult run_narrow_pass(sccd_ctx* c, const sccd_mesh* m, sccd_broad_phase* bp, int is_vf, int max_iter, double tol, double ms,
+                                    int allow_zero_toi, double* toi)
+{
+    pass_recull(c, bp, *toi, max_iter);
+    NarrowParams p = narrow_params(c, m, nullptr, 0, is_vf, max_iter, tol, ms, allow_zero_toi);
+    pass_lists(bp, &p);
+    if (c->scalar_f32) *toi = (double)(float)*toi;
+    narrow_phase_run(c, p, narrow_counters(c), toi, nullptr);
     return narrow_result(c);
 }
 
@@ -179,41 +248,54 @@ extern "C" int sccd_narrow_phase(sccd_ctx* c, const sccd_mesh* m, const int32_t*
     });
 }
 
+static void query_cull(sccd_ctx* c, const sccd_mesh* m, const int32_t* pairs, int64_t n, int is_vf, double ms, double tol, double t_lo, double t_hi,
+                       int32_t* kept, int64_t* n_kept)
+{
+    SCCD_REQUIRE(n >= 0 && (n == 0 || (pairs && kept)), "query_cull: bad pair list");
+    SCCD_REQUIRE(tol > 0 && std::isfinite(tol) && ms >= 0 && std::isfinite(ms), "query_cull: tolerance must be positive and finite, minimum separation >= 0");
+    SCCD_REQUIRE(t_lo >= 0 && t_lo < t_hi && t_hi <= 1, "query_cull: the slab must satisfy 0 <= t_lo < t_hi <= 1");
+    if (n == 0) return;
+    const int na = is_vf ? m->nV : m->nE, nb = is_vf ? m->nF : m->nE;
+    for (int64_t i = 0; i < n; i++)
+        SCCD_REQUIRE(pairs[2 * i] >= 0 && pairs[2 * i] < na && pairs[2 * i + 1] >= 0 && pairs[2 * i + 1] < nb, "query_cull: pair index out of range");
+    DevBuf d_in, d_out, d_cnt;
+    d_in.ensure(sizeof(int2) * (size_t)n);
+    d_out.ensure(sizeof(int2) * (size_t)n);
+    d_cnt.ensure(16);
+    const unsigned long long h_cnt[2] = { (unsigned long long)n, 0ull }; // {pairs in, pairs kept}
+    copy_in(c, d_in.p, pairs, sizeof(int2) * (size_t)n, 0);
+    copy_in(c, d_cnt.p, h_cnt, sizeof h_cnt, 0);
+    NarrowParams p {};
+    p.V = m->V.as<double>();
+    p.E = m->E.as<int2>();
+    p.F = m->F.as<int4>();
+    p.pairs = d_in.as<int2>();
+    p.is_vf = is_vf;
+    p.ms = ms;
+    p.tol = tol;
+    narrow_cull_launch(c, p, d_cnt.as<unsigned long long>(), (long long)n, d_out.as<int2>(), d_cnt.as<unsigned long long>() + 1, t_lo, t_hi);
+    unsigned long long k = 0;
+    SCCD_HIP(hipMemcpyAsync(&k, d_cnt.as<unsigned long long>() + 1, sizeof k, hipMemcpyDeviceToHost, c->stream));
+    SCCD_HIP(hipStreamSynchronize(c->stream));
+    SCCD_REQUIRE((int64_t)k <= n, "query_cull: kept more than it was given");
+    if (k) SCCD_HIP(hipMemcpy(kept, d_out.p, sizeof(int2) * (size_t)k, hipMemcpyDeviceToHost));
+    *n_kept = (int64_t)k;
+}
+
 extern "C" int sccd_query_cull(sccd_ctx* c, const sccd_mesh* m, const int32_t* pairs, int64_t n, int is_vf, double ms, double tol,
                                int32_t* kept, int64_t* n_kept)
 {
     if (!c || !m || !n_kept) return SCCD_E_INVALID;
     *n_kept = 0;
-    return guarded(c, [&] {
-        SCCD_REQUIRE(n >= 0 && (n == 0 || (pairs && kept)), "query_cull: bad pair list");
-        SCCD_REQUIRE(tol > 0 && std::isfinite(tol) && ms >= 0 && std::isfinite(ms), "query_cull: tolerance must be positive and finite, minimum separation >= 0");
-        if (n == 0) return;
-        const int na = is_vf ? m->nV : m->nE, nb = is_vf ? m->nF : m->nE;
-        for (int64_t i = 0; i < n; i++)
-            SCCD_REQUIRE(pairs[2 * i] >= 0 && pairs[2 * i] < na && pairs[2 * i + 1] >= 0 && pairs[2 * i + 1] < nb, "query_cull: pair index out of range");
-        DevBuf d_in, d_out, d_cnt;
-        d_in.ensure(sizeof(int2) * (size_t)n);
-        d_out.ensure(sizeof(int2) * (size_t)n);
-        d_cnt.ensure(16);
-        const unsigned long long h_cnt[2] = { (unsigned long long)n, 0ull }; // {pairs in, pairs kept}
-        copy_in(c, d_in.p, pairs, sizeof(int2) * (size_t)n, 0);
-        copy_in(c, d_cnt.p, h_cnt, sizeof h_cnt, 0);
-        NarrowParams p {};
-        p.V = m->V.as<double>();
-        p.E = m->E.as<int2>();
-        p.F = m->F.as<int4>();
-        p.pairs = d_in.as<int2>();
-        p.is_vf = is_vf;
-        p.ms = ms;
-        p.tol = tol;
-        narrow_cull_launch(c, p, d_cnt.as<unsigned long long>(), (long long)n, d_out.as<int2>(), d_cnt.as<unsigned long long>() + 1);
-        unsigned long long k = 0;
-        SCCD_HIP(hipMemcpyAsync(&k, d_cnt.as<unsigned long long>() + 1, sizeof k, hipMemcpyDeviceToHost, c->stream));
-        SCCD_HIP(hipStreamSynchronize(c->stream));
-        SCCD_REQUIRE((int64_t)k <= n, "query_cull: kept more than it was given");
-        if (k) SCCD_HIP(hipMemcpy(kept, d_out.p, sizeof(int2) * (size_t)k, hipMemcpyDeviceToHost));
-        *n_kept = (int64_t)k;
-    });
+    return guarded(c, [&] { query_cull(c, m, pairs, n, is_vf, ms, tol, 0.0, 1.0, kept, n_kept); });
+}
+
+extern "C" int sccd_query_cull_slab(sccd_ctx* c, const sccd_mesh* m, const int32_t* pairs, int64_t n, int is_vf, double ms, double tol,
+                                    double t_lo, double t_hi, int32_t* kept, int64_t* n_kept)
+{
+    if (!c || !m || !n_kept) return SCCD_E_INVALID;
+    *n_kept = 0;
+    return guarded(c, [&] { query_cull(c, m, pairs, n, is_vf, ms, tol, t_lo, t_hi, kept, n_kept); });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -226,7 +308,7 @@ static void ccd_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, sccd_broad_p
                      double tol, int allow_zero_toi, double* toi, sccd_stats* st, bool built = false, bool swept = false,
                      std::function<void()>* before_narrow = nullptr)
 {
-    if (!swept) pass_cull_setup(c, bp, m, vf, ms, max_iter, tol); // (a sweep that is enqueued already was set up by its caller)
+    if (!swept) pass_cull_setup(c, bp, m, vf, ms, max_iter, tol, *toi); // (a sweep that is enqueued already was set up by its caller)
     if (built) {} // (ccd() had the lists built already, by the helper)
     else if (vf) bp_build(bp, &pl->vb, &pl->fb);
     else bp_build(bp, &pl->eb, nullptr);
@@ -238,14 +320,15 @@ static void ccd_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, sccd_broad_p
             const NarrowParams p0 = narrow_params(c, m, nullptr, 0, vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi);
             narrow_counters_upload(c, narrow_counters(c), narrow_start_toi(c, p0, *toi, false));
         }
+        if (!started && bp->cull.on) // (every chunk's cull looks at what is left of the step)
+            bp->cull.slabs = narrow_cull_slabs(c, narrow_params(c, m, nullptr, 0, vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi), *toi);
         bp_detect_partial(bp, started ? 2 : 0);
         started = false;
         if (before_narrow && *before_narrow) {
             (*before_narrow)();
             *before_narrow = nullptr; // once
         }
-        const NarrowResult r = run_narrow(c, m, pass_pairs(bp), pass_count(bp), vf ? 1 : 0, max_iter, tol, ms,
-                                          allow_zero_toi, toi, nullptr);
+        const NarrowResult r = run_narrow_pass(c, m, bp, vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi, toi);
         if (st) {
             (vf ? st->n_vf_pairs : st->n_ee_pairs) += bp->n_overlaps;
             (vf ? st->n_vf_culled : st->n_ee_culled) += bp->n_overlaps - pass_count(bp);
@@ -297,8 +380,9 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
                 // both pair lists are still on the device, each swept in one chunk: only the narrow phases again (ccd.cu:125-143)
                 Pipeline* const pl = pipeline_of(c);
                 toi = 1.0;
-                const NarrowResult rv = run_narrow(c, m, pass_pairs(&pl->bp), pass_count(&pl->bp), 1, max_iter, tol, ms, allow_zero_toi, &toi, nullptr);
-                const NarrowResult re = run_narrow(c, m, pass_pairs(&pl->bp_ee), pass_count(&pl->bp_ee), 0, max_iter, tol, ms, allow_zero_toi, &toi, nullptr);
+                // (the culls looked at the step up to the bound: run_narrow_pass makes the lists again for what the pass now starts from)
+                const NarrowResult rv = run_narrow_pass(c, m, &pl->bp, 1, max_iter, tol, ms, allow_zero_toi, &toi);
+                const NarrowResult re = run_narrow_pass(c, m, &pl->bp_ee, 0, max_iter, tol, ms, allow_zero_toi, &toi);
                 if (st) {
                     st->n_vf_checks += (int64_t)rv.n_checks;
                     st->n_ee_checks += (int64_t)re.n_checks;
@@ -337,25 +421,28 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
     }
     // (a rank of a multi-GPU job builds the edge and face boxes of its window of cells only: see boxes_from_mesh)
     const bool lazy_ef = c->shard_count > 1 && c->sort_axis >= 0 && c->max_overlap_cutoff == 0 && !c->build_scan;
-    boxes_from_mesh(c, m, ms, pl, true, true, true, lazy_ef); // inflation radius = min_distance (ccd.cu:112)
+    const bool overlap_env = lab_env().overlap;
+    const bool with_helper = overlap_env && !c->passes_apart && m->nE > 0;
+    if (with_helper && !c->side) {
+        if (sccd_create(c->device, &c->side) != SCCD_OK) throw SccdError { SCCD_E_NOMEM, "ccd: cannot create the helper context" };
+        SCCD_HIP(hipEventCreateWithFlags(&c->side_event, hipEventDisableTiming));
+        SCCD_HIP(hipEventCreateWithFlags(&c->side_event2, hipEventDisableTiming));
+        SCCD_HIP(hipEventCreateWithFlags(&c->side_event3, hipEventDisableTiming));
+        pl->bp_ee.ctx = c->side;
+        // (the helper's stream with the lowest / highest queue priority was measured in round 3: no effect)
+    }
+    // (with the helper: the edge boxes are its stream's first kernel, beside the face boxes on this one -- boxes_from_mesh)
+    const bool split_boxes = with_helper && !lazy_ef && lab_env().split_boxes;
+    boxes_from_mesh(c, m, ms, pl, true, true, true, lazy_ef, split_boxes ? c->side_event : nullptr); // inflation radius = min_distance (ccd.cu:112)
     double toi = toi0; // ccd.cu:125 starts from 1; ccd_on_mesh may hand a bound over
     // The edge-edge lists do not depend on the vertex-face pass: a helper context (own stream, scratch, pinned mirror)
     // builds them on a worker thread meanwhile.  Both builds are chains of short, latency-bound kernels with host
     // round trips in between, so two of them interleave almost for free (2.23 instead of 2.34 ms per step on the
     // 1M-triangle cloth; 1.99 instead of 2.11 with the round-2 kernels).  On by default since the whole GPU suite
     // and the soak run with it; SCCD_OVERLAP=0 keeps the passes apart.
-    const bool overlap_env = lab_env().overlap;
     bool helper = false, presweep_done = false;
     const bool presweep_env = lab_env().presweep;
-    if (overlap_env && !c->passes_apart && m->nE > 0) {
-        if (!c->side) {
-            if (sccd_create(c->device, &c->side) != SCCD_OK) throw SccdError { SCCD_E_NOMEM, "ccd: cannot create the helper context" };
-            SCCD_HIP(hipEventCreateWithFlags(&c->side_event, hipEventDisableTiming));
-            SCCD_HIP(hipEventCreateWithFlags(&c->side_event2, hipEventDisableTiming));
-            SCCD_HIP(hipEventCreateWithFlags(&c->side_event3, hipEventDisableTiming));
-            pl->bp_ee.ctx = c->side;
-            // (the helper's stream with the lowest / highest queue priority was measured in round 3: no effect)
-        }
+    if (with_helper) {
         sccd_ctx* const sc = c->side;
         sc->sort_axis = c->sort_axis;
         sc->sweep_algo = c->sweep_algo;
@@ -367,7 +454,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
         sc->max_overlap_cutoff = c->max_overlap_cutoff;
         sc->memory_limit_mb = c->memory_limit_mb;
         sc->profile = c->profile;
-        SCCD_HIP(hipEventRecord(c->side_event, c->stream)); // the boxes are complete behind this point
+        if (!split_boxes) SCCD_HIP(hipEventRecord(c->side_event, c->stream)); // the boxes are complete behind this point
         const int device = c->device;
         hipEvent_t const ev = c->side_event;
         sccd_broad_phase* const bp_ee = &pl->bp_ee;
@@ -380,6 +467,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
         pl->worker.submit([=] {
             SCCD_HIP(hipSetDevice(device));
             SCCD_HIP(hipStreamWaitEvent(sc->stream, ev, 0));
+            if (split_boxes) edge_boxes_on(sc, m, pl);
             sc->np_init_pending = true; // (the build's grid kernel starts the counters of the edge-edge narrow launch too)
             sc->np_init_toi = toi_start;
             bp_build(bp_ee, eb, nullptr);
@@ -409,7 +497,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
             c->side->cull_on = c->cull_on;
             c->side->scalar_f32 = c->scalar_f32;
             c->side->narrow_algo = c->narrow_algo;
-            pass_cull_setup(c->side, &pl->bp_ee, m, false, ms, max_iter, tol);
+            pass_cull_setup(c->side, &pl->bp_ee, m, false, ms, max_iter, tol, toi);
             try {
                 bp_detect_partial(&pl->bp_ee, 1);
             } catch (...) {
@@ -438,7 +526,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
             sc->limit_level_order = c->limit_level_order;
             c->np_init_pending = true; // (the counters of the vertex-face narrow launch: started by the build's grid kernel)
             c->np_init_toi = narrow_start_toi(c, narrow_params(c, m, nullptr, 0, 1, max_iter, tol, ms, allow_zero_toi), toi, false);
-            pass_cull_setup(c, &pl->bp, m, true, ms, max_iter, tol);
+            pass_cull_setup(c, &pl->bp, m, true, ms, max_iter, tol, toi);
             bp_build(&pl->bp, &pl->vb, &pl->fb);
             c->np_init_pending = false;
             // the vertex-face sweep is enqueued, the edge-edge sweep behind it (on the helper's stream, by an event), and only
@@ -460,7 +548,8 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
             start_ee_sweep = nullptr;
             bp_detect_partial(&pl->bp, 2);
             const bool vf_one_chunk = pl->bp.cursor >= pl->bp.total_rows;
-            const NarrowParams pv = narrow_params(c, m, pass_pairs(&pl->bp), pass_count(&pl->bp), 1, max_iter, tol, ms, allow_zero_toi);
+            NarrowParams pv = narrow_params(c, m, nullptr, 0, 1, max_iter, tol, ms, allow_zero_toi);
+            pass_lists(&pl->bp, &pv);
             if (vf_one_chunk && narrow_uses_walk_kernel(c, pv, false)) {
                 double toi_vf = toi, toi_ee = toi;
                 if (lab_env().narrow_order) SCCD_HIP(hipStreamWaitEvent(c->stream, c->side_event2, 0)); // (start_ee_sweep)
@@ -472,7 +561,8 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
                 // kernel (same stream): if the first attempt did not stand after all (the pair buffer overflowed, the
                 // speculative build's guess broke), the kernel has run on a prefix of the true list or on nothing -- whatever it
                 // put into the running TOI is an accepted domain of a true pair -- and the pass is done again as before.
-                NarrowParams pe = narrow_params(sc, m, pass_pairs(&pl->bp_ee), 0, 0, max_iter, tol, ms, allow_zero_toi);
+                NarrowParams pe = narrow_params(sc, m, nullptr, 0, 0, max_iter, tol, ms, allow_zero_toi);
+                pass_lists(&pl->bp_ee, &pe); // (the buffers; the counts are on the device)
                 // (the two kernels share ONE running TOI -- unless a pass runs its two halves of time: its word then holds the bound
                 // 0.5 for a while, which the other pass must not prune by; each keeps its own word, the minimum is taken below)
                 if (narrow_start_toi(c, pv, toi_vf, false) == toi_vf && narrow_start_toi(sc, pe, toi_ee, false) == toi_ee)
@@ -505,8 +595,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
                 pl->bp_ee.rb_ctx = nullptr;
                 const bool early_stands = early && pl->bp_ee.sweeps_in_call == 1;
                 if (pl->bp_ee.cursor >= pl->bp_ee.total_rows) {
-                    pe.pairs = pass_pairs(&pl->bp_ee);
-                    pe.n_pairs = pass_count(&pl->bp_ee);
+                    pass_lists(&pl->bp_ee, &pe);
                     c->np_peer_stream = sc->stream; // (the helper's counters were started by its build: narrow_phase_begin uploads only if not)
                     try {
                         if (!early_stands) narrow_phase_begin(sc, pe, narrow_counters(sc), &toi_ee, nullptr);
@@ -543,8 +632,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
                         st->n_vf_candidates = pl->bp.candidates;
                     }
                     // the first edge-edge chunk is swept already: its narrow phase, then the rest of the loop
-                    const NarrowResult re = run_narrow(c, m, pass_pairs(&pl->bp_ee), pass_count(&pl->bp_ee), 0, max_iter, tol, ms,
-                                                       allow_zero_toi, &toi, nullptr);
+                    const NarrowResult re = run_narrow_pass(c, m, &pl->bp_ee, 0, max_iter, tol, ms, allow_zero_toi, &toi);
                     if (st) {
                         st->n_ee_pairs += pl->bp_ee.n_overlaps;
                         st->n_ee_culled += pl->bp_ee.n_overlaps - pass_count(&pl->bp_ee);
@@ -553,8 +641,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
                     presweep_done = false; // (consumed)
                 }
             } else { // not this time: the vertex-face pass as usual (its lists are built and its first chunk swept)
-                const NarrowResult rv = run_narrow(c, m, pass_pairs(&pl->bp), pass_count(&pl->bp), 1, max_iter, tol, ms,
-                                                   allow_zero_toi, &toi, nullptr);
+                const NarrowResult rv = run_narrow_pass(c, m, &pl->bp, 1, max_iter, tol, ms, allow_zero_toi, &toi);
                 if (st) {
                     st->n_vf_pairs += pl->bp.n_overlaps;
                     st->n_vf_culled += pl->bp.n_overlaps - pass_count(&pl->bp);

@@ -73,6 +73,12 @@ struct SweepRecs {
 inline SweepRecs sweep_recs(const SortedList* L) { return SweepRecs { L->recs.as<uint4>(), L->pstride }; }
 constexpr size_t SCCD_LIST_PAD = 64; // entries allocated past the last one: the sweep stages whole 32-column segments
 
+// The slabs of the step a pass's projection cull is run for (narrow_cull.inc, "slabs of time"): [0, t_end], or -- for the two launches
+// of the walk kernel's "two halves of time" -- [0, t_mid] behind the sweep and [t_mid, t_end] between the two launches.
+struct CullSlabs {
+    bool two = false;
+    double t_mid = 0.5, t_end = 1.0;
+};
 struct sccd_broad_phase {
     sccd_ctx* ctx = nullptr;
     const sccd_boxes* A = nullptr;
@@ -107,6 +113,7 @@ struct sccd_broad_phase {
         const sccd_mesh* mesh = nullptr;
         int is_vf = 0;
         double ms = 0, tol = 0;
+        CullSlabs slabs; // what the lists are good for: narrow launches that start at or below slabs.t_end
     } cull;
     // called ONCE, between the launch of the next sweep and the launch of its cull (bp_detect_partial): ccd() puts the event that
     // releases the OTHER pass's sweep there -- that sweep waits for this one, not for this one's cull
@@ -117,7 +124,8 @@ struct sccd_broad_phase {
     // object's stream already, and a read-back queued behind that kernel would come at the very end of the step.  Used once.
     sccd_ctx* rb_ctx = nullptr;
     hipEvent_t rb_after = nullptr;
-    DevBuf kept;         // int2[capacity]
+    DevBuf kept, kept_b; // int2[capacity]: the cull's list; kept_b: the list of the second half of time (cull.slabs.two), made on
+                         // the device only when that half is asked for at all (run_walk) -- its length stays there
     int64_t n_kept = 0;
     bool one_class = false;                // a two-list build whose sweep runs list B's rows only (api.hip bp_build)
     bool speculative = false;              // la.m / lb.m are BOUNDS until bp_detect_partial has checked the guess
@@ -202,7 +210,8 @@ struct SweepCounters { // lives in device memory (ctx->scalars)
     unsigned long long cand_parts[32]; // candidate columns tested (key range on the sort axis), summed over the rows; spread to avoid one hot word
     unsigned long long diag[4];        // SCCD_SWEEP_DIAG=1: filter blocks, filter groups of 8 steps, confirm rounds, segments staged (summed over waves)
     unsigned long long n_kept;         // ccd(): pairs the projection cull behind this sweep kept (narrow_cull.inc); cleared with the rest
-    unsigned long long pad2[24];       // 512 bytes: hipMemsetAsync clears an aligned size with ONE fill kernel (280 B took two)
+    unsigned long long n_kept_b;       // ... and the cull for the second half of the pass's time, if that ran (run_walk)
+    unsigned long long pad2[23];       // 512 bytes: hipMemsetAsync clears an aligned size with ONE fill kernel (280 B took two)
 };
 static_assert(sizeof(SweepCounters) == 512, "SweepCounters: keep the size a multiple of 256 bytes");
 // rows [row_begin, row_end) of `rows` against the columns of `cols` (rows == cols: one list)
@@ -229,6 +238,17 @@ struct NarrowParams {
     // the running TOI of this launch lives in ANOTHER launch's counters (ccd(): the edge-edge kernel starts beside the
     // vertex-face kernel and shares its word, so that each prunes with what the other finds); nullptr: its own
     unsigned long long* toi_word = nullptr;
+    // The SECOND launch of the two halves of time has a list of its own where the pass culls per slab of time (src != nullptr):
+    // made between the two launches, on the device, from the pass's whole overlap list -- and only if the first launch accepted
+    // nothing (np_cull_k's go word).  nullptr: the second launch walks the first one's list.
+    struct SecondHalf {
+        const int2* src = nullptr;                 // the pass's overlaps
+        const unsigned long long* d_n_src = nullptr; // ... how many (device)
+        long long capacity = 0;                    // ... at most (the buffers' size)
+        int2* kept = nullptr;                      // the list to make
+        unsigned long long* d_n_kept = nullptr;    // ... its length (device; 0 at launch)
+        double t_lo = 0.5, t_hi = 1.0;
+    } second;
 };
 struct NarrowCounters;
 void narrow_counters_upload(sccd_ctx* c, NarrowCounters* d_cnt, double toi);
@@ -282,7 +302,9 @@ double narrow_start_toi(const sccd_ctx* c, const NarrowParams& p, double toi, bo
 // the projection cull (narrow_cull.inc): pairs[0 .. min(*d_n_pairs, capacity)) -> the pairs that may have an impact, compacted
 // into d_kept[0 .. *d_n_kept) (any order; *d_n_kept must be 0); on c->stream.  Only p's mesh pointers, pairs, is_vf, ms, tol are used.
 void narrow_cull_launch(sccd_ctx* c, const NarrowParams& p, const unsigned long long* d_n_pairs, long long capacity, int2* d_kept,
-                        unsigned long long* d_n_kept);
+                        unsigned long long* d_n_kept, double t_lo = 0.0, double t_hi = 1.0, const unsigned* go = nullptr);
+// the slabs for a pass whose narrow launches start from `toi` at most (narrow_start_toi decides about the two halves)
+CullSlabs narrow_cull_slabs(const sccd_ctx* c, const NarrowParams& p, double toi);
 // ti_census.cpp (host): ONE query bisected alone in the reference's level order with the check limit
 double ti_census_level_order(const double v[8][3], int is_vf, int arith, double ms, double tol, int max_iter, int allow_zero_toi,
                              double toi_init, long long max_live, bool* gave_up);

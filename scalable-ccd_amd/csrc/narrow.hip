@@ -670,6 +670,16 @@ bool narrow_uses_walk_kernel(const sccd_ctx* c, const NarrowParams& p, bool per_
              || (p.max_iter >= 0 && (c->limit_level_order || (!per_query && p.max_iter < SCCD_QUEUE_MIN_MAX_ITER))));
 }
 
+CullSlabs narrow_cull_slabs(const sccd_ctx* c, const NarrowParams& p, double toi)
+{
+    CullSlabs sl;
+    sl.t_end = (toi > 0.0 && toi < 1.0) ? toi : 1.0; // (a start from 0 launches nothing: narrow_phase_begin)
+    sl.two = lab_env().cull_slabs && narrow_start_toi(c, p, toi, false) != toi; // (a list per half: exactly when the launches will be two)
+    sl.t_mid = 0.5;
+    if (!lab_env().cull_slabs) sl.t_end = 1.0; // (SCCD_CULL_SLABS=0: the whole step, one list -- round 5's first cull)
+    return sl;
+}
+
 double narrow_start_toi(const sccd_ctx* c, const NarrowParams& p, double toi, bool per_query)
 {
     // (exactly the launches narrow_phase_begin serves with the plain walk kernel; diagnostics builds count one launch)
@@ -708,6 +718,7 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
     }
     // (counters that were started from 0.5 for the two halves of time get their launches even for an empty list: the kernel
     // between the two puts the caller's TOI back)
+    SCCD_REQUIRE(!p.second.src || two_halves_from > 0.5 || start_toi <= 0.5, "narrow_phase: a list per half of time, but one launch over the whole step");
     if (run && (n > 0 || two_halves_from > 0.5)) {
         ProfScope ps(c, p.is_vf ? SCCD_PROF_NARROW_VF : SCCD_PROF_NARROW_EE);
         // A check limit (max_iter >= 0: the IPC Toolkit passes 10^7) is defined in the reference's LEVEL ORDER: it counts the

@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "sccd_ccd_mesh", "sccd_ccd_mesh_prepare", "sccd_ccd_mesh_pass", "sccd_ipc_ccd_strategy", "sccd_get_profile", "sccd_reset_profile", "sccd_sort_pairs_u32",
     "sccd_shard_bounds", "sccd_boxes_variance_axis", "sccd_selftest_lds_gather",
     "sccd_dev_alloc", "sccd_dev_free", "sccd_dev_upload", "sccd_dev_download", "sccd_dev_copy", "sccd_ccd_collisions",
-    "sccd_ccd_mesh_dev", "sccd_get_stream", "sccd_query_cull",
+    "sccd_ccd_mesh_dev", "sccd_get_stream", "sccd_query_cull", "sccd_query_cull_slab",
 ]
 
 
@@ -469,6 +469,18 @@ def query_cull(mesh, overlaps, is_vf, ms=0.0, tol=1e-6):
     k = C.c_int64()
     ctx._check(lib().sccd_query_cull(ctx._h, mesh._h, _ptr(ov), C.c_int64(len(ov)), C.c_int(int(is_vf)), C.c_double(ms), C.c_double(tol),
                                      _ptr(kept), C.byref(k)))
+    return kept[: k.value].copy()
+
+
+def query_cull_slab(mesh, overlaps, is_vf, ms=0.0, tol=1e-6, t_lo=0.0, t_hi=1.0):
+    """The projection cull for one slab of time (sccd_query_cull_slab): the pairs that may have an accepted domain meeting
+    t in [t_lo, t_hi] -- what a narrow launch asking about that part of the step has to look at."""
+    ctx = mesh.ctx
+    ov = np.ascontiguousarray(overlaps, dtype=np.int32).reshape(-1, 2)
+    kept = np.zeros_like(ov)
+    k = C.c_int64()
+    ctx._check(lib().sccd_query_cull_slab(ctx._h, mesh._h, _ptr(ov), C.c_int64(len(ov)), C.c_int(int(is_vf)), C.c_double(ms), C.c_double(tol),
+                                          C.c_double(t_lo), C.c_double(t_hi), _ptr(kept), C.byref(k)))
     return kept[: k.value].copy()
 
 

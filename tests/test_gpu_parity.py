@@ -790,7 +790,12 @@ def test_check_limit_that_no_query_reaches_runs_on_the_fast_kernel(sccd, ctx, or
     level-synchronous kernels regardless: the same answers."""
     V0, V1, E, F = _scene("cloth_ball_10k")
     mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
-    t_free, st_free = sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True, want_stats=True)
+    try:  # (a call with a limit keeps the reference's own list: the count to compare with is that of a call without the projection cull)
+        ctx.set_option(sccd.OPT_CULL, 0)
+        t_free, st_free = sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True, want_stats=True)
+    finally:
+        ctx.set_option(sccd.OPT_CULL, 1)
+    assert sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True) == t_free
     free_checks = st_free["n_vf_checks"] + st_free["n_ee_checks"]
     for limit in (4096, 10_000_000):
         t, st = sccd.ccd_mesh(mesh, 0.0, limit, 1e-6, True, want_stats=True)
@@ -1511,6 +1516,47 @@ def test_culled_queries_have_no_impact_in_the_oracle(sccd, ctx, orc, case):
             _, per_query, _ = orc.narrow_phase(V0, V1, E, F, culled, is_vf, ms=ms, allow_zero_toi=allow_zero, per_query=True, arith=arith)
             assert np.all(np.isinf(per_query)), (name, is_vf, allow_zero, arith, int(np.isfinite(per_query).sum()), len(culled))
     mesh.close()
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_slab_culls_drop_no_query_with_an_impact_in_their_slab(sccd, ctx, orc, case):
+    """The cull per slab of time (narrow_cull.inc, "slabs of time"; sccd_query_cull_slab): a pair that is dropped for [t_lo, t_hi] has
+    no earliest impact inside [t_lo, t_hi) in the oracle's per-query output -- the slabs ccd() uses ([0, 0.5] and [0.5, 1] for the
+    two launches of a start from 1, [0, b] and [0.5, b] for a start from a bound) and a few others.  And the whole step is the
+    slab (0, 1): the same list as sccd_query_cull's."""
+    name, V0, V1, E, F, ms = _cull_scenes()[case]
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F, ms)
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    key = lambda p: p[:, 0].astype(np.int64) << 32 | p[:, 1].astype(np.int64)  # noqa: E731
+    dropped_somewhere = 0
+    for is_vf, pairs in ((True, orc.sort_and_sweep(vb, fb, nthreads=8)[0]), (False, orc.sort_and_sweep(eb, nthreads=8)[0])):
+        pairs = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+        if len(pairs) == 0:
+            continue
+        ka = key(pairs)
+        whole = np.sort(key(sccd.query_cull(mesh, pairs, is_vf, ms, 1e-6)))
+        assert np.array_equal(np.sort(key(sccd.query_cull_slab(mesh, pairs, is_vf, ms, 1e-6, 0.0, 1.0))), whole), name
+        slabs = ((0.0, 0.5), (0.5, 1.0), (0.0, 0.3), (0.5, 0.77), (0.25, 0.75), (0.0, 1e-3), (0.999, 1.0))
+        gone = []
+        for t_lo, t_hi in slabs:
+            kk = np.sort(key(sccd.query_cull_slab(mesh, pairs, is_vf, ms, 1e-6, t_lo, t_hi)))
+            assert len(np.unique(kk)) == len(kk) and np.isin(kk, ka).all(), (name, t_lo, t_hi)
+            gone.append(~np.isin(ka, kk))
+        # (the oracle bisects the pairs that were dropped for some slab: the ones kept everywhere include the resting contacts, whose
+        # level-order bisection outgrows its memory budget on the shifted scene)
+        some = np.logical_or.reduce(gone)
+        dropped_somewhere += int(some.sum())
+        if not some.any():
+            continue
+        for az, ar in ((True, 1), (False, 1), (True, 0)):
+            pq = np.full(len(pairs), np.inf)
+            pq[some] = orc.narrow_phase(V0, V1, E, F, pairs[some], is_vf, ms=ms, allow_zero_toi=az, per_query=True, arith=ar)[1]
+            for (t_lo, t_hi), g in zip(slabs, gone):
+                bad = g & (pq >= t_lo) & (pq < t_hi)
+                assert not bad.any(), (name, is_vf, az, ar, t_lo, t_hi, int(bad.sum()), pq[bad][:4])
+    mesh.close()
+    if name in ("cloth_ball", "folded", "soup"):
+        assert dropped_somewhere > 0, name
 
 
 def test_float_build_is_bounded_on_a_query_that_explodes(sccd, ctx):
