@@ -750,7 +750,11 @@ __global__ __launch_bounds__(1024) void shard_window_k(const uint32_t* __restric
 // the column keys: two waves find its ends with 64 probes per round, every row then searches inside the window (a few
 // hundred keys in this CU's L1).  The sweep finds the END of a row's columns itself (the first key beyond K(max)).
 // own_tagged / other_tagged: this list's / the column list's keys carry the list tag of a merged sort (grid tag_bit).
-constexpr int ER_THREADS = 1024;
+#ifndef ER_THREADS_
+#define ER_THREADS_ 1024
+#endif
+constexpr int ER_THREADS = ER_THREADS_;
+constexpr int ER_WINDOW = ER_THREADS_ * 4; // column keys of a block's window staged in LDS (16 KB per 1024 threads)
 struct RecordArgs { // one list's share of a record launch
     const sccd_aabb* raw;
     const uint32_t *key, *idx;
@@ -762,7 +766,7 @@ struct RecordArgs { // one list's share of a record launch
     uint32_t pstride;
 };
 template <int MODE>
-__device__ __forceinline__ void entry_record_body(const RecordArgs& a, const GridParams* __restrict__ gp, unsigned* s_win, int block,
+__device__ __forceinline__ void entry_record_body(const RecordArgs& a, const GridParams* __restrict__ gp, unsigned* s_win, uint32_t* s_keys, int block,
                                                   uint32_t ext_q = 0xFFFFFFFFu)
 {
     const sccd_aabb* __restrict__ raw = a.raw;
@@ -778,6 +782,17 @@ __device__ __forceinline__ void entry_record_body(const RecordArgs& a, const Gri
     const uint32_t tag = g.tag_bit >= 0 ? (1u << g.tag_bit) : 0u;
     const uint32_t own_strip = own_tagged ? tag : 0u, other_or = other_tagged ? tag : 0u;
     const uint32_t k_e = valid ? (key[e] & ~own_strip) : 0u;
+    // the box is asked for FIRST: its two dependent loads (index, then the 64-byte record) are in flight while the block's window and
+    // the row's first column are searched for (behind the searches they were another ~3 us of every block's latency chain)
+    double4 q0 = make_double4(0.0, 0.0, 0.0, 0.0);
+    double2 q1 = make_double2(0.0, 0.0);
+    int4 ids = make_int4(0, 0, 0, 0);
+    if (valid) {
+        const sccd_aabb* src = raw + idx[e];
+        q0 = reinterpret_cast<const double4*>(src)[0];
+        q1 = reinterpret_cast<const double2*>(src)[2];
+        ids = reinterpret_cast<const int4*>(src)[3];
+    }
     uint32_t start = (uint32_t)e + 1u;
     if (MODE == 1 && ext_q == 0xFFFFFFFEu) {
         start = 0u; // (list A of a one-class sweep: its entries are columns only, no row of it is ever swept)
@@ -804,16 +819,18 @@ __device__ __forceinline__ void entry_record_body(const RecordArgs& a, const Gri
         }
         __syncthreads();
         const unsigned w0 = s_win[0], w1 = max(s_win[0], s_win[1]);
-        if (valid)
-            start = MODE == 1 ? lower_bound_in(other, w0, w1, k_e | other_or)
-                : one_class   ? lower_bound_in(other, w0, w1, back(k_e) | other_or)
-                              : upper_bound_in(other, w0, w1, k_e | other_or);
+        // the window's keys go through LDS when they fit (they do, by a wide margin, unless one list dwarfs the other): a row's
+        // binary search is then ~10 LDS reads instead of ~10 dependent trips to the vector cache
+        const uint32_t needle = (MODE == 1 || !one_class) ? (k_e | other_or) : (back(k_e) | other_or);
+        if (w1 - w0 <= (unsigned)ER_WINDOW) { // (block-uniform)
+            for (unsigned i = threadIdx.x; i < w1 - w0; i += blockDim.x) s_keys[i] = other[w0 + i];
+            __syncthreads();
+            if (valid) start = w0 + ((MODE == 1 || one_class) ? lower_bound_in(s_keys, 0u, w1 - w0, needle) : upper_bound_in(s_keys, 0u, w1 - w0, needle));
+        } else if (valid) {
+            start = (MODE == 1 || one_class) ? lower_bound_in(other, w0, w1, needle) : upper_bound_in(other, w0, w1, needle);
+        }
     }
     if (!valid) return;
-    const sccd_aabb* src = raw + idx[e];
-    const double4 q0 = reinterpret_cast<const double4*>(src)[0];
-    const double2 q1 = reinterpret_cast<const double2*>(src)[2];
-    const int4 ids = reinterpret_cast<const int4*>(src)[3];
     const double lo[3] = { q0.x, q0.y, q0.z };
     const double hi[3] = { q0.w, q1.x, q1.y };
     reinterpret_cast<double2*>(recs + (size_t)REC_X * pstride)[e] = make_double2(sel3d(lo, g.axis), sel3d(hi, g.axis));
@@ -832,13 +849,14 @@ __global__ __launch_bounds__(ER_THREADS) void entry_record_k(RecordArgs a, const
     // d_tot (may be null): the list's entry count in DEVICE memory -- a build whose records are made before the host knows
     // the count (api.hip: the speculative build) launches for the count it expects; the real one is taken from here
     __shared__ unsigned s_win[2];
+    __shared__ uint32_t s_keys[MODE != 0 ? ER_WINDOW : 1];
     if (d_tot) { // (a count beyond the bound the launch was sized for is a failed guess: nothing is done here, the host finds out)
         // (so is another key width than the sort was run for: the pairs are not in order then)
         if (d_tot[0] > (uint32_t)a.m || gp->key_bits != expect_bits) return;
         a.m = (int)d_tot[0];
     }
     if ((long long)blockIdx.x * ER_THREADS >= a.m) return;
-    entry_record_body<MODE>(a, gp, s_win, (int)blockIdx.x);
+    entry_record_body<MODE>(a, gp, s_win, s_keys, (int)blockIdx.x);
 }
 // both lists of a two-list build in ONE launch (the first blocks_a blocks: list A's rows; two launches in a row sat on the
 // critical path of every vertex-face pass)
@@ -847,6 +865,7 @@ __global__ __launch_bounds__(ER_THREADS) void entry_record2_k(RecordArgs a, Reco
                                                               const uint32_t* __restrict__ d_extq /* one-class sweep: list A's extent, or null */)
 {
     __shared__ unsigned s_win[2];
+    __shared__ uint32_t s_keys[ER_WINDOW];
     if (d_tot) { // device-side counts (entry_record_k): ONE merged, sorted array -- list A's pairs, then list B's
         if (d_tot[0] > (uint32_t)a.m || d_tot[1] > (uint32_t)b.m || gp->key_bits != expect_bits) return; // (a failed guess: entry_record_k)
         const int ma = (int)d_tot[0], mb = (int)d_tot[1];
@@ -859,8 +878,8 @@ __global__ __launch_bounds__(ER_THREADS) void entry_record2_k(RecordArgs a, Reco
         blocks_a = (ma + ER_THREADS - 1) / ER_THREADS;
         if ((int)blockIdx.x >= blocks_a + (mb + ER_THREADS - 1) / ER_THREADS) return;
     }
-    if ((int)blockIdx.x < blocks_a) entry_record_body<1>(a, gp, s_win, (int)blockIdx.x, d_extq ? 0xFFFFFFFEu : 0xFFFFFFFFu);
-    else entry_record_body<2>(b, gp, s_win, (int)blockIdx.x - blocks_a, d_extq ? min(*d_extq, 0xFFFFFFF0u) : 0xFFFFFFFFu);
+    if ((int)blockIdx.x < blocks_a) entry_record_body<1>(a, gp, s_win, s_keys, (int)blockIdx.x, d_extq ? 0xFFFFFFFEu : 0xFFFFFFFFu);
+    else entry_record_body<2>(b, gp, s_win, s_keys, (int)blockIdx.x - blocks_a, d_extq ? min(*d_extq, 0xFFFFFFF0u) : 0xFFFFFFFFu);
 }
 
 // sum and sum of squares of the box centres per axis (sort_and_sweep.cpp:176-186): per-block

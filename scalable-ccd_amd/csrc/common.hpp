@@ -116,6 +116,7 @@ struct LabEnv {
     bool sort_tickets = false;         // SCCD_SORT_TICKETS=1: sort tiles by atomic ticket even when every tile has its block
     long long level_budget_mb = 0;     // SCCD_LEVEL_BUDGET_MB: budget per level buffer of the level-synchronous narrow phase
     bool split_boxes = true;           // SCCD_SPLIT_BOXES=0: ccd()'s edge and face boxes in one launch on the caller's stream (round 4)
+    int np_waves = 3;                  // SCCD_NP_WAVES=1|2: the plain walk kernel's grid fills that many waves per SIMD at most (it is built for three)
     bool cull_slabs = true;            // SCCD_CULL_SLABS=0: the projection cull looks at the whole step whatever the launches ask (round 5's first cull)
     bool ee_early = true;              // SCCD_EE_EARLY=0: ccd()'s edge-edge walk kernel launched by the host once it has the pair count (round 4)
                                        // instead of right behind its sweep and cull with the count read on the device
@@ -139,6 +140,7 @@ struct LabEnv {
         spec_break_every = num("SCCD_SPEC_BREAK", 0);
         ee_early = num("SCCD_EE_EARLY", 1) != 0;
         cull_slabs = num("SCCD_CULL_SLABS", 1) != 0;
+        np_waves = (int)num("SCCD_NP_WAVES", 3);
         split_boxes = num("SCCD_SPLIT_BOXES", 1) != 0;
         const char* s = std::getenv("SCCD_SYNC");
         sync_block = s && std::string(s) == "block";
