@@ -199,6 +199,7 @@ int sccd_set_option(sccd_ctx* c, int opt, int64_t v)
     case SCCD_OPT_TOI_GUESS:
         c->toi_guess_on = v ? 1 : 0;
         c->toi_guess = 1.0; // (forget what was learnt)
+        c->toi_last = -1.0;
         break;
     case SCCD_OPT_TOI_GUESS_HITS:
     case SCCD_OPT_TOI_GUESS_MISSES: c->toi_guess_hits = c->toi_guess_misses = 0; break;

@@ -185,6 +185,8 @@ struct sccd_ctx {
     int toi_guess_n[3] = { 0, 0, 0 };
     int64_t toi_guess_hits = 0, toi_guess_misses = 0;
     int toi_guess_rest = 0, toi_guess_backoff = 4; // steps without a bound after a miss (doubling up to 64, halved by a hit)
+    double toi_last = -1.0;    // what the last ccd() on toi_guess_mesh returned (-1: nothing yet)
+    int two_halves_off = 0;    // this call only (ccd_on_mesh): the last call on the same mesh found nothing before 0.5 -- one launch per pass
     int two_halves = 1;        // SCCD_OPT_TWO_HALVES: a plain narrow launch from a TOI above 0.5 is two launches over the halves of time (narrow_walk.inc)
     int cull_on = 1;           // SCCD_OPT_CULL: ccd()'s passes drop the pairs that provably have no impact before the bisection (narrow_cull.inc)
     int cell_factor_milli = 0; // SCCD_OPT_CELL_FACTOR_MILLI: grid cell size in thousandths of the mean box extent (0: the default, 4000; < 0: one cell)

@@ -361,6 +361,15 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
         c->toi_guess_rest -= 1;
         spec = false;
     }
+    // THE TWO HALVES OF TIME ARE A BET (narrow_walk.inc): they pay when the earliest impact lies before 0.5 -- 0.85 instead of 0.95 ms
+    // on the 1M-triangle cloth -- and cost a second cull and a second launch per pass when it lies later or there is none (+ 20 %
+    // on a 500k-triangle cloth whose impact comes at 0.59).  What the LAST call on this mesh returned settles the bet for this one
+    // (same history, same switch as the bound: SCCD_OPT_TOI_GUESS); exact either way -- only the number of launches changes.
+    struct HalvesOff {
+        sccd_ctx* c;
+        ~HalvesOff() { c->two_halves_off = 0; }
+    } halves_off { c };
+    c->two_halves_off = (c->toi_guess_on && lab_env().speculate && same_mesh && c->toi_last >= 0.5) ? 1 : 0;
     double toi = 1.0;
     bool resident = false;
     // (the float build's kernels and run_narrow() round the TOI they start from to float: the bound must BE the value they start
@@ -395,6 +404,7 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
         ccd_on_mesh_from(c, m, ms, max_iter, tol, allow_zero_toi, 1.0, &toi, st, nullptr);
     }
     c->toi_guess = (toi < 1.0 && toi > 0.0) ? std::min(1.0, toi * 1.125) : 1.0; // (an eighth above: the pruning a bound buys comes in dyadic steps -- 1.25 x 0.408 = 0.51 keeps the later half of every first time split alive, 0.459 does not)
+    c->toi_last = toi;
     c->toi_guess_mesh = (const void*)m;
     c->toi_guess_n[0] = m->nV;
     c->toi_guess_n[1] = m->nE;
@@ -463,6 +473,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
         sc->scalar_f32 = c->scalar_f32;
         sc->narrow_algo = c->narrow_algo;
         sc->two_halves = c->two_halves;
+        sc->two_halves_off = c->two_halves_off;
         const double toi_start = narrow_start_toi(sc, narrow_params(sc, m, nullptr, 0, 0, max_iter, tol, ms, allow_zero_toi), toi, false);
         pl->worker.submit([=] {
             SCCD_HIP(hipSetDevice(device));

@@ -683,7 +683,7 @@ CullSlabs narrow_cull_slabs(const sccd_ctx* c, const NarrowParams& p, double toi
 double narrow_start_toi(const sccd_ctx* c, const NarrowParams& p, double toi, bool per_query)
 {
     // (exactly the launches narrow_phase_begin serves with the plain walk kernel; diagnostics builds count one launch)
-    const bool two = c->two_halves && !per_query && p.max_iter < 0 && !c->scalar_f32 && c->narrow_algo != 1 && lab_env().np_diag == 0 && toi > 0.5;
+    const bool two = c->two_halves && !c->two_halves_off && !per_query && p.max_iter < 0 && !c->scalar_f32 && c->narrow_algo != 1 && lab_env().np_diag == 0 && toi > 0.5;
     return two ? 0.5 : toi;
 }
 
