@@ -493,6 +493,24 @@ def main():
             ctx.set_option(sccd.OPT_SCALAR, 1)
             cliffs["float_build_step_ms"] = best(lambda: sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True), 2)
             ctx.set_option(sccd.OPT_SCALAR, 0)
+            # THE BET OF THE TWO HALVES OF TIME (csrc/narrow_walk.inc): the same mesh, the step cut short so that the earliest impact comes
+            # late (x 0.6: at 0.68) or not at all (x 0.3) -- without history (every call bets on an early impact), with one launch per
+            # pass (SCCD_OPT_TWO_HALVES = 0), and with history (the library's default: the last call on the mesh settles the bet)
+            g_was, h_was = ctx.get_option(sccd.OPT_TOI_GUESS), ctx.get_option(sccd.OPT_TWO_HALVES)
+            late = {}
+            for tag, scale in (("impact_at_0.68", 0.6), ("no_impact", 0.3)):
+                m2 = sccd.Mesh(V0, V0 + scale * (V1 - V0), E, F, ctx=ctx)
+                row = {}
+                for name, gh, hv in (("two_halves_no_history_ms", 0, 1), ("one_launch_no_history_ms", 0, 0), ("with_history_ms", 1, 1)):  # (1: the defaults)
+                    ctx.set_option(sccd.OPT_TOI_GUESS, gh)
+                    ctx.set_option(sccd.OPT_TWO_HALVES, hv)
+                    row[name] = best(lambda: sccd.ccd_mesh(m2, 0.0, -1, 1e-6, True), 5)
+                row["toi"] = sccd.ccd_mesh(m2, 0.0, -1, 1e-6, True)
+                late[tag] = row
+                m2.close()
+            ctx.set_option(sccd.OPT_TOI_GUESS, g_was)
+            ctx.set_option(sccd.OPT_TWO_HALVES, h_was)
+            cliffs["late_impact"] = late
             cliffs["note"] = ("host_path: sccd_ccd() from pageable host matrices (upload inside the call), collisions = the SCALABLE_CCD_TOI_PER_QUERY signature; "
                               "step: sccd_ccd_mesh() on the resident mesh; best of 3 / 5 / 2")
         result = {
@@ -504,6 +522,10 @@ def main():
                            parallelism=f"cell windows sharded over {world} GPU(s), one RCCL all-reduce(min) of the TOI per step",
                            rccl_ranks=rccl_ranks, backend=(backend if use_dist else "none"),
                            projection_cull=int(ctx.get_option(sccd.OPT_CULL)), two_halves_of_time=int(ctx.get_option(sccd.OPT_TWO_HALVES)), culled_per_step=int(stats.get("n_vf_culled", 0) + stats.get("n_ee_culled", 0)),
+                           history=0,
+                           history_note="value / ms_per_step: SCCD_OPT_TOI_GUESS = 0 -- no call uses anything of the call before it (neither the TOI bound nor the choice "
+                                        "between one and two narrow launches per pass: with history off every call runs the two halves of time, a bet on an impact before 0.5 -- "
+                                        "`--cliffs` late_impact prices the bet where it is lost)",
                            culled_note="overlap pairs the projection cull (csrc/narrow_cull.inc) dropped before the bisection: provably no impact; they count as answered queries"),
             # schema 2 (round 4): min_toi_latency_ms is ONE thing again -- the step's latency on a device-resident mesh, = ms_per_step,
             # as in rounds 1-2 and for any number of ranks; the reference-shaped call from host matrices is host_path_ms only
@@ -521,8 +543,9 @@ def main():
             "max_iter": args.max_iter,
             "broad_phase": broad,
             "toi_guess": dict(guess, ms_per_step_without=round(dt / args.steps * 1e3, 4),
-                              note="speculative TOI bound (SCCD_OPT_TOI_GUESS = 1, the library's default; OFF in value / ms_per_step): a step starts from "
-                                   "1.125 x the previous step's TOI on the same mesh and is redone from 1 if nothing is found below the bound (exact "
+                              note="history (SCCD_OPT_TOI_GUESS = 1, the library's default; OFF in value / ms_per_step): a step starts from "
+                                   "1.125 x the previous step's TOI on the same mesh and is redone from 1 if nothing is found below the bound, and it runs one narrow "
+                                   "launch per pass instead of two when the previous step found nothing before 0.5 (exact "
                                    "either way).  On this FROZEN mesh every bound is the step's own previous answer: ms_per_step_with is an upper bound "
                                    "on what the prior can buy, not a headline; `--jitter` lines show it on a mesh that moves"),
             "cliffs": cliffs,

@@ -106,7 +106,7 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
 #define SCCD_OPT_BUILD_SCAN 18        /* 1: entries by count -> device-wide scan -> fill, in box order (reproducible entry order; was SCCD_BUILD=scan) */
 #define SCCD_OPT_TOI_GUESS 19         /* 1 (default): sccd_ccd_mesh / sccd_ccd on a mesh whose previous call found an impact at T start from the bound
                                        * min(1, 1.125 T) instead of 1 and verify (a result below the bound is exact; a result at the bound: the step is
-                                       * redone from 1); 0: always from 1, as ccd.cu:125 */
+                                       * redone from 1); 0: always from 1, as ccd.cu:125.  The same history also settles SCCD_OPT_TWO_HALVES' bet. */
 #define SCCD_OPT_TOI_GUESS_HITS 20    /* read: calls whose bound held / broke (redone); setting either resets both */
 #define SCCD_OPT_TOI_GUESS_MISSES 21
 #define SCCD_OPT_CULL 24              /* sccd_ccd / sccd_ccd_mesh / sccd_ccd_mesh_pass (double build, no check limit): 1 (default) the overlap pairs of a pass
@@ -114,12 +114,19 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        * corner values of d . F (F: the collision function, affine in each of t, u, v) all beyond the reach of any
                                        * domain the reference's bisection could accept (csrc/narrow_cull.inc): the result is unchanged, the narrow
                                        * phase bisects a fraction of the pairs; 0: every pair is bisected, as root_finder.cu:372-457 does.
+                                       * The cull looks at the slab of time the pass's narrow launch asks about ([0, b] for a start from b; the halves
+                                       * of SCCD_OPT_TWO_HALVES each have their own).  1 means "where it pays": meshes of 50,000 edges + faces or more (a
+                                       * launch per sweep costs a small step more than it saves); 2: always.
                                        * sccd_narrow_phase and the collision-list / per-query drivers never cull. */
 #define SCCD_OPT_TWO_HALVES 25        /* 1 (default): a narrow-phase launch of the plain walk kernel (double build, no check limit, no per-query output) that
                                        * starts from a TOI above 0.5 runs as two launches over the halves of time: the first from the bound 0.5; if it
                                        * accepts nothing, the second bisects what lies at or beyond 0.5, from the caller's TOI (csrc/narrow_walk.inc).
                                        * The same accepted domains as one launch (root_finder.cu:277-370), hence the same result; a call whose earliest
-                                       * impact lies before 0.5 never explores the later halves of its first time splits.  0: one launch */
+                                       * impact lies before 0.5 never explores the later halves of its first time splits.  0: one launch.
+                                       * The two launches are a BET on an early impact: where the earliest impact lies at or beyond 0.5, or there is none, they
+                                       * cost a second cull and a second launch per pass (+ 10-20 %).  Under 1, sccd_ccd / sccd_ccd_mesh take the bet only
+                                       * for meshes of 600,000 edges + faces or more and -- with SCCD_OPT_TOI_GUESS on -- only if the last call on the
+                                       * same mesh did not return a TOI >= 0.5; 2: always. */
 #define SCCD_OPT_ALLOC_COUNT 23       /* read: device allocations the library's grow-only buffers have made since it was loaded (all contexts): a call
                                        * during which the count rises has grown a buffer -- hipFree + hipMalloc, milliseconds */
 #define SCCD_OPT_SPEC_HITS 15   /* read: speculative builds (sort, records and sweep enqueued for the previous build's entry counts) whose */

@@ -194,8 +194,8 @@ int sccd_set_option(sccd_ctx* c, int opt, int64_t v)
     case SCCD_OPT_PASSES_APART: c->passes_apart = v ? 1 : 0; break;
     case SCCD_OPT_CELL_FACTOR_MILLI: c->cell_factor_milli = (int)v; break;
     case SCCD_OPT_BUILD_SCAN: c->build_scan = v ? 1 : 0; break;
-    case SCCD_OPT_CULL: c->cull_on = v ? 1 : 0; break;
-    case SCCD_OPT_TWO_HALVES: c->two_halves = v ? 1 : 0; break;
+    case SCCD_OPT_CULL: c->cull_on = v < 0 ? 0 : (v > 2 ? 2 : (int)v); break; // 0 off, 1 where it pays (by mesh size), 2 always
+    case SCCD_OPT_TWO_HALVES: c->two_halves = v < 0 ? 0 : (v > 2 ? 2 : (int)v); break; // 0 off, 1 where it pays (mesh size, history), 2 always
     case SCCD_OPT_TOI_GUESS:
         c->toi_guess_on = v ? 1 : 0;
         c->toi_guess = 1.0; // (forget what was learnt)

@@ -42,7 +42,10 @@ static NarrowParams narrow_params(sccd_ctx* c, const sccd_mesh* m, const int2* d
                                   double tol, double ms, int allow_zero_toi);
 static void pass_cull_setup(sccd_ctx* c, sccd_broad_phase* bp, const sccd_mesh* m, bool vf, double ms, int max_iter, double tol, double toi)
 {
-    bp->cull.on = c->cull_on && !c->scalar_f32 && max_iter < 0 && c->narrow_algo != 1 && std::isfinite(tol) && tol > 0 && ms >= 0;
+    // (SCCD_OPT_CULL = 1: where it pays -- the cull is a launch per sweep, ~5 us of a small step's latency chain; measured on folded
+    // cloths and the cloth-on-ball scenes: a gain from ~20,000 triangles on, a loss of 15 us at 10,000.  2: always)
+    const bool big_enough = c->cull_on >= 2 || (long long)m->nE + m->nF >= SCCD_CULL_MIN_ELEMENTS;
+    bp->cull.on = c->cull_on && big_enough && !c->scalar_f32 && max_iter < 0 && c->narrow_algo != 1 && std::isfinite(tol) && tol > 0 && ms >= 0;
     bp->cull.mesh = m;
     bp->cull.is_vf = vf ? 1 : 0;
     bp->cull.ms = ms;
@@ -369,7 +372,11 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
         sccd_ctx* c;
         ~HalvesOff() { c->two_halves_off = 0; }
     } halves_off { c };
-    c->two_halves_off = (c->toi_guess_on && lab_env().speculate && same_mesh && c->toi_last >= 0.5) ? 1 : 0;
+    c->two_halves_off = (c->two_halves == 1 && c->toi_guess_on && lab_env().speculate && same_mesh && c->toi_last >= 0.5) ? 1 : 0;
+    // (... and the size of the mesh: the second launch, its cull and the kernel between them are ~25 us of launches in a row -- more
+    // than a small step's narrow phase has to give: 0.296 -> 0.323 ms on the 10k-triangle cloth-on-ball scene, 0.97 -> 0.86 on the
+    // 1M-triangle cloth.  SCCD_OPT_TWO_HALVES = 2: always)
+    if (c->two_halves == 1 && (long long)m->nE + m->nF < SCCD_TWO_HALVES_MIN_ELEMENTS) c->two_halves_off = 1;
     double toi = 1.0;
     bool resident = false;
     // (the float build's kernels and run_narrow() round the TOI they start from to float: the bound must BE the value they start

@@ -73,6 +73,9 @@ struct SweepRecs {
 inline SweepRecs sweep_recs(const SortedList* L) { return SweepRecs { L->recs.as<uint4>(), L->pstride }; }
 constexpr size_t SCCD_LIST_PAD = 64; // entries allocated past the last one: the sweep stages whole 32-column segments
 
+// ccd() on small meshes: the sizes (edges + faces) from which the projection cull and the two halves of time are used under their
+// default settings (drivers.hip: pass_cull_setup, ccd_on_mesh)
+constexpr long long SCCD_CULL_MIN_ELEMENTS = 50000, SCCD_TWO_HALVES_MIN_ELEMENTS = 600000;
 // The slabs of the step a pass's projection cull is run for (narrow_cull.inc, "slabs of time"): [0, t_end], or -- for the two launches
 // of the walk kernel's "two halves of time" -- [0, t_mid] behind the sweep and [t_mid, t_end] between the two launches.
 struct CullSlabs {

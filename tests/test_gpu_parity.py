@@ -1416,9 +1416,9 @@ def test_two_halves_of_time_change_no_result(sccd, orc, scene):
             mesh.update_vertices(V0, W1)
             for allow_zero in (True, False):
                 want = orc.ccd(V0, W1, E, F, 0.0, -1, 1e-6, allow_zero, nthreads=8)[0]
-                for cull in (1, 0):
+                for cull in (2, 0):  # (2: forced -- under the defaults, 1, meshes this small run neither the cull nor the two halves)
                     c.set_option(sccd.OPT_CULL, cull)
-                    c.set_option(sccd.OPT_TWO_HALVES, 1)
+                    c.set_option(sccd.OPT_TWO_HALVES, 2)
                     two = sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, allow_zero)
                     c.set_option(sccd.OPT_TWO_HALVES, 0)
                     one = sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, allow_zero)
@@ -1427,8 +1427,8 @@ def test_two_halves_of_time_change_no_result(sccd, orc, scene):
         if scene == "cloth_ball_small":  # (the soup collides at once whatever the scale, the small folded cloth never: covered, not counted)
             assert min(seen) < 0.5 and any(0.5 <= t < 1.0 for t in seen) and max(seen) == 1.0, seen  # either launch got to decide, and neither
         # the pass-by-pass API (a rank of a multi-GPU job) and a start from a caller's TOI between 0.5 and 1
-        c.set_option(sccd.OPT_CULL, 1)
-        c.set_option(sccd.OPT_TWO_HALVES, 1)
+        c.set_option(sccd.OPT_CULL, 2)
+        c.set_option(sccd.OPT_TWO_HALVES, 2)
         mesh.update_vertices(V0, V1)
         sccd.ccd_mesh_prepare(mesh, 0.0)
         want = orc.ccd(V0, V1, E, F, 0.0, -1, 1e-6, True, nthreads=8)[0]
@@ -1479,7 +1479,7 @@ def test_projection_cull_changes_no_result(sccd, orc, case):
         mesh = sccd.Mesh(V0, V1, E, F, ctx=c)
         for allow_zero in (True, False):
             want = orc.ccd(V0, V1, E, F, ms, -1, 1e-6, allow_zero, nthreads=8)[0]
-            c.set_option(sccd.OPT_CULL, 1)
+            c.set_option(sccd.OPT_CULL, 2)  # (forced: the default, 1, leaves meshes this small alone)
             got, st = sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero, want_stats=True)
             c.set_option(sccd.OPT_CULL, 0)
             plain, st0 = sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero, want_stats=True)

@@ -1,7 +1,7 @@
-# Refresh profiles/ for the CURRENT build (run on the GPU box): bash tools/collect_profiles.sh [round tag, default r04]
+# Refresh profiles/ for the CURRENT build (run on the GPU box): bash tools/collect_profiles.sh [round tag, default r05]
 # Everything lands in gpurun_out/prof/; copy what is to be kept into profiles/ afterwards (the PMC traffic files carry
 # the hash of the library they were taken on: bench.py quotes them only for that very build).
-R=${1:-r04}
+R=${1:-r05}
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
@@ -31,6 +31,17 @@ for W in cloth1m boxes1m sort16m clothball10k; do
 done
 SCCD_OVERLAP=0 timeout 600 python3 bench.py --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_passes_apart.json.log
 timeout 600 python3 bench.py --no-cpu-baseline --max-iter 10000000 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_max_iter_1e7.json.log
+# every round: the strict contract, the step without the cull / with one narrow launch per pass, the cliffs, a mesh that moves
+timeout 600 python3 bench.py --no-cpu-baseline --arith 0 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_strict.json.log
+timeout 600 python3 bench.py --no-cpu-baseline --cull 0 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_no_cull.json.log
+timeout 600 python3 bench.py --no-cpu-baseline --two-halves 0 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_one_launch_per_pass.json.log
+timeout 900 python3 bench.py --no-cpu-baseline --cliffs 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_cliffs.json.log
+for J in 1e-4 1e-3 3e-3; do
+  timeout 900 python3 bench.py --no-cpu-baseline --jitter $J --steps 1000 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_jitter_$J.json.log
+done
+timeout 900 python3 bench.py --no-cpu-baseline --jitter 1e-3 --jitter-alternate 0.05 --steps 1000 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_jitter_alternating.json.log
+# the driver's command five times, then its 100-step line
+bash tools/jobs/r05_bench5.sh prof/${R}_driver_shaped > gpurun_out/prof/${R}_driver_shaped_lines.txt 2>&1
 timeout 600 python3 bench.py --workload boxes1m --boxes-variant thin 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_boxes1m_thin.json.log
 timeout 600 python3 bench.py --workload boxes1m --boxes-n 16000000 --steps 10 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_boxes16m.json.log
 # SURVEY 8d's other C3 shapes: kernel stats and HBM traffic

@@ -115,6 +115,10 @@ def main():
             ctx.set_option(sccd.OPT_ARITH, arith)
             ctx.set_option(sccd.OPT_SWEEP_ALGO, sweep_algo)
             ctx.set_option(sccd.OPT_NARROW_ALGO, narrow_algo)
+            # (the scenes are small: under the defaults (1) ccd() would run neither the projection cull nor the two halves of time on
+            # them -- three seeds in four force them (2), one in four takes the defaults)
+            ctx.set_option(sccd.OPT_CULL, 1 if seed % 4 == 3 else 2)
+            ctx.set_option(sccd.OPT_TWO_HALVES, 1 if seed % 4 == 3 else 2)
             mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
             dv, de, df = sccd.DeviceAABBs.from_mesh(mesh, ms)
             got_vf, got_ee, tois = [], [], []
@@ -169,6 +173,8 @@ def main():
             ctx.set_option(sccd.OPT_ARITH, sccd.ARITH_DEFAULT)
             ctx.set_option(sccd.OPT_SWEEP_ALGO, 0)
             ctx.set_option(sccd.OPT_NARROW_ALGO, 0)
+            ctx.set_option(sccd.OPT_CULL, 1)
+            ctx.set_option(sccd.OPT_TWO_HALVES, 1)
         if not ok:
             bad += 1
             print("MISMATCH", tag, "toi", min(tois) if tois else None, "want", want, "vf", sum(map(len, got_vf)), len(want_vf), "ee",
