@@ -362,9 +362,11 @@ def main():
         n_boxes = len(V0) + len(F) + len(E)
         q_vf, q_ee = stats["n_vf_pairs"], stats["n_ee_pairs"]  # this rank's queries per step
         c_vf, c_ee = stats["n_vf_checks"], stats["n_ee_checks"]  # ... and inclusion checks (last step)
+        # (the walk kernels see what the projection cull left of a pass's queries; the cull sees them all)
+        k_vf, k_ee = q_vf - stats.get("n_vf_culled", 0), q_ee - stats.get("n_ee_culled", 0)
         units = {  # class -> (algorithmic bytes per step, kernel name, name in the rocprofv3 summaries)
-            "narrow_ee": (BYTES_PER_QUERY * q_ee, "np_walk_k<false> (edge-edge Tight-Inclusion)", "np_walk_k<false, %d, 0>" % args.arith),
-            "narrow_vf": (BYTES_PER_QUERY * q_vf, "np_walk_k<true> (vertex-face Tight-Inclusion)", "np_walk_k<true, %d, 0>" % args.arith),
+            "narrow_ee": (BYTES_PER_QUERY * k_ee, "np_walk_k<false> (edge-edge Tight-Inclusion)", "np_walk_k<false, %d, 0>" % args.arith),
+            "narrow_vf": (BYTES_PER_QUERY * k_vf, "np_walk_k<true> (vertex-face Tight-Inclusion)", "np_walk_k<true, %d, 0>" % args.arith),
             "sweep": (BYTES_SWEEP_PER_BOX * n_boxes + 8.0 * (q_vf + q_ee), "sweep_band_k / sweep_band2_k (2 launches per step)", "sweep_band_k"),
             "sort": (BYTES_SORT_PER_KEY_PASS * 4 * n_boxes, "onesweep radix sort + scans", "os_pass_k"),
             "boxes": (124.0 * n_boxes, "box build, cell fill, sorted records", "entry_record_k"),
@@ -378,7 +380,8 @@ def main():
         # THIS build of the library: the JSON carries the hash of the libsccd_hip.so it profiled
         traffic, traffic_note = None, "no PMC profile of this workload"
         try:
-            if args.workload == "cloth1m" and args.cloth_n == 708 and world == 1 and os.path.exists(os.path.join(ROOT, "profiles", "r05_pmc_traffic_cloth1m.json")):
+            defaults = args.cull is None and args.two_halves is None and args.max_iter < 0 and args.jitter == 0.0  # (the profile is of the default step)
+            if defaults and args.workload == "cloth1m" and args.cloth_n == 708 and world == 1 and os.path.exists(os.path.join(ROOT, "profiles", "r05_pmc_traffic_cloth1m.json")):
                 tj = _pmc_file("r05_pmc_traffic_cloth1m.json")
                 if tj:
                     traffic = tj["kernels"][units[dom][2]]["hbm_bytes_per_launch_corrected"]
@@ -406,6 +409,11 @@ def main():
                 "executed_flop_per_check": FLOP_PER_CHECK_EXECUTED,
                 "executed_tflops": round(achieved * FLOP_PER_CHECK_EXECUTED / FLOP_PER_CHECK, 3),
                 "executed_frac": round(achieved * FLOP_PER_CHECK_EXECUTED / FLOP_PER_CHECK / FP64_VALU_PEAK_TFLOPS, 5),
+                "queries_per_launch": float(k_ee if dom == "narrow_ee" else k_vf),
+                "note": ("since round 5 the pass's projection cull drops ~95 % of the overlap pairs in front of this kernel and its launch asks about the first half of the "
+                         "step only: it bisects %.2f M of the pass's %.2f M queries, and its duration is the longest walk's dependent chain (50-65 checks of ~1.7 us on a lone "
+                         "wave), not vector issue -- `frac` fell from 0.34 (round 4: 27 M checks in 0.52 ms) because the work went away, the step from 1.18 to 0.86 ms" % (
+                             (k_ee if dom == "narrow_ee" else k_vf) / 1e6, (q_ee if dom == "narrow_ee" else q_vf) / 1e6)),
                 "valu_per_check": valu_per_check,  # wave-level VALU instructions per check (SQ_INSTS_VALU of this build's PMC profile), else null
                 "hbm": {"achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(hbm_achieved / HBM_PEAK_GBS, 5), "bytes_per_query": BYTES_PER_QUERY},
