@@ -410,7 +410,7 @@ def main():
                 "executed_tflops": round(achieved * FLOP_PER_CHECK_EXECUTED / FLOP_PER_CHECK, 3),
                 "executed_frac": round(achieved * FLOP_PER_CHECK_EXECUTED / FLOP_PER_CHECK / FP64_VALU_PEAK_TFLOPS, 5),
                 "queries_per_launch": float(k_ee if dom == "narrow_ee" else k_vf),
-                "note": ("since round 5 the pass's projection cull drops ~95 % of the overlap pairs in front of this kernel and its launch asks about the first half of the "
+                "note": ("since round 5 the pass's projection cull drops ~95 %% of the overlap pairs in front of this kernel and its launch asks about the first half of the "
                          "step only: it bisects %.2f M of the pass's %.2f M queries, and its duration is the longest walk's dependent chain (50-65 checks of ~1.7 us on a lone "
                          "wave), not vector issue -- `frac` fell from 0.34 (round 4: 27 M checks in 0.52 ms) because the work went away, the step from 1.18 to 0.86 ms" % (
                              (k_ee if dom == "narrow_ee" else k_vf) / 1e6, (q_ee if dom == "narrow_ee" else q_vf) / 1e6)),
