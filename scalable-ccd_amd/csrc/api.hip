@@ -108,6 +108,10 @@ int sccd_create(int device, sccd_ctx** out)
         void* dev = nullptr;
         SCCD_HIP(hipHostGetDevicePointer(&dev, c->mailbox.p, 0));
         c->mailbox_dev = static_cast<char*>(dev);
+        c->verdict.ensure(4096, hipHostMallocCoherent); // (the counters of a narrow launch, 2 KB, and the sequence word behind them at 2048)
+        std::memset(c->verdict.p, 0, 4096);
+        SCCD_HIP(hipHostGetDevicePointer(&dev, c->verdict.p, 0));
+        c->verdict_dev = static_cast<char*>(dev);
     });
     if (rc != SCCD_OK) {
         g_create_error = c->err;

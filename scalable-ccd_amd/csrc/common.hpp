@@ -115,6 +115,7 @@ struct LabEnv {
     bool readback_copy = false;        // SCCD_READBACK=copy: read-backs as copies + a polled event instead of one gather kernel + a polled word
     bool sort_tickets = false;         // SCCD_SORT_TICKETS=1: sort tiles by atomic ticket even when every tile has its block
     long long level_budget_mb = 0;     // SCCD_LEVEL_BUDGET_MB: budget per level buffer of the level-synchronous narrow phase
+    bool early_verdict = true;         // SCCD_EARLY_VERDICT=0: a narrow phase in two halves waits for its whole stream, as before
     bool split_boxes = true;           // SCCD_SPLIT_BOXES=0: ccd()'s edge and face boxes in one launch on the caller's stream (round 4)
     int np_waves = 3;                  // SCCD_NP_WAVES=1|2: the plain walk kernel's grid fills that many waves per SIMD at most (it is built for three)
     bool cull_slabs = true;            // SCCD_CULL_SLABS=0: the projection cull looks at the whole step whatever the launches ask (round 5's first cull)
@@ -142,6 +143,7 @@ struct LabEnv {
         cull_slabs = num("SCCD_CULL_SLABS", 1) != 0;
         np_waves = (int)num("SCCD_NP_WAVES", 3);
         split_boxes = num("SCCD_SPLIT_BOXES", 1) != 0;
+        early_verdict = num("SCCD_EARLY_VERDICT", 1) != 0;
         const char* s = std::getenv("SCCD_SYNC");
         sync_block = s && std::string(s) == "block";
         const char* r = std::getenv("SCCD_READBACK");
@@ -234,6 +236,14 @@ struct sccd_ctx {
     // sequence word behind them.  mailbox_dev is the same memory as the device addresses it.
     PinnedBuf mailbox;
     char* mailbox_dev = nullptr;
+    // THE EARLY VERDICT of a narrow phase in two halves of time (narrow_walk.inc): np_second_half_k, the kernel between the two
+    // launches, also leaves the pass's counters and a sequence word HERE (host-coherent pinned memory, like the mailbox); if the first
+    // half found its impact the host has its result then and does not wait for what is still enqueued behind that kernel -- the
+    // second half's cull, its launch and the read-back, three launches that find nothing to do.
+    PinnedBuf verdict;
+    char* verdict_dev = nullptr;
+    unsigned long long verdict_seq = 0; // the number the next verdict carries
+    bool verdict_armed = false;         // narrow_phase_begin enqueued one for narrow_phase_end to look at
     unsigned long long rb_seq = 0;
     DevBuf np_scratch0, np_scratch1, np_scratch2, np_scratch3, np_scratch4, np_scratch3_ovf;
     DevBuf tmp0, tmp1, tmp2;

@@ -795,7 +795,30 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
 {
     NarrowCounters h;
     const long long n = p.n_pairs;
-    {
+    bool have = false;
+    if (c->verdict_armed) {
+        // THE EARLY VERDICT (sccd_ctx::verdict, np_second_half_k): the first half's counters are on the host the moment the kernel
+        // between the halves has run.  It found its impact: that is the pass's result -- what is still enqueued behind that kernel
+        // finds nothing to do and is not waited for (the stream orders the next call behind it).  It did not: the whole stream, as before.
+        c->verdict_armed = false;
+        const char* const from = c->verdict.as<char>();
+        const unsigned long long* const word = reinterpret_cast<const unsigned long long*>(from + 2048);
+        const unsigned long long want = c->verdict_seq;
+        bool arrived = true;
+        for (unsigned spins = 1; __atomic_load_n(word, __ATOMIC_ACQUIRE) != want; spins++) {
+            __builtin_ia32_pause();
+            if ((spins & 0xFFFFu) != 0) continue;
+            const hipError_t e = hipStreamQuery(c->stream); // (a stream that drained or failed without the word: the read-back below finds out)
+            if (e == hipErrorNotReady) continue;
+            arrived = __atomic_load_n(word, __ATOMIC_ACQUIRE) == want;
+            break;
+        }
+        if (arrived) {
+            std::memcpy(&h, from, sizeof h);
+            have = h.second_go == 0u;
+        }
+    }
+    if (!have) {
         // (a launch that kept its running TOI in another launch's word: that word is its result so far -- read in the same
         // round trip; a second, blocking copy here was 25 us at the end of every ccd() step)
         unsigned long long toi_elsewhere = 0;
