@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void readback_gather_k(ReadBackItems it, unsig
     // cache (first version: the 1M-triangle step 1.17 -> 1.26 ms).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (lane == 0) __hip_atomic_store(seq_word, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (round 5, ADVICE r04: the word itself is a RELEASE store at system scope -- buffer_wbl2 sc0 sc1 in front of it, the write-back
+    // half of a fence without the invalidate that hurt: 0.8446 against 0.8458 ms per step over three A/B rounds, eight registers still)
+    if (lane == 0) __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 void readback_gather_launch(sccd_ctx* c, const ReadBackItems& it, unsigned long long seq)
 {
