@@ -1013,6 +1013,43 @@ def test_full_size_ccd_matches_golden_toi(sccd, ctx, cloth1m, arith):
     assert t_vf == float.fromhex(G["toi_vf_fma" if arith else "toi_vf_strict"])
 
 
+def test_full_size_strategies_agree_where_the_default_rules_pick_them(sccd, orc, cloth1m):
+    """The 1M-triangle cloth is large enough for the DEFAULT settings (SCCD_OPT_CULL = SCCD_OPT_TWO_HALVES = 1) to use the projection
+    cull and the two halves of time, and with history on (SCCD_OPT_TOI_GUESS, the default) the last call on the mesh decides between one
+    narrow launch per pass and two and lends the next call its bound.  The step as it is (impact at 0.408), cut to 0.6 (impact at 0.68:
+    the bet of the two halves is lost) and to 0.3 (no impact): every strategy returns the same bits -- the defaults called three times in
+    a row (first call, history settled, bound tried), no history, one launch per pass, no cull -- and the full step's are the golden TOI."""
+    G = json.load(open(GOLDEN))["folded_cloth_708"]
+    V0, V1, E, F = cloth1m
+    c = sccd.Context(0)
+    try:
+        mesh = sccd.Mesh(V0, V1, E, F, ctx=c)
+        seen = []
+        for s in (1.0, 0.6, 0.3):
+            mesh.update_vertices(V0, V0 + s * (V1 - V0))
+            got = {}
+            c.set_option(sccd.OPT_TOI_GUESS, 1)
+            got["defaults"] = [sccd.ccd_mesh(mesh, want_stats=True) for _ in range(3)]
+            st = got["defaults"][0][1]
+            assert st["n_vf_culled"] + st["n_ee_culled"] > 0.5 * (st["n_vf_pairs"] + st["n_ee_pairs"]), st  # (the size rule let the cull run)
+            ref = got["defaults"][0][0]
+            assert all(t == ref for t, _ in got["defaults"]), (s, [t for t, _ in got["defaults"]])
+            c.set_option(sccd.OPT_TOI_GUESS, 0)
+            for name, cull, halves in (("no_history", 1, 1), ("one_launch", 1, 0), ("no_cull", 0, 1), ("neither", 0, 0)):
+                c.set_option(sccd.OPT_CULL, cull)
+                c.set_option(sccd.OPT_TWO_HALVES, halves)
+                t, st2 = sccd.ccd_mesh(mesh, want_stats=True)
+                assert t == ref, (s, name, t, ref)
+                assert (st2["n_vf_pairs"], st2["n_ee_pairs"]) == (st["n_vf_pairs"], st["n_ee_pairs"])
+            c.set_option(sccd.OPT_CULL, 1)
+            c.set_option(sccd.OPT_TWO_HALVES, 1)
+            seen.append(ref)
+        assert seen[0] == float.fromhex(G["toi_fma"]) and 0.5 < seen[1] < 1.0 and seen[2] == 1.0, seen
+        assert seen[1] == orc.ccd(V0, V0 + 0.6 * (V1 - V0), E, F, 0.0, -1, 1e-6, True, nthreads=64)[0]  # (the late impact: the oracle's)
+    finally:
+        c.close()
+
+
 def test_full_size_sharded_passes_reduce_to_the_same_toi(sccd, ctx, cloth1m):
     """4 ranks emulated on one GPU: the shards partition the queries and the min over the ranks'
     TOIs, threaded VF -> EE like dist.ccd_sharded does, is the single-GPU TOI."""
