@@ -552,14 +552,16 @@ void boxes_from_mesh(sccd_ctx* c, const sccd_mesh* m, double r, Pipeline* pl, bo
     }
     pl->eb.lazy = pl->fb.lazy = false;
     if (lazy_ef) {
+        const bool both = want_e && want_f && pl->eb.n > 0 && pl->fb.n > 0;
         for (sccd_boxes* b : { want_e ? &pl->eb : nullptr, want_f ? &pl->fb : nullptr }) {
             if (!b || b->n == 0) continue;
             b->lazy = true;
             b->lazy_vb = pl->vb.raw.as<sccd_aabb>();
             b->lazy_elems = b == &pl->eb ? (const void*)m->E.as<int2>() : (const void*)m->F.as<int4>();
-            b->n_part = launch_elem_stats(c, b, LAZY_STATS_STRIDE, b->stats_head(), b->stats_part());
+            if (!both) b->n_part = launch_elem_stats(c, b, LAZY_STATS_STRIDE, b->stats_head(), b->stats_part());
             b->have_stats = true;
         }
+        if (both) launch_elem_stats_two(c, &pl->eb, &pl->fb, LAZY_STATS_STRIDE, &pl->eb.n_part, &pl->fb.n_part); // (one launch: the same partials)
         return;
     }
     if (after_vertices) want_e = false; // (edge_boxes_on: the buffers are ready, the launch is the helper's)

@@ -336,6 +336,26 @@ __global__ void elem_stats_k(BoxSrc bs, int n, int stride, GridStats* __restrict
     acc.finish(st, part);
 }
 
+// both lazy lists of a mesh (edges: the first blocks_e blocks; faces) in ONE launch -- a rank of a multi-GPU job runs a build chain of
+// 10-17 us kernels, and two of them in a row for the statistics were 12 us of it.  The same partials as two launches of elem_stats_k:
+// a list's blocks stride over it by THEIR number, and write partials by their index among them.
+__global__ void elem_stats2_k(BoxSrc be, int ne, int blocks_e, BoxSrc bf, int nf, int stride, GridStats* __restrict__ st_e, double* __restrict__ part_e,
+                              GridStats* __restrict__ st_f, double* __restrict__ part_f)
+{
+    const bool edges = (int)blockIdx.x < blocks_e; // (block-uniform)
+    const int block = edges ? (int)blockIdx.x : (int)blockIdx.x - blocks_e, blocks = edges ? blocks_e : (int)gridDim.x - blocks_e;
+    const int n = edges ? ne : nf;
+    StatsAcc acc;
+    for (long long i = (long long)(block * (int)blockDim.x + (int)threadIdx.x) * stride; i < n; i += (long long)blocks * blockDim.x * stride) {
+        int4 ids;
+        const BoxLoad b = edges ? src_box<1>(be, (int)i, &ids) : src_box<2>(bf, (int)i, &ids);
+        acc.add(b.lo, b.hi);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) acc.se[k] *= (double)stride;
+    acc.finish(edges ? st_e : st_f, edges ? part_e : part_f, block);
+}
+
 // cell size = cell_factor x mean box extent on that axis; at most 2^10 cells in total
 __global__ __launch_bounds__(SCCD_STATS_BLOCKS) void grid_setup_k(const GridStats* __restrict__ st_a, const double* __restrict__ part_a, int n_part_a,
                              const GridStats* __restrict__ st_b, const double* __restrict__ part_b, int n_part_b,
@@ -1060,6 +1080,16 @@ int launch_elem_stats(sccd_ctx* c, const sccd_boxes* b, int stride, GridStats* s
     else hipLaunchKernelGGL(elem_stats_k<2>, dim3(grid), dim3(TPB), 0, c->stream, bs, n, stride, st, part);
     SCCD_HIP(hipGetLastError());
     return grid;
+}
+// the statistics of a mesh's lazy edge and face lists in one launch; *n_part_e / *n_part_f: block partials written per list
+void launch_elem_stats_two(sccd_ctx* c, const sccd_boxes* e, const sccd_boxes* f, int stride, int* n_part_e, int* n_part_f)
+{
+    const int ge = std::min(grid_for((e->n + stride - 1) / stride), SCCD_STATS_BLOCKS), gf = std::min(grid_for((f->n + stride - 1) / stride), SCCD_STATS_BLOCKS);
+    *n_part_e = ge;
+    *n_part_f = gf;
+    hipLaunchKernelGGL(elem_stats2_k, dim3((unsigned)(ge + gf)), dim3(TPB), 0, c->stream, box_src(e), e->n, ge, box_src(f), f->n, stride, e->stats_head(),
+                       e->stats_part(), f->stats_head(), f->stats_part());
+    SCCD_HIP(hipGetLastError());
 }
 void launch_shard_window(sccd_ctx* c, const uint32_t* hist, const GridParams* g, int stride, int rank, int parts, ShardWindow* out)
 {

@@ -161,6 +161,7 @@ void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a,
                        GridParams* g, uint32_t* cursors, bool reserve_tag = false, uint32_t* zero_hist = nullptr);
 void launch_cell_hist(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B /* or null */, const GridParams* g, int stride, uint32_t* hist);
 int launch_elem_stats(sccd_ctx* c, const sccd_boxes* b, int stride, GridStats* st, double* part);
+void launch_elem_stats_two(sccd_ctx* c, const sccd_boxes* e, const sccd_boxes* f, int stride, int* n_part_e, int* n_part_f);
 // a rank's window of cells, decided on the device (boxes.hip shard_window_k)
 struct ShardWindow {
     int cell_lo, cell_hi; // this rank's cells
