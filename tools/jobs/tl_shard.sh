@@ -7,7 +7,7 @@ from sccd import scenes
 V0, V1, E, F = scenes.folded_cloth(708, seed=7)
 ctx = sccd.default_context()
 mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
-ctx.set_option(sccd.OPT_SHARD_COUNT, 8); ctx.set_option(sccd.OPT_SHARD_RANK, 3)
+ctx.set_option(sccd.OPT_SHARD_COUNT, 8); ctx.set_option(sccd.OPT_SHARD_RANK, int(os.environ.get("TL_RANK", "3")))
 for _ in range(6):
     toi, st = sccd.ccd_mesh(mesh, want_stats=True)
     ctx.synchronize()

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--profile", action="store_true", help="also print rank 0's per-class device time")
     ap.add_argument("--prior", action="store_true", help="leave the speculative TOI bound on (SCCD_OPT_TOI_GUESS = 1: every repetition on this frozen mesh then starts "
                     "from its own previous answer); default: every call from toi = 1, like bench.py's headline")
+    ap.add_argument("--two-halves", type=int, default=None, help="SCCD_OPT_TWO_HALVES (0 never, 1 the default rules, 2 always)")
     ap.add_argument("--split", action="store_true", help="the pass-by-pass protocol (prepare + VF pass + EE pass) instead of one ccd() per rank")
     args = ap.parse_args()
 
@@ -34,6 +35,8 @@ def main():
     ctx = sccd.default_context()
     if not args.prior:
         ctx.set_option(sccd.OPT_TOI_GUESS, 0)
+    if args.two_halves is not None:
+        ctx.set_option(sccd.OPT_TWO_HALVES, args.two_halves)
     mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
     out = []
     for world in [int(x) for x in args.worlds.split(",")]:
