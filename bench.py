@@ -302,7 +302,7 @@ def main():
         prof_all = ctx.profile()
         # the dominant KERNEL: the class with the longest launch, each alone on the chip (above)
         dom = max(prof_apart_raw, key=lambda k: prof_apart_raw[k][0] / max(1, prof_apart_raw[k][1]))
-        class_id = {"boxes": 0, "sort": 1, "cull": 2, "sweep": 3, "narrow_vf": 4, "narrow_ee": 5}  # SCCD_PROF_*
+        class_id = {"boxes": 0, "sort": 1, "cull": 2, "sweep": 3, "narrow_vf": 4, "narrow_ee": 5, "sweep_ee": 6}  # SCCD_PROF_*
         ctx.set_option(sccd.OPT_PROFILE, (1 << class_id[dom]) << 1)
         # settling steps AFTER the last option change and BEFORE t0 (round 4 timed the steps right behind three option writes and a
         # profile reset: the driver's 20-step window came out 10 % above the 100-step lines of the same library); the profile of
@@ -367,7 +367,8 @@ def main():
         units = {  # class -> (algorithmic bytes per step, kernel name, name in the rocprofv3 summaries)
             "narrow_ee": (BYTES_PER_QUERY * k_ee, "np_walk_k<false> (edge-edge Tight-Inclusion)", "np_walk_k<false, %d, 0>" % args.arith),
             "narrow_vf": (BYTES_PER_QUERY * k_vf, "np_walk_k<true> (vertex-face Tight-Inclusion)", "np_walk_k<true, %d, 0>" % args.arith),
-            "sweep": (BYTES_SWEEP_PER_BOX * n_boxes + 8.0 * (q_vf + q_ee), "sweep_band_k / sweep_band2_k (2 launches per step)", "sweep_band_k"),
+            "sweep": (BYTES_SWEEP_PER_BOX * (len(V0) + len(F)) + 8.0 * q_vf, "sweep_band_k<false, 3> (vertices x faces: the faces' rows)", "sweep_band_k<false, 3>"),
+            "sweep_ee": (BYTES_SWEEP_PER_BOX * len(E) + 8.0 * q_ee, "sweep_band_k<true, 1> (the edge-edge sweep)", "sweep_band_k<true, 1>"),
             "sort": (BYTES_SORT_PER_KEY_PASS * 4 * n_boxes, "onesweep radix sort + scans", "os_pass_k"),
             "boxes": (124.0 * n_boxes, "box build, cell fill, sorted records", "entry_record_k"),
             "cull": (BYTES_PER_QUERY * (q_vf + q_ee), "np_cull_k (the projection cull: 2 launches per step)", "np_cull_k"),
@@ -420,7 +421,16 @@ def main():
             }
         else:
             roofline = {"bound": "hbm", "kernel": units[dom][1], "achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 5), "traffic": traffic}
+                        "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": units[dom][0] / launches_per_step}
+            if dom.startswith("sweep"):
+                roofline["note"] = ("since round 5 the longest kernel of the step is a sweep, not a narrow launch (the projection cull took 95 % of the bisection's work: "
+                                    "DESIGN 5.7).  SURVEY 8d prices a sweep in bytes -- 64 B per sorted box + 8 B per emitted pair -- against HBM; the kernel itself is bound "
+                                    "by instruction issue (filter, queue and confirm stages per candidate column: DESIGN 5.4), which is why `frac` is low and has been since round 3")
+            if prof_apart.get(dom, 0) > 0:
+                a_alone = units[dom][0] / launches_per_step / (prof_apart[dom] / launches_per_step * 1e-3) / 1e9
+                roofline["alone"] = {"launch_ms": round(prof_apart[dom] / launches_per_step, 4), "achieved": round(a_alone, 2), "frac": round(a_alone / HBM_PEAK_GBS, 5),
+                                     "note": "the same launch with nothing beside it (SCCD_OPT_PASSES_APART, untimed steps in this process)"}
         roofline.update({
             "traffic_note": traffic_note, "avg_launch_ms": round(per_launch_ms, 4), "launches": launches,
             "class_ms_per_step": {k: round(v[0] / n_prof, 4) for k, v in prof_all.items()},
@@ -430,7 +440,7 @@ def main():
                              "note": "the two narrow launches overlap in the default configuration: launch_ms_sum is not their wall span (broad_phase.passes_apart has each launch alone)"},
         })
         # ---- the broad phase against SURVEY 8d's formula (548 B per box + 8 B per pair), passes apart (measured before the timed region)
-        broad_ms = prof_apart["boxes"] + prof_apart["sort"] + prof_apart["sweep"]
+        broad_ms = prof_apart["boxes"] + prof_apart["sort"] + prof_apart["sweep"] + prof_apart.get("sweep_ee", 0.0)
         if dom.startswith("narrow") and prof_apart.get(dom, 0) > 0:
             # `achieved` above is the contract's figure: the launch's own duration in the timed region.  Since round 4's read-back
             # mailbox the edge-edge launch STARTS ~120 us earlier -- in the SIMD slots its sweep left, beside the

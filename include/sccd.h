@@ -298,7 +298,8 @@ int sccd_ipc_ccd_strategy(sccd_ctx* ctx, const double* V0, const double* V1, int
 #define SCCD_PROF_SWEEP 3
 #define SCCD_PROF_NARROW_VF 4 /* np_walk_k<true> / np_level_k<true> launches  */
 #define SCCD_PROF_NARROW_EE 5 /* np_walk_k<false> / np_level_k<false> launches */
-#define SCCD_PROF_COUNT 6
+#define SCCD_PROF_SWEEP_EE 6  /* (0.3, late) the sweep of a mesh's EDGE list -- the longest kernel of a ccd() step -- apart from the other sweeps (slot 3) */
+#define SCCD_PROF_COUNT 7
 /* accumulated device milliseconds and launch counts per kernel class since the last reset */
 int sccd_get_profile(sccd_ctx* ctx, double ms[SCCD_PROF_COUNT], int64_t launches[SCCD_PROF_COUNT]);
 int sccd_reset_profile(sccd_ctx* ctx);

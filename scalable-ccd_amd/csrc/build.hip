@@ -610,7 +610,7 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
         if (c->sweep_cnt_cleared && attempt == 0) c->sweep_cnt_cleared = false;
         else SCCD_HIP(hipMemsetAsync(d_cnt, 0, sizeof(SweepCounters), c->stream));
         {
-            ProfScope ps(c, SCCD_PROF_SWEEP);
+            ProfScope ps(c, (!B && bp->la.kind == BOX_EDGE) ? SCCD_PROF_SWEEP_EE : SCCD_PROF_SWEEP);
             // (a speculative build: the lists' sizes are bounds, the kernels take the real counts from device memory)
             const uint32_t* const d_tot = bp->speculative
                 ? reinterpret_cast<const uint32_t*>(bp->grid.as<char>() + 512 + offsetof(GridReadBack, total)) : nullptr;

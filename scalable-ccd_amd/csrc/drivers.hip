@@ -701,7 +701,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
         merge_side_profile(c); // (the edge-edge half of the step ran on the helper context)
         st->ms_boxes = c->prof_ms[SCCD_PROF_BOXES] - before[SCCD_PROF_BOXES];
         st->ms_sort = c->prof_ms[SCCD_PROF_SORT] - before[SCCD_PROF_SORT];
-        st->ms_sweep = c->prof_ms[SCCD_PROF_SWEEP] - before[SCCD_PROF_SWEEP];
+        st->ms_sweep = (c->prof_ms[SCCD_PROF_SWEEP] - before[SCCD_PROF_SWEEP]) + (c->prof_ms[SCCD_PROF_SWEEP_EE] - before[SCCD_PROF_SWEEP_EE]);
         st->ms_narrow = (c->prof_ms[SCCD_PROF_NARROW_VF] - before[SCCD_PROF_NARROW_VF])
             + (c->prof_ms[SCCD_PROF_NARROW_EE] - before[SCCD_PROF_NARROW_EE]) + (c->prof_ms[SCCD_PROF_CULL] - before[SCCD_PROF_CULL]);
     }

@@ -47,7 +47,7 @@ OPT_TWO_HALVES = 25  # 1 (default): plain narrow launches from a TOI above 0.5 r
 OPT_ALLOC_COUNT = 23  # read-only: device allocations made by the library's grow-only buffers (a step that allocates is a slow step)
 OPT_SPEC_HITS, OPT_SPEC_MISSES = 15, 16  # read-only counters of the speculative build (set: reset)
 OPT_LIMIT_LEVEL_ORDER = 14  # 1: check limits always on the level-synchronous kernels; default: fast kernel + certificate (same result)
-PROF_NAMES = ["boxes", "sort", "cull", "sweep", "narrow_vf", "narrow_ee"]  # SCCD_PROF_*
+PROF_NAMES = ["boxes", "sort", "cull", "sweep", "narrow_vf", "narrow_ee", "sweep_ee"]  # SCCD_PROF_* ("sweep_ee": a mesh's edge list; "sweep": every other sweep)
 
 # every symbol include/sccd.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
