@@ -341,6 +341,21 @@ def main():
         guess = {"ms_per_step_with": round((time.perf_counter() - tg) / 20 * 1e3, 4),
                  "hits": ctx.get_option(sccd.OPT_TOI_GUESS_HITS), "misses": ctx.get_option(sccd.OPT_TOI_GUESS_MISSES)}
         ctx.set_option(sccd.OPT_TOI_GUESS, 0)
+        if use_dist:
+            # a JOB's history: every rank starts from 1.125 x the REDUCED result of the last step (sccd.dist.GlobalPrior; a rank's own last
+            # result is a worse bound, and a rank must not redo a step because ITS shard has nothing below the bound)
+            gp = sdist.GlobalPrior(device=red_dev)
+            run_from = lambda b: sccd.ccd_mesh_from(mesh, b, want_stats=True, **params)  # noqa: E731
+            for _ in range(N_SETTLE):
+                gp.step(run_from)
+            gp.hits = gp.misses = 0
+            barrier()
+            tgp = time.perf_counter()
+            for _ in range(20):
+                gp.step(run_from)
+            barrier()
+            guess["ms_per_step_global_prior"] = round((time.perf_counter() - tgp) / 20 * 1e3, 4)
+            guess["global_prior_hits"], guess["global_prior_misses"] = gp.hits, gp.misses
         for _ in range(N_SETTLE):
             step()
         # max over ranks of the elapsed time, sum over ranks of the queries

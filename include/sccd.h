@@ -273,6 +273,13 @@ int sccd_ccd_mesh(sccd_ctx* ctx, const sccd_mesh* mesh, double min_distance, int
  * (src/scalable_ccd/cuda/broad_phase/CMakeLists.txt:21 leaves _multigpu out of the build). */
 int sccd_ccd_mesh_dev(sccd_ctx* ctx, const sccd_mesh* mesh, double min_distance, int max_iterations,
                       double tolerance, int allow_zero_toi, double* d_toi, double* toi, sccd_stats* stats);
+/* ccd() on a resident mesh FROM A CALLER'S BOUND in (0, 1]: *toi = min(bound, the earliest impact below it) -- narrow_phase's toi is in / out
+ * (narrow_phase.cu:126); a result below the bound is bit for bit what a start from 1 returns, a result AT the bound says only that nothing
+ * lies below it.  The context's own history (SCCD_OPT_TOI_GUESS) is neither used nor updated.  For callers that hold a better bound than the
+ * context can: the ranks of a multi-GPU job start from 1.125 x the REDUCED result of their last step (sccd/dist.py GlobalPrior).  Calls with
+ * a check limit start from 1 whatever the bound (the limit's certificate is about the TOI a call started with). */
+int sccd_ccd_mesh_from(sccd_ctx* ctx, const sccd_mesh* mesh, double min_distance, int max_iterations, double tolerance, int allow_zero_toi,
+                       double bound, double* toi, sccd_stats* stats);
 /* The two halves of ccd() for multi-GPU runs (one process per GPU).  A rank (SCCD_OPT_SHARD_RANK / SCCD_OPT_SHARD_COUNT) owns a
  * contiguous window of grid cells cut ON THE DEVICE from a sampled cell histogram; prepare builds the vertex boxes only (the
  * edge and face boxes of a sharded call are computed inside the fill, and stored only where they fall into the rank's

@@ -717,6 +717,31 @@ extern "C" int sccd_ccd_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max
     });
 }
 
+// ccd() that starts from a CALLER'S bound: min(bound, earliest accepted domain below it) -- narrow_phase's toi is in / out
+// (narrow_phase.cu:126), and a result below the bound is what a start from 1 returns.  Nothing of the context's own history is used
+// or kept (no speculative bound, no redo; the two halves of time by the option and the mesh's size alone): the bound is the caller's
+// business -- the ranks of a multi-GPU job start from 1.125 x the REDUCED result of their last step and redo the step only if the
+// reduced result is the bound itself (sccd/dist.py GlobalPrior).
+extern "C" int sccd_ccd_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter, double tol, int allow_zero_toi, double bound,
+                                  double* toi, sccd_stats* stats)
+{
+    if (!c || !m || !toi) return SCCD_E_INVALID;
+    return guarded(c, [&] {
+        SCCD_REQUIRE(m->ctx == c, "ccd: mesh belongs to another context");
+        SCCD_REQUIRE(bound > 0 && bound <= 1, "ccd: the bound a call starts from lies in (0, 1]");
+        struct HalvesOff {
+            sccd_ctx* c;
+            ~HalvesOff() { c->two_halves_off = 0; }
+        } halves_off { c };
+        c->two_halves_off = (c->two_halves == 1 && (long long)m->nE + m->nF < SCCD_TWO_HALVES_MIN_ELEMENTS) ? 1 : 0;
+        const double b = c->scalar_f32 ? (double)(float)bound : bound; // (the value the float build's kernels start from: ccd_on_mesh)
+        double t = 1.0;
+        ccd_on_mesh_from(c, m, ms, max_iter, tol, allow_zero_toi, max_iter < 0 ? b : 1.0, &t, stats, nullptr);
+        c->toi_guess_mesh = nullptr; // (the context's own history knows nothing of this call)
+        *toi = t;
+    });
+}
+
 constexpr size_t TOI_OUT_MIRROR = 11280; // the source of sccd_ccd_mesh_dev's 8-byte upload in the pinned mirror (common.hpp: h_scalars)
 extern "C" int sccd_ccd_mesh_dev(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter, double tol, int allow_zero_toi,
                                  double* d_toi, double* toi, sccd_stats* stats)

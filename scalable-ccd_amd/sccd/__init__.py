@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "sccd_ccd_mesh", "sccd_ccd_mesh_prepare", "sccd_ccd_mesh_pass", "sccd_ipc_ccd_strategy", "sccd_get_profile", "sccd_reset_profile", "sccd_sort_pairs_u32",
     "sccd_shard_bounds", "sccd_boxes_variance_axis", "sccd_selftest_lds_gather",
     "sccd_dev_alloc", "sccd_dev_free", "sccd_dev_upload", "sccd_dev_download", "sccd_dev_copy", "sccd_ccd_collisions",
-    "sccd_ccd_mesh_dev", "sccd_get_stream", "sccd_query_cull", "sccd_query_cull_slab",
+    "sccd_ccd_mesh_dev", "sccd_get_stream", "sccd_query_cull", "sccd_query_cull_slab", "sccd_ccd_mesh_from",
 ]
 
 
@@ -539,6 +539,17 @@ def ccd_mesh(mesh, min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow_ze
     mesh.ctx._check(lib().sccd_ccd_mesh(
         mesh.ctx._h, mesh._h, C.c_double(min_distance), C.c_int(max_iterations), C.c_double(tolerance),
         C.c_int(int(allow_zero_toi)), C.byref(t), C.byref(st) if want_stats else None))
+    return (t.value, st.as_dict()) if want_stats else t.value
+
+
+def ccd_mesh_from(mesh, bound, min_distance=0.0, max_iterations=-1, tolerance=1e-6, allow_zero_toi=True, want_stats=False):
+    """ccd_mesh() that starts from the caller's bound in (0, 1] (sccd_ccd_mesh_from): min(bound, earliest impact below it); the context's
+    own history is neither used nor kept.  -> toi or (toi, stats dict)."""
+    t = C.c_double(1.0)
+    st = Stats()
+    mesh.ctx._check(lib().sccd_ccd_mesh_from(
+        mesh.ctx._h, mesh._h, C.c_double(min_distance), C.c_int(max_iterations), C.c_double(tolerance),
+        C.c_int(int(allow_zero_toi)), C.c_double(bound), C.byref(t), C.byref(st) if want_stats else None))
     return (t.value, st.as_dict()) if want_stats else t.value
 
 

@@ -84,6 +84,37 @@ class DeviceMin:
         return float(self.word.item())
 
 
+class GlobalPrior:
+    """The speculative bound of a multi-GPU job: every rank starts a step from 1.125 x the REDUCED result of the job's last step on the
+    mesh (a rank's own last result is a worse bound -- its shard's earliest impact may lie far behind the job's -- and a rank must not
+    redo a step just because ITS shard has nothing below the bound).  run(bound) -> (toi, stats) is one ccd() of this rank from that bound
+    (sccd.ccd_mesh_from on a context with SHARD_RANK / SHARD_COUNT set).  The reduced minimum is below the bound: exact, done.  It IS the
+    bound (no rank found anything below it): every rank knows, and every rank redoes the step from 1.  Exact either way; one more
+    collective only for a bound that broke."""
+
+    def __init__(self, group=None, device=None):
+        self.group, self.device = group, device
+        self.bound = 1.0
+        self.hits = self.misses = 0
+
+    def step(self, run):
+        bound = self.bound
+        toi, st = run(bound)
+        toi = allreduce_min(toi, group=self.group, device=self.device)
+        if bound < 1.0:
+            if toi < bound:
+                self.hits += 1
+            else:  # nothing below the bound anywhere: the earliest impact lies at or beyond it
+                self.misses += 1
+                toi, st = run(1.0)
+                toi = allreduce_min(toi, group=self.group, device=self.device)
+        self.bound = min(1.0, 1.125 * toi) if 0.0 < toi < 1.0 else 1.0
+        return toi, st
+
+    def forget(self):
+        self.bound = 1.0
+
+
 def ccd_sharded(run_pass, rank, world, group=None, device=None, prepare=None, reduce_between_passes=False):
     """ccd() across `world` ranks.
 

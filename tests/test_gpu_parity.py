@@ -1013,6 +1013,40 @@ def test_full_size_ccd_matches_golden_toi(sccd, ctx, cloth1m, arith):
     assert t_vf == float.fromhex(G["toi_vf_fma" if arith else "toi_vf_strict"])
 
 
+def test_ccd_from_a_callers_bound(sccd, ctx, orc):
+    """sccd_ccd_mesh_from: min(bound, earliest impact below it).  Below the bound: the oracle's TOI, bit for bit; a bound at or below the
+    earliest impact comes back itself; the context's own history is not touched (the next plain call returns the same as ever); and the
+    job-wide protocol built on it (sccd.dist.GlobalPrior, here with one rank) walks through hits and a broken bound."""
+    from sccd import dist as sdist
+
+    V0, V1, E, F = _scene("cloth_ball_small")
+    want = orc.ccd(V0, V1, E, F, 0.0, -1, 1e-6, True, nthreads=8)[0]
+    assert 0.0 < want < 1.0
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    for cull, halves in ((2, 2), (0, 0), (1, 1)):
+        ctx.set_option(sccd.OPT_CULL, cull)
+        ctx.set_option(sccd.OPT_TWO_HALVES, halves)
+        for bound in (1.0, 0.9, min(1.0, 1.125 * want), float(np.nextafter(want, 1.0))):
+            assert sccd.ccd_mesh_from(mesh, bound) == want, (cull, halves, bound)
+        for bound in (want, 0.5 * want, 1e-9):
+            assert sccd.ccd_mesh_from(mesh, bound) == bound, (cull, halves, bound)
+        assert sccd.ccd_mesh(mesh) == want
+    ctx.set_option(sccd.OPT_CULL, 1)
+    ctx.set_option(sccd.OPT_TWO_HALVES, 1)
+    with pytest.raises(Exception):
+        sccd.ccd_mesh_from(mesh, 0.0)
+    gp = sdist.GlobalPrior()
+    run = lambda b: sccd.ccd_mesh_from(mesh, b, want_stats=True)  # noqa: E731
+    assert gp.step(run)[0] == want and gp.bound == min(1.0, 1.125 * want)
+    assert gp.step(run)[0] == want and (gp.hits, gp.misses) == (1, 0)
+    mesh.update_vertices(V0, V0 + 0.5 * (V1 - V0))  # the impact moves to twice the time: beyond the bound
+    later = orc.ccd(V0, V0 + 0.5 * (V1 - V0), E, F, 0.0, -1, 1e-6, True, nthreads=8)[0]
+    assert later > gp.bound
+    assert gp.step(run)[0] == later and (gp.hits, gp.misses) == (1, 1)
+    assert gp.step(run)[0] == later and (gp.hits, gp.misses) == (2, 1)
+    mesh.close()
+
+
 def test_full_size_strategies_agree_where_the_default_rules_pick_them(sccd, orc, cloth1m):
     """The 1M-triangle cloth is large enough for the DEFAULT settings (SCCD_OPT_CULL = SCCD_OPT_TWO_HALVES = 1) to use the projection
     cull and the two halves of time, and with history on (SCCD_OPT_TOI_GUESS, the default) the last call on the mesh decides between one

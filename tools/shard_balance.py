@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--profile", action="store_true", help="also print rank 0's per-class device time")
     ap.add_argument("--prior", action="store_true", help="leave the speculative TOI bound on (SCCD_OPT_TOI_GUESS = 1: every repetition on this frozen mesh then starts "
                     "from its own previous answer); default: every call from toi = 1, like bench.py's headline")
+    ap.add_argument("--global-prior", type=float, default=0.0, help="every rank starts from this bound (sccd_ccd_mesh_from): what a job's ranks do with "
+                    "sccd.dist.GlobalPrior -- 1.125 x the job's last reduced TOI, e.g. 0.4592 for the folded cloth")
     ap.add_argument("--two-halves", type=int, default=None, help="SCCD_OPT_TWO_HALVES (0 never, 1 the default rules, 2 always)")
     ap.add_argument("--split", action="store_true", help="the pass-by-pass protocol (prepare + VF pass + EE pass) instead of one ccd() per rank")
     args = ap.parse_args()
@@ -57,6 +59,9 @@ def main():
                     for is_vf in (True, False):
                         toi, st = sccd.ccd_mesh_pass(mesh, is_vf, toi)
                         pairs += st["n_vf_pairs"] + st["n_ee_pairs"]
+                elif args.global_prior > 0:
+                    toi, st = sccd.ccd_mesh_from(mesh, args.global_prior, want_stats=True)
+                    pairs = st["n_vf_pairs"] + st["n_ee_pairs"]
                 else:  # what bench.py runs per rank: one ccd() on the rank's shard
                     toi, st = sccd.ccd_mesh(mesh, want_stats=True)
                     pairs = st["n_vf_pairs"] + st["n_ee_pairs"]
