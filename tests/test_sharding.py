@@ -110,6 +110,68 @@ def test_sharded_ccd_two_ranks_gloo():
     assert m0 == m1 == 5.0                               # all-reduce(min) really reduces over ranks
 
 
+def _prior_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "scalable-ccd_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+
+    import orc
+    from sccd import dist as sdist
+    from sccd import scenes
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        V0, V1, E, F = scenes.triangle_soup(150, seed=21)
+        gp = sdist.GlobalPrior()
+        log = []
+        for scale in (1.0, 1.0, 0.4, 0.4, 1.0):  # (the step cut to 0.4: every impact moves to 2.5 x the time -- the bound breaks; then back)
+            W1 = V0 + scale * (V1 - V0)
+            vb, eb, fb = orc.build_boxes(V0, W1, E, F)
+            vf, _, _ = orc.sort_and_sweep(vb, fb)
+            ee, _, _ = orc.sort_and_sweep(eb)
+            calls = []
+
+            def run(bound):  # this rank's ccd() from the bound: both passes on its share of the pairs, toi in / out
+                calls.append(bound)
+                t = bound
+                for is_vf, pairs in ((True, vf), (False, ee)):
+                    b = sdist.balanced_bounds(np.ones(len(pairs), np.int64), world)
+                    t, _ = orc.narrow_phase_mt(V0, W1, E, F, pairs[b[rank]:b[rank + 1]], is_vf, toi=t, nthreads=2)
+                return t, {}
+
+            toi, _ = gp.step(run)
+            log.append((toi, orc.ccd(V0, W1, E, F)[0], tuple(calls), gp.bound))
+        q.put((rank, log, gp.hits, gp.misses))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_global_prior_two_ranks_gloo():
+    """sccd.dist.GlobalPrior over gloo: both ranks start from 1.125 x the last REDUCED result, a bound that breaks is redone from 1 on
+    every rank, and every step ends with the oracle's TOI on both."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prior_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=480) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out.sort()
+    (_, log0, h0, m0), (_, log1, h1, m1) = out
+    assert log0 == log1 and (h0, m0) == (h1, m1)  # the ranks agree on every result, every bound and every redo
+    for toi, want, calls, bound in log0:
+        assert toi == want
+        assert bound == (min(1.0, 1.125 * want) if 0 < want < 1 else 1.0)
+    assert log0[0][2] == (1.0,) and len(log0[1][2]) == 1 and log0[1][2][0] < 1.0  # first from 1, then from the bound
+    assert len(log0[2][2]) == 2 and log0[2][2][1] == 1.0  # the broken bound: again from 1
+    assert h0 >= 2 and m0 >= 1
+
+
 def test_single_rank_needs_no_process_group():
     from sccd import dist as sdist
 
