@@ -140,6 +140,7 @@ void sccd_destroy(sccd_ctx* c)
     if (c->side_event) (void)hipEventDestroy(c->side_event);
     if (c->side_event2) (void)hipEventDestroy(c->side_event2);
     if (c->side_event3) (void)hipEventDestroy(c->side_event3);
+    if (c->records_gate.ev) (void)hipEventDestroy(c->records_gate.ev);
     if (c->side) sccd_destroy(c->side);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     __atomic_sub_fetch(&live_context_count(), 1, __ATOMIC_RELAXED);

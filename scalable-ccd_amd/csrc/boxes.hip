@@ -766,15 +766,18 @@ __global__ __launch_bounds__(1024) void shard_window_k(const uint32_t* __restric
 //     rows A: lower_bound(keys B, K(min_a))      -- the columns with K(min_a) <= K(min_b) <= K(max_a) start there
 //     rows B: upper_bound(keys A, K(min_b))      -- ... with K(min_b) <  K(min_a) <= K(max_b)
 // (the reference walks j = i + 1, ... of ONE merged list, sweep.cu:125-131; two lists swept as two classes never test
-// a vertex against a vertex or a face against a face).  A block's 1024 consecutive rows all start inside one window of
+// a vertex against a vertex or a face against a face).  A block's consecutive rows all start inside one window of
 // the column keys: two waves find its ends with 64 probes per round, every row then searches inside the window (a few
 // hundred keys in this CU's L1).  The sweep finds the END of a row's columns itself (the first key beyond K(max)).
 // own_tagged / other_tagged: this list's / the column list's keys carry the list tag of a merged sort (grid tag_bit).
+// Rows per block: 512.  As kernels the two record launches of a step do not care (1,024 / 512 / 256: noise) -- but ccd() runs the edge
+// list's beside the vertex-face SWEEP (drivers.hip: the records gate), whose two 216-register waves per SIMD leave 80 registers: eight
+// waves of 32 fit beside them, sixteen -- a block of 1,024 rows -- wait for a CU the sweep has left.
 #ifndef ER_THREADS_
-#define ER_THREADS_ 1024
+#define ER_THREADS_ 512
 #endif
 constexpr int ER_THREADS = ER_THREADS_;
-constexpr int ER_WINDOW = ER_THREADS_ * 4; // column keys of a block's window staged in LDS (16 KB per 1024 threads)
+constexpr int ER_WINDOW = ER_THREADS_ * 4; // column keys of a block's window staged in LDS (8 KB per 512 threads)
 struct RecordArgs { // one list's share of a record launch
     const sccd_aabb* raw;
     const uint32_t *key, *idx;

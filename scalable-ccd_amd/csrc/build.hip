@@ -1,6 +1,7 @@
 // build.hip -- the C ABI of include/sccd.h, part 2: BroadPhase (broad_phase.cuh:15-92, broad_phase.cu:29-252) -- the cell
 // grid, the entry lists (one-pass append fill or count -> scan -> fill), the merged sort, the sorted records, the speculative
 // build, a rank's window of cells, and detect_overlaps_partial with its overflow rerun, cursor and memory limit.
+#include <chrono>
 #include "api_internal.hpp"
 
 extern "C" int sccd_broad_phase_create(sccd_ctx* c, sccd_broad_phase** out)
@@ -104,12 +105,35 @@ static void list_sort(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, in
         }
     }
 }
+// SCCD_EREC_LATE (drivers.hip, ccd()): the two record kernels of a step -- vertices + faces on the caller's stream, edges on the
+// helper's -- are bandwidth-bound and side by side each takes twice its time, but only the first is on the way to the first sweep.
+// The helper's kernel is ordered behind the END of the caller's: it then runs beside the vertex-face sweep (instruction issue).
+static void records_gate_signal(sccd_ctx* c)
+{
+    StageGate* g = c->records_gate_signal;
+    if (!g || g->state.load(std::memory_order_relaxed) != 0) return;
+    SCCD_HIP(hipEventRecord(g->ev, c->stream));
+    g->state.store(1, std::memory_order_release);
+}
+static void records_gate_wait(sccd_ctx* c)
+{
+    StageGate* g = c->records_gate_wait;
+    if (!g) return;
+    // (the caller's thread enqueues its chain at the same pace: microseconds; a build that takes another path opens the gate when it
+    // is through -- drivers.hip -- and the bound keeps a forgotten gate from ever costing more than this)
+    const auto t0 = std::chrono::steady_clock::now();
+    int st;
+    while ((st = g->state.load(std::memory_order_acquire)) == 0)
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) return;
+    if (st == 1) SCCD_HIP(hipStreamWaitEvent(c->stream, g->ev, 0));
+}
 // the sorted records of the lists of a build whose (key, index) pairs are sorted, each list in its own arrays
 static void lists_records(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B, const GridParams* gp, SortedList* LA,
                           SortedList* LB, const uint32_t* d_tot = nullptr, int expect_bits = 0)
 {
     ProfScope ps(c, SCCD_PROF_BOXES);
     if (!B) {
+        records_gate_wait(c);
         launch_entry_records(c, A->raw.as<sccd_aabb>(), LA->key.as<uint32_t>(), LA->idx.as<uint32_t>(), LA->m, gp, 0, nullptr,
                              0, false, false, LA, d_tot, expect_bits);
         return;
@@ -118,6 +142,7 @@ static void lists_records(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B,
     if (LA->m == 0 || LB->m == 0) return;
     launch_entry_records_two(c, A->raw.as<sccd_aabb>(), LA->key.as<uint32_t>(), LA->idx.as<uint32_t>(), LA->m,
                              B->raw.as<sccd_aabb>(), LB->key.as<uint32_t>(), LB->idx.as<uint32_t>(), LB->m, /*b_tagged=*/false, gp, LA, LB);
+    records_gate_signal(c);
 }
 
 // BroadPhase::build (broad_phase.cu:29-101) together with the key split + sort the reference
@@ -159,6 +184,7 @@ static void lists_finish_merged(sccd_ctx* c, const sccd_boxes* A, const sccd_box
         const uint32_t* idx = LA->idx.as<uint32_t>();
         launch_entry_records_two(c, A->raw.as<sccd_aabb>(), keys, idx, (int)ma, B->raw.as<sccd_aabb>(), keys + ma, idx + ma, (int)mb,
                                  /*b_tagged=*/true, gp, LA, LB, d_tot, key_bits, d_extq);
+        records_gate_signal(c);
     }
 }
 

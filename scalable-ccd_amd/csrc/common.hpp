@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -104,6 +105,12 @@ struct PinnedBuf {
 // The laboratory switches that are left (tools/README.md), read ONCE, when the first context is made.  Everything else that
 // used to be an environment variable is either gone with the path it selected (SCCD_SORT=classic, SCCD_SWEEP_CHUNK,
 // SCCD_MERGED_SORT, SCCD_NP_PERM, ...) or an option of the context (SCCD_OPT_CELL_FACTOR_MILLI, SCCD_OPT_BUILD_SCAN).
+// ccd()'s two build chains (drivers.hip): a point of the caller's chain a kernel of the helper's chain is ordered behind, on the
+// device.  The caller's thread records the event on its stream and THEN publishes state 1; state 2 = "go without waiting".
+struct StageGate {
+    std::atomic<int> state { 0 }; // 0 closed, 1 open: wait for `ev` on the device, 2 open: no wait
+    hipEvent_t ev = nullptr;
+};
 struct LabEnv {
     int np_diag = 0, sweep_diag = 0;   // SCCD_NP_DIAG / SCCD_SWEEP_DIAG: counters and cycle stamps of the narrow / sweep kernels
     bool speculate = true;             // SCCD_SPECULATE=0: every build waits for its entry counts (no speculative build)
@@ -119,6 +126,8 @@ struct LabEnv {
     bool split_boxes = true;           // SCCD_SPLIT_BOXES=0: ccd()'s edge and face boxes in one launch on the caller's stream (round 4)
     int np_waves = 3;                  // SCCD_NP_WAVES=1|2: the plain walk kernel's grid fills that many waves per SIMD at most (it is built for three)
     bool cull_slabs = true;            // SCCD_CULL_SLABS=0: the projection cull looks at the whole step whatever the launches ask (round 5's first cull)
+    int erec_late = 1;                 // SCCD_EREC_LATE=0: ccd()'s edge-list records kernel beside the vertex + face records kernel, not behind its end;
+                                       // 2: behind it whatever the mesh's size (1: from SCCD_RECORDS_GATE_MIN_ELEMENTS edges + faces)
     bool ee_early = true;              // SCCD_EE_EARLY=0: ccd()'s edge-edge walk kernel launched by the host once it has the pair count (round 4)
                                        // instead of right behind its sweep and cull with the count read on the device
     int spec_break_every = 0;          // SCCD_SPEC_BREAK=N: every N-th speculative build is declared a failed guess (measures what a miss costs)
@@ -144,6 +153,7 @@ struct LabEnv {
         np_waves = (int)num("SCCD_NP_WAVES", 3);
         split_boxes = num("SCCD_SPLIT_BOXES", 1) != 0;
         early_verdict = num("SCCD_EARLY_VERDICT", 1) != 0;
+        erec_late = num("SCCD_EREC_LATE", 1);
         const char* s = std::getenv("SCCD_SYNC");
         sync_block = s && std::string(s) == "block";
         const char* r = std::getenv("SCCD_READBACK");
@@ -202,6 +212,11 @@ struct sccd_ctx {
     double np_init_toi = 0;
     hipEvent_t side_event2 = nullptr; // ccd(): "the helper's stream has reached its sweep" (drivers.hip)
     hipEvent_t side_event3 = nullptr; // ccd(): "the helper's sweep and cull are done" (their counters are read through this context's stream)
+    // ccd(): the helper's records kernel (edge list) is ordered behind the END of this context's two-list records kernel (vertices +
+    // faces) -- build.hip: records_gate_signal / records_gate_wait; SCCD_EREC_LATE=0 leaves them side by side
+    StageGate records_gate;                    // the caller's context owns it
+    StageGate* records_gate_signal = nullptr;  // caller's context: its own gate while a ccd() call uses it
+    StageGate* records_gate_wait = nullptr;    // helper context: the gate in front of its one-list records kernel
     double np_uploaded_toi = 0;
     // a narrow-phase launch of ANOTHER context that shares this one's TOI word is running on that stream: before this
     // context resets its counters (fallback paths) it waits for it

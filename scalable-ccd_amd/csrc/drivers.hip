@@ -459,8 +459,25 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
     // and the soak run with it; SCCD_OVERLAP=0 keeps the passes apart.
     bool helper = false, presweep_done = false;
     const bool presweep_env = lab_env().presweep;
+    // The helper's records kernel behind the END of this stream's (build.hip: records_gate_*).  Whatever way this call ends, the gate
+    // is open when it is left.
+    struct GateOpen {
+        StageGate* g;
+        void open() const
+        {
+            int closed = 0;
+            if (g) g->state.compare_exchange_strong(closed, 2, std::memory_order_release, std::memory_order_relaxed);
+        }
+        ~GateOpen() { open(); }
+    } gate_open { nullptr };
     if (with_helper) {
         sccd_ctx* const sc = c->side;
+        c->records_gate_signal = sc->records_gate_wait = nullptr;
+        if (!lazy_ef && (lab_env().erec_late >= 2 || (lab_env().erec_late == 1 && (long long)m->nE + m->nF >= SCCD_RECORDS_GATE_MIN_ELEMENTS))) {
+            if (!c->records_gate.ev) SCCD_HIP(hipEventCreateWithFlags(&c->records_gate.ev, hipEventDisableTiming));
+            c->records_gate.state.store(0, std::memory_order_relaxed);
+            c->records_gate_signal = sc->records_gate_wait = gate_open.g = &c->records_gate;
+        }
         sc->sort_axis = c->sort_axis;
         sc->sweep_algo = c->sweep_algo;
         sc->cell_factor_milli = c->cell_factor_milli;
@@ -501,6 +518,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
     std::function<void()> start_ee_sweep;
     if (helper && presweep_env)
         start_ee_sweep = [&] {
+            gate_open.open();  // (a vertex-face build that came another way than by its two-list records kernel)
             pl->worker.wait(); // the lists are built (long since: the build is shorter than the vertex-face broad phase)
             // ... behind whatever this context's stream holds now (the vertex-face sweep): ordered on the DEVICE, so the
             // edge-edge sweep starts the moment that sweep ends -- not a host round trip later
@@ -672,6 +690,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
         }
     } catch (...) {
         if (helper) {
+            gate_open.open();
             try {
                 pl->worker.wait();
             } catch (...) {
@@ -684,6 +703,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
         // (both passes are behind us; each pair list was swept in one chunk and is still on the device)
         if (lists_resident) *lists_resident = true;
     } else if (helper) {
+        gate_open.open();
         pl->worker.wait();
         ccd_pass(c, m, pl, &pl->bp_ee, false, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true, /*swept=*/presweep_done);
     } else {

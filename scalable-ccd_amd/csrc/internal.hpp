@@ -76,6 +76,9 @@ constexpr size_t SCCD_LIST_PAD = 64; // entries allocated past the last one: the
 // ccd() on small meshes: the sizes (edges + faces) from which the projection cull and the two halves of time are used under their
 // default settings (drivers.hip: pass_cull_setup, ccd_on_mesh)
 constexpr long long SCCD_CULL_MIN_ELEMENTS = 50000, SCCD_TWO_HALVES_MIN_ELEMENTS = 600000;
+// ... and the size from which the edge list's records kernel is ordered behind the end of the vertex + face one (drivers.hip, the
+// records gate): below it the cross-queue wait costs the 5-10 us a step gains above it (cloths of 100 k - 200 k triangles: +2 %)
+constexpr long long SCCD_RECORDS_GATE_MIN_ELEMENTS = 600000;
 // The slabs of the step a pass's projection cull is run for (narrow_cull.inc, "slabs of time"): [0, t_end], or -- for the two launches
 // of the walk kernel's "two halves of time" -- [0, t_mid] behind the sweep and [t_mid, t_end] between the two launches.
 struct CullSlabs {

@@ -2,7 +2,7 @@
 # (functional checks of the multi-process path: the timings of shared-GPU runs mean nothing).   bash tools/jobs/env_matrix.sh
 cd $GRAFT_REPO_ROOT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-for sw in SCCD_OVERLAP=0 SCCD_NARROW_BESIDE=0 SCCD_PRESWEEP=0 SCCD_SYNC=block SCCD_SPECULATE=0 SCCD_SORT_TICKETS=1 SCCD_READBACK=copy SCCD_NARROW_ORDER=0 SCCD_EE_EARLY=0 SCCD_SPLIT_BOXES=0 SCCD_CULL_SLABS=0 SCCD_EARLY_VERDICT=0; do
+for sw in SCCD_OVERLAP=0 SCCD_NARROW_BESIDE=0 SCCD_PRESWEEP=0 SCCD_SYNC=block SCCD_SPECULATE=0 SCCD_SORT_TICKETS=1 SCCD_READBACK=copy SCCD_NARROW_ORDER=0 SCCD_EE_EARLY=0 SCCD_SPLIT_BOXES=0 SCCD_CULL_SLABS=0 SCCD_EARLY_VERDICT=0 SCCD_EREC_LATE=0 SCCD_EREC_LATE=2; do
   echo "== $sw"
   env $sw timeout 900 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -1
 done
