@@ -3,6 +3,7 @@
 //  0  same stream (the floor: back-to-back dispatch)
 //  1  hipEventRecord(s1) + hipStreamWaitEvent(s2)            (what ccd() does between its two streams)
 //  2  A's last wave sets a device word; a one-wave kernel on s2, enqueued beforehand, polls it (bounded) and B follows it on s2
+//  3  same stream, with a hipEventRecord between A and B (what a stream pays for being waited on: the marker packet between its kernels)
 // build: hipcc --offload-arch=gfx950 -O2 tools/probe/xqueue_probe.hip -o /tmp/xqueue_probe
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -50,12 +51,16 @@ int main()
     hipEvent_t ev;
     CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     const int N = 300;
-    for (int mode = 0; mode < 3; mode++) {
+    for (int mode = 0; mode < 4; mode++) {
         std::vector<double> gap;
         for (int i = 1; i <= N; i++) {
             if (mode == 2) hipLaunchKernelGGL(poll_k, dim3(1), dim3(64), 0, s2, flag, (unsigned)i, gave_up); // enqueued BEFORE A, as a step would
             hipLaunchKernelGGL(a_k, dim3(512), dim3(256), 0, s1, t_end, done, mode == 2 ? flag : nullptr, (unsigned)i, 20000);
             if (mode == 0) hipLaunchKernelGGL(b_k, dim3(512), dim3(256), 0, s1, t_start);
+            else if (mode == 3) {
+                CK(hipEventRecord(ev, s1));
+                hipLaunchKernelGGL(b_k, dim3(512), dim3(256), 0, s1, t_start);
+            }
             else {
                 if (mode == 1) { CK(hipEventRecord(ev, s1)); CK(hipStreamWaitEvent(s2, ev, 0)); }
                 hipLaunchKernelGGL(b_k, dim3(512), dim3(256), 0, s2, t_start);
