@@ -74,3 +74,22 @@ def test_readback_gather_kernel_fits_beside_narrow_phase_waves(tmp_path):
     assert len(ks) == 2
     for name, r in ks.items():
         assert r["next_free_vgpr"] <= 8 and r["group_segment_fixed_size"] == 0, (name, r)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_edge_records_kernel_fits_beside_the_vertex_face_sweep(tmp_path):
+    # ccd() runs the edge list's records kernel beside the vertex-face sweep (the records gate): a block of it must fit
+    # on a CU that holds two sweep waves per SIMD -- 512 registers per SIMD lane minus the sweep's two waves, shared by the block's
+    # waves on that SIMD (ER_THREADS / 256); with blocks that do not fit the gate costs 15 us instead of gaining 20
+    boxes = _kernels("boxes", tmp_path)
+    sweep = _kernels("sweep", tmp_path)
+    rec = [v for k, v in boxes.items() if "entry_record_kILi0E" in k]
+    vf = [v for k, v in sweep.items() if re.search(r"sweep_band_kILb0ELi3E", k)]
+    assert len(rec) == 1 and len(vf) == 1
+    granule = lambda v: (v + 7) // 8 * 8
+    left = 512 - 2 * granule(vf[0]["next_free_vgpr"])
+    src = open(os.path.join(ROOT, "scalable-ccd_amd", "csrc", "boxes.hip")).read()
+    threads = int(re.search(r"#define ER_THREADS_ (\d+)", src).group(1))
+    waves_per_simd = threads // 256
+    assert waves_per_simd * granule(rec[0]["next_free_vgpr"]) <= left, (rec[0], vf[0], threads)
+    assert rec[0]["group_segment_fixed_size"] <= 160 * 1024 - 2 * vf[0]["group_segment_fixed_size"]  # (the sweep's two blocks take 153 of a CU's 160 KB of LDS: 6.9 KB are left)
