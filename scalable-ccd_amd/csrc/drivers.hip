@@ -473,7 +473,8 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
     if (with_helper) {
         sccd_ctx* const sc = c->side;
         c->records_gate_signal = sc->records_gate_wait = nullptr;
-        if (!lazy_ef && (lab_env().erec_late >= 2 || (lab_env().erec_late == 1 && (long long)m->nE + m->nF >= SCCD_RECORDS_GATE_MIN_ELEMENTS))) {
+        // (a rank of a multi-GPU job: its share of the mesh counts)
+        if (lab_env().erec_late >= 2 || (lab_env().erec_late == 1 && ((long long)m->nE + m->nF) / std::max(1, c->shard_count) >= SCCD_RECORDS_GATE_MIN_ELEMENTS)) {
             if (!c->records_gate.ev) SCCD_HIP(hipEventCreateWithFlags(&c->records_gate.ev, hipEventDisableTiming));
             c->records_gate.state.store(0, std::memory_order_relaxed);
             c->records_gate_signal = sc->records_gate_wait = gate_open.g = &c->records_gate;
