@@ -29,9 +29,21 @@
 
 namespace {
 
-constexpr int RS_THREADS = 256;
+// A tile of 4,096 keys is ranked by EIGHT waves of 8 rows (round 5, late; rounds 1-4: four waves of 16): at the sizes the broad phase sorts
+// a pass is a chain of latencies, not of bytes -- load, rank, stage and write all run over a wave's rows one after the other -- and twice
+// the waves per tile halve that part of it: os_pass_k 23.8 -> ~19 us at 1.9 M pairs, the step's sort class 0.226 -> 0.202 ms; 16 M keys: the
+// same (0.534 / 0.536 ms).  Sixteen waves of 4 rows: 66 KB of LDS per block, slower on both (0.25 ms; 0.64 ms).  103 registers: two blocks
+// per CU by registers (three by LDS: 50 KB), 512 tiles resident at once -- enough for the broad phase's ~460.
+// (RS_THREADS_ / RS_ITEMS_: tools/variants.sh)
+#ifndef RS_THREADS_
+#define RS_THREADS_ 512
+#endif
+#ifndef RS_ITEMS_
+#define RS_ITEMS_ 8
+#endif
+constexpr int RS_THREADS = RS_THREADS_;        // >= 256: thread d < 256 owns digit d
 constexpr int RS_WAVES = RS_THREADS / 64;
-constexpr int RS_ITEMS = 16;                   // rows of 64 keys per wave (8: -30 %, 24: +7 % at 16M keys but -10 % at 2-5M)
+constexpr int RS_ITEMS = RS_ITEMS_;            // rows of 64 keys per wave (256 threads x 8: -30 %, x 24: +7 % at 16M keys but -10 % at 2-5M)
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS; // 4096 keys per tile
 constexpr int RS_WAVE_SPAN = RS_ITEMS * 64;    // keys owned by one wave
 
@@ -289,9 +301,9 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restri
             *reinterpret_cast<uint4*>(wv + sgm * 256 + lane * 4) = pre.v[sgm];
         }
 #pragma unroll
-        for (int k = 0; k < RS_WAVES; k++) {
-            wtot[k][threadIdx.x] = 0;
-            wrun[k][threadIdx.x] = 0;
+        for (int k = 0; k < RS_WAVES * 256 / RS_THREADS; k++) { // (256 threads: thread d zeroes column d of every wave's row)
+            (&wtot[0][0])[k * RS_THREADS + threadIdx.x] = 0;
+            (&wrun[0][0])[k * RS_THREADS + threadIdx.x] = 0;
         }
         // request the next ticket (a launch with a block per tile has none to give: the broad phase's size, where the 400
         // wasted atomics on the one ticket word were a third of the 7 us a pass spends queueing there)
@@ -320,23 +332,29 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restri
             if (valid[r]) atomicAdd(&wtot[w][(key[r] >> shift) & 255u], 1u);
         __syncthreads();
         uint32_t cnt = 0;
-        uint32_t* my = status + (size_t)tile * 256 + threadIdx.x;
+        const bool dig = RS_THREADS == 256 || threadIdx.x < 256; // thread d < 256 owns digit d
+        uint32_t* my = status + (size_t)tile * 256 + (threadIdx.x & 255);
         {
-            const int d = threadIdx.x;
+            const int d = threadIdx.x & 255;
+            uint32_t incl = 0;
+            if (dig) {
 #pragma unroll
-            for (int k = 0; k < RS_WAVES; k++) {
-                const uint32_t t = wtot[k][d];
-                wtot[k][d] = cnt; // offset of wave k inside the digit's run
-                cnt += t;
+                for (int k = 0; k < RS_WAVES; k++) {
+                    const uint32_t t = wtot[k][d];
+                    wtot[k][d] = cnt; // offset of wave k inside the digit's run
+                    cnt += t;
+                }
+                __hip_atomic_store(my, cnt | OS_FLAG_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // exclusive scan of cnt over the 256 digits -> position of the digit's run inside the tile
+                incl = (uint32_t)wave_incl_scan((int)cnt);
+                if (lane == 63) dig_gbase[w] = incl; // scratch
             }
-            __hip_atomic_store(my, cnt | OS_FLAG_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // exclusive scan of cnt over the 256 digits -> position of the digit's run inside the tile
-            const uint32_t incl = (uint32_t)wave_incl_scan((int)cnt);
-            if (lane == 63) dig_gbase[w] = incl; // scratch
             __syncthreads();
-            uint32_t base = 0;
-            for (int k = 0; k < w; k++) base += dig_gbase[k];
-            dig_excl[d] = base + incl - cnt;
+            if (dig) {
+                uint32_t base = 0;
+                for (int k = 0; k < w; k++) base += dig_gbase[k];
+                dig_excl[d] = base + incl - cnt;
+            }
         }
         // 2. ranking (the predecessors' words propagate meanwhile)
         if (dbg & 2) {
@@ -354,7 +372,7 @@ __global__ __launch_bounds__(RS_THREADS) void os_pass_k(const uint32_t* __restri
         const uint32_t t1 = s_tk[1];
         if ((int)t1 < num_tiles) tile_load(pre, keys_in, vals_in, (long long)t1 * RS_TILE + (long long)w * RS_WAVE_SPAN, lane, n_load);
         // 3. decoupled look-back, thread d = digit d, eight predecessor tiles probed per round
-        {
+        if (dig) {
             const int d = threadIdx.x;
             uint32_t excl = 0;
             long long t = (long long)tile - 1;
@@ -442,7 +460,7 @@ bool radix_sort_pairs_u32(sccd_ctx* c, uint32_t* keys, uint32_t* vals, int64_t n
                        reinterpret_cast<uint4*>(base), (long long)((512 + status_bytes) / 16), passes, d_n_real);
     hipLaunchKernelGGL(os_bases_k, dim3(4), dim3(1024), 0, c->stream, partial, hist_blocks, bases);
     for (int pass = 0; pass < passes; pass++) {
-        constexpr int pass_blocks = 3; // resident blocks per CU (41 KB of LDS each)
+        constexpr int pass_blocks = 2; // resident blocks per CU (103 registers x 8 waves: two per CU; 50 KB of LDS each)
         // (tiles by block index only while at most one ccd() call's two contexts are alive: the argument for it is about two
         // concurrent sorts -- common.hpp live_context_count)
         const bool force_tickets = lab_env().sort_tickets || __atomic_load_n(&live_context_count(), __ATOMIC_RELAXED) > 2;
