@@ -31,7 +31,7 @@ namespace {
 
 // A tile of 4,096 keys is ranked by EIGHT waves of 8 rows (round 5, late; rounds 1-4: four waves of 16): at the sizes the broad phase sorts
 // a pass is a chain of latencies, not of bytes -- load, rank, stage and write all run over a wave's rows one after the other -- and twice
-// the waves per tile halve that part of it: os_pass_k 23.8 -> ~19 us at 1.9 M pairs, the step's sort class 0.226 -> 0.202 ms; 16 M keys: the
+// the waves per tile shorten that part of it: os_pass_k 23.8 -> 21.6 us at 1.9 M pairs alone (29 -> 26 in the step), the step's sort class 0.226 -> 0.197 ms; 16 M keys: the
 // same (0.534 / 0.536 ms).  Sixteen waves of 4 rows: 66 KB of LDS per block, slower on both (0.25 ms; 0.64 ms).  103 registers: two blocks
 // per CU by registers (three by LDS: 50 KB), 512 tiles resident at once -- enough for the broad phase's ~460.
 // (RS_THREADS_ / RS_ITEMS_: tools/variants.sh)
