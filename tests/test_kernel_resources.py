@@ -93,3 +93,20 @@ def test_edge_records_kernel_fits_beside_the_vertex_face_sweep(tmp_path):
     waves_per_simd = threads // 256
     assert waves_per_simd * granule(rec[0]["next_free_vgpr"]) <= left, (rec[0], vf[0], threads)
     assert rec[0]["group_segment_fixed_size"] <= 160 * 1024 - 2 * vf[0]["group_segment_fixed_size"]  # (the sweep's two blocks take 153 of a CU's 160 KB of LDS: 6.9 KB are left)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_sort_pass_keeps_two_blocks_per_cu(tmp_path):
+    # os_pass_k's tile is ranked by eight waves; radix_sort_pairs_u32 launches a block per tile, tiles by block index, while
+    # num_tiles <= 2 blocks per CU (`pass_blocks`) -- which assumes two 512-thread blocks ARE resident per CU: four waves per SIMD
+    # (<= 128 registers), <= 80 KB of LDS each
+    ks = {k: v for k, v in _kernels("sort", tmp_path).items() if "os_pass_k" in k}
+    assert len(ks) == 1
+    src = open(os.path.join(ROOT, "scalable-ccd_amd", "csrc", "sort.hip")).read()
+    threads = int(re.search(r"#define RS_THREADS_ (\d+)", src).group(1))
+    blocks = int(re.search(r"constexpr int pass_blocks = (\d+);", src).group(1))
+    for name, r in ks.items():
+        waves_per_simd = blocks * threads // 256
+        assert waves_per_simd * ((r["next_free_vgpr"] + 7) // 8 * 8) <= 512, (name, r, threads, blocks)
+        assert blocks * r["group_segment_fixed_size"] <= 160 * 1024, (name, r)
+        assert r["private_segment_fixed_size"] == 0, (name, r)
