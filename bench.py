@@ -316,13 +316,17 @@ def main():
         stats = {}
         toi = 1.0
         step_ms = []
+        dev_ms = []  # the DEVICE's own clock around each step (SCCD_OPT_DEVICE_SPAN_NS: first kernel's start .. the kernel behind the last read-back)
+        waits0 = ctx.get_option(sccd.OPT_HOST_WAITS)
         for _ in range(args.steps):
             ts = time.perf_counter()
             toi, stats = step()
             step_ms.append((time.perf_counter() - ts) * 1e3)  # (a step ends with its TOI on the host: the host clock sees all of it)
+            dev_ms.append(ctx.get_option(sccd.OPT_DEVICE_SPAN_NS) * 1e-6)
             q_local += stats["n_vf_pairs"] + stats["n_ee_pairs"]
         barrier()
         dt = time.perf_counter() - t0
+        host_waits_per_step = (ctx.get_option(sccd.OPT_HOST_WAITS) - waits0) / max(1, args.steps)
         if dev_min is not None:
             toi = dev_min.value()  # (the reduced word of the last step; every step of this frozen mesh has the same)
         prof = ctx.profile()
@@ -482,7 +486,10 @@ def main():
         broad = {"bytes_per_step": broad_bytes, "formula": "548 B x boxes + 8 B x pairs (SURVEY 8d)", "boxes": n_boxes,
                  "ms_passes_apart": round(broad_ms, 4), "achieved": round(broad_bytes / max(1e-9, broad_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
                  "peak": HBM_PEAK_GBS, "frac": round(broad_bytes / max(1e-9, broad_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                 "passes_apart": {k: round(v, 4) for k, v in prof_apart.items()}}
+                 "passes_apart": {k: round(v, 4) for k, v in prof_apart.items()},
+                 # the sort + scan class by SURVEY 8d's fixed credit (232 B per box: eight 8-bit passes of a 12-byte pair + histogram + scan), whatever the passes really run
+                 "sort_class": {"bytes_per_step": 232.0 * n_boxes, "ms": round(prof_apart["sort"], 4),
+                                "frac": round(232.0 * n_boxes / max(1e-9, prof_apart["sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
         # ---- the reference ccd()'s real entry cost (ccd.cu:103-106 uploads the mesh inside the call): sccd_ccd from pageable host matrices
         host_ms = None
         if world == 1:
@@ -497,6 +504,34 @@ def main():
                 sccd.ccd(hV0, hV1, hE, hF, 0.0, args.max_iter, 1e-6, True, ctx=ctx)
                 t_h.append((time.perf_counter() - th0) * 1e3)
             host_ms = round(min(t_h), 4)
+        # ---- THE BET OF THE TWO HALVES, PRICED IN THE DEFAULT LINE: the same mesh with the step cut to 0.6 -- the earliest
+        # impact at 0.68, behind the first half of time -- under the headline's terms (no history: every call takes the bet, and loses it here)
+        late_headline = None
+        if world == 1 and args.max_iter < 0 and args.jitter == 0.0:
+            m_late = sccd.Mesh(V0, V0 + 0.6 * (V1 - V0), E, F, ctx=ctx)
+            for _ in range(N_SETTLE + 2):
+                toi_late = sccd.ccd_mesh(m_late, **params)
+            lt = []
+            for _ in range(20):
+                tl0 = time.perf_counter()
+                sccd.ccd_mesh(m_late, **params)
+                lt.append((time.perf_counter() - tl0) * 1e3)
+            ctx.set_option(sccd.OPT_TWO_HALVES, 0)
+            for _ in range(N_SETTLE):
+                sccd.ccd_mesh(m_late, **params)
+            lo = []
+            for _ in range(20):
+                tl0 = time.perf_counter()
+                sccd.ccd_mesh(m_late, **params)
+                lo.append((time.perf_counter() - tl0) * 1e3)
+            ctx.set_option(sccd.OPT_TWO_HALVES, args.two_halves if args.two_halves is not None else 1)
+            late_headline = {"step_scale": 0.6, "toi": toi_late, "ms_per_step": round(sum(lt) / len(lt), 4), "ms_per_step_p50": round(sorted(lt)[len(lt) // 2], 4),
+                             "one_launch_ms_per_step": round(sum(lo) / len(lo), 4), "one_launch_ms_per_step_p50": round(sorted(lo)[len(lo) // 2], 4),
+                             "note": "the headline's mesh with its motion cut to 0.6 (earliest impact behind 0.5), history off like the headline: the default settings "
+                                     "(two launches per pass, a bet on an early impact, lost here) against SCCD_OPT_TWO_HALVES = 0; 20 steps each"}
+            m_late.close()
+            for _ in range(N_SETTLE):
+                step()
         cliffs = None
         if args.cliffs and world == 1:
             def best(fn, reps=3):
@@ -519,6 +554,7 @@ def main():
             cliffs["collisions_max_iter_1e7_host_path_ms"] = best(lambda: sccd.ccd(hV0, hV1, hE, hF, 0.0, 10_000_000, 1e-6, True, ctx=ctx, want_collisions=True))
             cliffs["collisions_max_iter_1000_host_path_ms"] = best(lambda: sccd.ccd(hV0, hV1, hE, hF, 0.0, 1000, 1e-6, True, ctx=ctx, want_collisions=True))
             cliffs["max_iter_1e7_step_ms"] = best(lambda: sccd.ccd_mesh(mesh, 0.0, 10_000_000, 1e-6, True), 5)
+            cliffs["ipc_ccd_strategy_max_iter_1e7_host_path_ms"] = best(lambda: sccd.ipc_ccd_strategy(hV0, hV1, hE, hF, 0.0, 10_000_000, 1e-6, ctx=ctx))
             ctx.set_option(sccd.OPT_LIMIT_LEVEL_ORDER, 1)
             cliffs["max_iter_1e7_level_order_step_ms"] = best(lambda: sccd.ccd_mesh(mesh, 0.0, 10_000_000, 1e-6, True), 2)
             ctx.set_option(sccd.OPT_LIMIT_LEVEL_ORDER, 0)
@@ -555,6 +591,7 @@ def main():
                            parallelism=f"cell windows sharded over {world} GPU(s), one RCCL all-reduce(min) of the TOI per step",
                            rccl_ranks=rccl_ranks, backend=(backend if use_dist else "none"),
                            projection_cull=int(ctx.get_option(sccd.OPT_CULL)), two_halves_of_time=int(ctx.get_option(sccd.OPT_TWO_HALVES)), culled_per_step=int(stats.get("n_vf_culled", 0) + stats.get("n_ee_culled", 0)),
+                           value_counts_culled_pairs=True,
                            history=0,
                            history_note="value / ms_per_step: SCCD_OPT_TOI_GUESS = 0 -- no call uses anything of the call before it (neither the TOI bound nor the choice "
                                         "between one and two narrow launches per pass: with history off every call runs the two halves of time, a bet on an impact before 0.5 -- "
@@ -565,7 +602,19 @@ def main():
             # schema 3 (round 5): value / ms_per_step are steps that start from toi = 1 (SCCD_OPT_TOI_GUESS = 0, as ccd.cu:125); every
             # timed step is also clocked on its own (ms_per_step_p50 / p99 / min / max: host clock around a step, which ends with its TOI
             # on the host); the speculative TOI bound has its own block (toi_guess.ms_per_step_with)
-            "schema": 3,
+            # schema 4 (round 6): what is credited stands at the top level -- ms_per_step (mean, the driver's figure), its median, the
+            # DEVICE's own span per step beside the host's clock, inclusion checks per second (the work that is left: `value` counts the
+            # culled pairs as answered queries), and the lost bet of the two halves (late_impact)
+            "schema": 4,
+            "checks_per_s": float(qq[1].item()) / (dt / args.steps),
+            "device_span_ms": {"p50": round(sorted(dev_ms)[len(dev_ms) // 2], 4), "p99": round(sorted(dev_ms)[min(len(dev_ms) - 1, int(len(dev_ms) * 0.99))], 4),
+                               "max": round(max(dev_ms), 4), "mean": round(sum(dev_ms) / len(dev_ms), 4),
+                               "note": "the device's real-time clock from the start of a step's first kernel to the end of the kernel behind the last read-back the host "
+                                       "waited for (SCCD_OPT_DEVICE_SPAN_NS); host clock minus this = what the host added in front of the first launch and behind the last"},
+            "slowest_steps": [{"step": i, "host_ms": round(step_ms[i], 4), "device_ms": round(dev_ms[i], 4)}
+                              for i in sorted(range(len(step_ms)), key=lambda k: -step_ms[k])[:3]],
+            "host_waits_per_step": host_waits_per_step,
+            "late_impact": late_headline,
             "ms_per_step_p50": round(sorted(step_ms)[len(step_ms) // 2], 4),
             "ms_per_step_p99": round(sorted(step_ms)[min(len(step_ms) - 1, int(len(step_ms) * 0.99))], 4),
             "ms_per_step_min": round(min(step_ms), 4), "ms_per_step_max": round(max(step_ms), 4),

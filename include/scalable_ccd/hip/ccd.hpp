@@ -68,6 +68,9 @@ class Context {
 public:
     explicit Context(int device = 0)
     {
+        // (the library writes sccd_stats and the profile arrays into memory sized by THIS header: refuse one built from another)
+        if (sccd_abi_sizeof_stats() != sizeof(sccd_stats) || sccd_abi_prof_count() != SCCD_PROF_COUNT)
+            throw std::runtime_error(std::string("libsccd_hip.so (") + sccd_version() + ") was built from another include/sccd.h");
         if (sccd_create(device, &m_ctx) != SCCD_OK)
             throw std::runtime_error(std::string("sccd_create: ") + sccd_last_error(nullptr));
     }

@@ -63,6 +63,12 @@ typedef struct sccd_collision {
  *  alive in the process -- a context and the helper context its ccd() makes are two -- the radix sort's passes take their tiles by
  *  atomic ticket instead of by block index, ~2 us per pass slower: the block-index form is only argued for two concurrent sorts.) */
 int sccd_create(int device, sccd_ctx** out);
+/* ABI CHECK.  sccd_stats and the SCCD_PROF_* arrays are written by the library into memory the caller sized at ITS compile time
+ * (sccd_ccd_mesh*, sccd_get_profile): a caller built against another version of this header compares sizeof(sccd_stats) and
+ * SCCD_PROF_COUNT with what the loaded library was built with before it hands such memory over (0.2 -> 0.3 grew both without a
+ * way to ask; the Python binding and include/scalable_ccd/hip/ccd.hpp refuse a library that disagrees). */
+size_t sccd_abi_sizeof_stats(void);
+int sccd_abi_prof_count(void);
 void sccd_destroy(sccd_ctx* ctx);
 const char* sccd_last_error(const sccd_ctx* ctx);
 const char* sccd_version(void);
@@ -109,7 +115,8 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        * redone from 1); 0: always from 1, as ccd.cu:125.  The same history also settles SCCD_OPT_TWO_HALVES' bet. */
 #define SCCD_OPT_TOI_GUESS_HITS 20    /* read: calls whose bound held / broke (redone); setting either resets both */
 #define SCCD_OPT_TOI_GUESS_MISSES 21
-#define SCCD_OPT_CULL 24              /* sccd_ccd / sccd_ccd_mesh / sccd_ccd_mesh_pass (double build, no check limit): 1 (default) the overlap pairs of a pass
+#define SCCD_OPT_CULL 24              /* sccd_ccd / sccd_ccd_mesh / sccd_ccd_mesh_pass / sccd_ipc_ccd_strategy (double build; since 0.4 with or without a
+                                       * check limit -- a culled pair has no acceptable domain under any traversal): 1 (default) the overlap pairs of a pass
                                        * go through the PROJECTION CULL before the bisection -- a pair is dropped if some direction d puts the eight
                                        * corner values of d . F (F: the collision function, affine in each of t, u, v) all beyond the reach of any
                                        * domain the reference's bisection could accept (csrc/narrow_cull.inc): the result is unchanged, the narrow
@@ -129,6 +136,12 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        * same mesh did not return a TOI >= 0.5; 2: always. */
 #define SCCD_OPT_ALLOC_COUNT 23       /* read: device allocations the library's grow-only buffers have made since it was loaded (all contexts): a call
                                        * during which the count rises has grown a buffer -- hipFree + hipMalloc, milliseconds */
+#define SCCD_OPT_DEVICE_SPAN_NS 26    /* read: what the DEVICE spent on the last sccd_ccd / sccd_ccd_mesh* call of this context, in nanoseconds of its own
+                                       * real-time clock: from the start of the call's first kernel to the end of the kernel behind the last read-back
+                                       * the host waited for (-1: no such call yet).  Beside the caller's own clock it separates a step the chip was
+                                       * slow on from a step the host was late for (bench.py: device_span_ms) */
+#define SCCD_OPT_HOST_WAITS 27        /* read: how often the host has waited for the device (read-backs of counters, early verdicts) since the context
+                                       * was made, its helper context included: the difference across a call is the number of host round trips in it */
 #define SCCD_OPT_SPEC_HITS 15   /* read: speculative builds (sort, records and sweep enqueued for the previous build's entry counts) whose */
 #define SCCD_OPT_SPEC_MISSES 16 /* guess held / broke and were redone, since the context was made; setting either resets both counters */
 int sccd_set_option(sccd_ctx* ctx, int option, int64_t value);
@@ -251,6 +264,11 @@ int sccd_query_cull_slab(sccd_ctx* ctx, const sccd_mesh* mesh, const int32_t* pa
 
 /* ccd(V0,V1,E,F,min_distance,max_iterations,tolerance,allow_zero_toi,memory_limit_GB):
  * src/scalable_ccd/cuda/ccd.cuh:26-38 / ccd.cu:80-146.  Host matrices in, earliest TOI out.
+ * STATEFUL BY DEFAULT (SCCD_OPT_TOI_GUESS = 1): the RESULT never depends on earlier calls, the LATENCY does -- a call on the mesh
+ * object and sizes of the previous call of this context starts from 1.125 x that call's TOI (and is redone from 1 if nothing lies
+ * below the bound: exact either way) and settles SCCD_OPT_TWO_HALVES' bet by that call's result; broad-phase buffers and the
+ * speculative build's entry counts are kept from call to call as well (the first call on a context allocates and builds the slow
+ * way).  SCCD_OPT_TOI_GUESS = 0 makes every call start from 1 as ccd.cu:125 does; sccd_ccd_mesh_from takes the caller's bound.
  * (The matrices go into a mesh the context owns and refills call after call; an index out of range is reported when the
  *  call ends -- the step has then run on indices clamped to 0, and its result is discarded.) */
 int sccd_ccd(sccd_ctx* ctx, const double* V0, const double* V1, int nV, const int32_t* E, int nE,

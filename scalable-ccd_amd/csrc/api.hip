@@ -66,7 +66,12 @@ __global__ __launch_bounds__(256) void readback_gather_k(ReadBackItems it, unsig
     __syncthreads();
     // (round 5, ADVICE r04: the word itself is a RELEASE store at system scope -- buffer_wbl2 sc0 sc1 in front of it, the write-back
     // half of a fence without the invalidate that hurt: 0.8446 against 0.8458 ms per step over three A/B rounds, eight registers still)
-    if (lane == 0) __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (... and, in front of it, the device's real-time clock: the END of a ccd() step for the host's account of where a slow step's
+    // time went -- sccd_ctx::step_stamp, SCCD_OPT_DEVICE_SPAN_NS)
+    if (lane == 0) {
+        __hip_atomic_store(seq_word + 9, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 void readback_gather_launch(sccd_ctx* c, const ReadBackItems& it, unsigned long long seq)
 {
@@ -77,7 +82,9 @@ void readback_gather_launch(sccd_ctx* c, const ReadBackItems& it, unsigned long 
 
 extern "C" {
 
-const char* sccd_version(void) { return "sccd-hip 0.3 (gfx950)"; } // 0.3: sccd_stats grew (n_*_culled), SCCD_OPT_CULL; 0.2: default contract fused, option id 12 retired
+const char* sccd_version(void) { return "sccd-hip 0.4 (gfx950)"; } // 0.4: sccd_abi_*, SCCD_OPT_DEVICE_SPAN_NS / _HOST_WAITS, the cull under check limits; 0.3: sccd_stats grew (n_*_culled), SCCD_OPT_CULL; 0.2: default contract fused, option id 12 retired
+size_t sccd_abi_sizeof_stats(void) { return sizeof(sccd_stats); }
+int sccd_abi_prof_count(void) { return SCCD_PROF_COUNT; }
 
 int sccd_create(int device, sccd_ctx** out)
 {
@@ -99,6 +106,9 @@ int sccd_create(int device, sccd_ctx** out)
         hipDeviceProp_t prop;
         SCCD_HIP(hipGetDeviceProperties(&prop, device));
         c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        int khz = 0; // (the clock behind s_memrealtime: sccd_ctx::device_span_ns)
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wall_clock_khz = khz;
+        else (void)hipGetLastError();
         SCCD_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
         c->scalars.ensure(4096);
@@ -248,6 +258,8 @@ int64_t sccd_get_option(const sccd_ctx* c, int opt)
     case SCCD_OPT_TOI_GUESS_MISSES: return c->toi_guess_misses;
     case SCCD_OPT_SPEC_HITS: return c->spec_hits + (c->side ? c->side->spec_hits : 0);
     case SCCD_OPT_SPEC_MISSES: return c->spec_misses + (c->side ? c->side->spec_misses : 0);
+    case SCCD_OPT_DEVICE_SPAN_NS: return c->device_span_ns;
+    case SCCD_OPT_HOST_WAITS: return c->host_waits + (c->side ? c->side->host_waits : 0);
     default: return 0;
     }
 }

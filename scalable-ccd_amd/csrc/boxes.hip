@@ -146,8 +146,12 @@ struct StatsAcc {
 // nextafterf and float sums; the float results are stored widened (every later comparison is exact on them)
 template <bool F32>
 __global__ void vertex_boxes_k(const double* __restrict__ V, int nV, double r, sccd_aabb* __restrict__ out,
-                               GridStats* __restrict__ st, double* __restrict__ part)
+                               GridStats* __restrict__ st, double* __restrict__ part, unsigned long long* __restrict__ t_first)
 {
+    // t_first (may be null; host-coherent pinned memory): the device's real-time clock as the FIRST kernel of a ccd() step starts --
+    // the step's other end is stamped by the kernel behind its last read-back (api.hip readback_gather_k): sccd_ctx::step_stamp
+    if (t_first && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(t_first, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     StatsAcc acc;
     const double ru = nextafter_up(r);
     const float ru_f = nextafter_up_f((float)r);
@@ -970,8 +974,10 @@ int launch_vertex_boxes(sccd_ctx* c, const double* dV, int nV, double inflation,
 {
     if (nV == 0) return 0;
     const int grid = std::min(grid_for(nV), SCCD_STATS_BLOCKS);
-    if (c->scalar_f32) hipLaunchKernelGGL(vertex_boxes_k<true>, dim3(grid), dim3(TPB), 0, c->stream, dV, nV, inflation, out, st, part);
-    else hipLaunchKernelGGL(vertex_boxes_k<false>, dim3(grid), dim3(TPB), 0, c->stream, dV, nV, inflation, out, st, part);
+    unsigned long long* const t_first = c->step_stamp_armed ? reinterpret_cast<unsigned long long*>(c->mailbox_dev + SCCD_MAILBOX_BYTES + 64) : nullptr;
+    c->step_stamp_armed = false; // (one stamp per step: its first kernel)
+    if (c->scalar_f32) hipLaunchKernelGGL(vertex_boxes_k<true>, dim3(grid), dim3(TPB), 0, c->stream, dV, nV, inflation, out, st, part, t_first);
+    else hipLaunchKernelGGL(vertex_boxes_k<false>, dim3(grid), dim3(TPB), 0, c->stream, dV, nV, inflation, out, st, part, t_first);
     SCCD_HIP(hipGetLastError());
     return grid;
 }

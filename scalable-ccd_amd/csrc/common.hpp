@@ -260,6 +260,16 @@ struct sccd_ctx {
     unsigned long long verdict_seq = 0; // the number the next verdict carries
     bool verdict_armed = false;         // narrow_phase_begin enqueued one for narrow_phase_end to look at
     unsigned long long rb_seq = 0;
+    // THE DEVICE'S OWN ACCOUNT OF A ccd() STEP (SCCD_OPT_DEVICE_SPAN_NS): the first kernel of the step stores the device's real-time
+    // clock into the mailbox's tail (boxes.hip vertex_boxes_k), every read-back kernel and early verdict stores it again behind its
+    // items (api.hip readback_gather_k, narrow_walk.inc np_second_half_k); the span between the first and the LAST of them, in this
+    // context and its helper, is what the device spent on the step -- beside the host's clock it tells a step the chip was slow on
+    // from a step the host was late for (bench.py device_span_ms)
+    bool step_stamp_armed = false;          // the next vertex-box launch carries the first stamp
+    unsigned long long step_t_last = 0;     // the latest end stamp a read-back of this context has seen since the step began
+    long long device_span_ns = -1;          // of the last ccd() call on a mesh (-1: none yet)
+    int wall_clock_khz = 100000;            // the rate of that clock (hipDeviceAttributeWallClockRate)
+    long long host_waits = 0;               // SCCD_OPT_HOST_WAITS: read-backs and early verdicts the host has waited for since the context was made (its helper counts its own)
     DevBuf np_scratch0, np_scratch1, np_scratch2, np_scratch3, np_scratch4, np_scratch3_ovf;
     DevBuf tmp0, tmp1, tmp2;
     struct sccd_mesh* scratch_mesh = nullptr; // the mesh behind the host-matrix drivers (api.hip: scratch_mesh_from_host)
@@ -349,6 +359,7 @@ struct ReadBack {
     }
     void sync()
     {
+        c->host_waits += 1;
         const char* from = c->h_scalars.as<char>();
         if (gather) {
             from = c->mailbox.as<char>();
@@ -380,6 +391,11 @@ struct ReadBack {
             }
         }
         for (int i = 0; i < n; i++) std::memcpy(items[i].dst, from + items[i].off, items[i].bytes);
+        if (gather) { // (the end stamp the gather kernel left in front of its sequence word: sccd_ctx::step_t_last)
+            unsigned long long t_end;
+            std::memcpy(&t_end, from + SCCD_MAILBOX_BYTES + 72, sizeof t_end);
+            if (t_end > c->step_t_last) c->step_t_last = t_end;
+        }
         n = 0;
         off = 0;
     }

@@ -35,8 +35,13 @@ static void pass_lists(const sccd_broad_phase* bp, NarrowParams* p)
         p->second.t_hi = bp->cull.slabs.t_end;
     }
 }
-// ... and whether a pass of ccd() culls at all: the double build's walk kernel without a check limit (the certificate of a limit,
-// the level-order kernels and the float build keep the reference's own list: their counts and fallbacks are defined on it).
+// ... and whether a pass of ccd() culls at all: the double build, with or without a check limit (SCCD_OPT_NARROW_ALGO = 1 and the
+// float build keep the reference's own list).  A CHECK LIMIT changes nothing about the cull's claim: a culled query has no domain
+// that passes the inclusion test behind an acceptance (narrow_cull.inc), whatever the order of the traversal and wherever a limit
+// cuts it off; the reference counts a query's checks per query (root_finder.cu:287-305) and prunes by a TOI only accepted domains
+// lower, so a query that accepts nothing changes neither another query's count nor the running TOI -- the limited level-order
+// result on the kept list IS the result on the whole list (the certificate and the level-order fallback of narrow.hip run on the
+// kept list; only the number of checks differs).  One slab, [0, toi]: launches with a limit are single ones (narrow_start_toi).
 // toi: the pass's narrow launches start from this TOI at most -- the slabs of time the cull looks at (narrow_cull_slabs)
 static NarrowParams narrow_params(sccd_ctx* c, const sccd_mesh* m, const int2* d_pairs, int64_t n, int is_vf, int max_iter,
                                   double tol, double ms, int allow_zero_toi);
@@ -45,7 +50,7 @@ static void pass_cull_setup(sccd_ctx* c, sccd_broad_phase* bp, const sccd_mesh* 
     // (SCCD_OPT_CULL = 1: where it pays -- the cull is a launch per sweep, ~5 us of a small step's latency chain; measured on folded
     // cloths and the cloth-on-ball scenes: a gain from ~20,000 triangles on, a loss of 15 us at 10,000.  2: always)
     const bool big_enough = c->cull_on >= 2 || (long long)m->nE + m->nF >= SCCD_CULL_MIN_ELEMENTS;
-    bp->cull.on = c->cull_on && big_enough && !c->scalar_f32 && max_iter < 0 && c->narrow_algo != 1 && std::isfinite(tol) && tol > 0 && ms >= 0;
+    bp->cull.on = c->cull_on && big_enough && !c->scalar_f32 && c->narrow_algo != 1 && std::isfinite(tol) && tol > 0 && ms >= 0;
     bp->cull.mesh = m;
     bp->cull.is_vf = vf ? 1 : 0;
     bp->cull.ms = ms;
@@ -343,6 +348,29 @@ static void ccd_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, sccd_broad_p
 
 static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter, double tol, int allow_zero_toi, double toi0,
                              double* toi_out, sccd_stats* st, bool* lists_resident);
+
+// The device's own clock around one ccd() call on a mesh (sccd_ctx::device_span_ns): armed here, stamped by the call's first kernel and
+// by the kernels behind its read-backs, read when the call is over -- whatever way it went (redone from 1, rebuilt, chunked).
+struct StepSpan {
+    sccd_ctx* c;
+    explicit StepSpan(sccd_ctx* ctx) : c(ctx)
+    {
+        c->step_stamp_armed = true;
+        c->step_t_last = 0;
+        if (c->side) c->side->step_t_last = 0;
+        c->device_span_ns = -1;
+    }
+    ~StepSpan()
+    {
+        const bool stamped = !c->step_stamp_armed; // (a call that launched no vertex boxes -- an empty mesh -- has no span)
+        c->step_stamp_armed = false;
+        if (!stamped || !c->mailbox.p) return;
+        unsigned long long t0;
+        std::memcpy(&t0, c->mailbox.as<char>() + SCCD_MAILBOX_BYTES + 64, sizeof t0);
+        const unsigned long long t1 = std::max(c->step_t_last, c->side ? c->side->step_t_last : 0ull);
+        if (t1 > t0) c->device_span_ns = (long long)((double)(t1 - t0) * 1e6 / (double)std::max(1, c->wall_clock_khz));
+    }
+};
 
 // ccd() of ccd.cu:80-146 on a resident mesh.  THE SPECULATIVE BOUND (round 4): the reference starts every call from toi = 1
 // (ccd.cu:125) and the vertex-face pass then runs without a bound until its first contact query has been bisected to the end --
@@ -659,6 +687,13 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
                     both_done = true;
                 } else { // (the edge-edge overlaps come in chunks: finish the vertex-face pass, then chunk by chunk as usual)
                     c->np_peer_stream = nullptr;
+                    if (early) {
+                        // the walk kernel that went into the helper's stream ahead of the count is still there, on a list that is
+                        // about to be made again chunk by chunk (same buffers, same counters): let it drain, and forget its verdict
+                        // (whatever it put into a running TOI is an accepted domain of a true pair -- nothing to take back)
+                        SCCD_HIP(hipStreamSynchronize(sc->stream));
+                        sc->verdict_armed = false;
+                    }
                     narrow_phase_end(c, pv, narrow_counters(c), &toi_vf, nullptr);
                     const NarrowResult rv = narrow_result(c);
                     toi = toi_vf;
@@ -734,6 +769,7 @@ extern "C" int sccd_ccd_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max
     if (!c || !m || !toi) return SCCD_E_INVALID;
     return guarded(c, [&] {
         SCCD_REQUIRE(m->ctx == c, "ccd: mesh belongs to another context");
+        StepSpan span(c);
         ccd_on_mesh(c, m, ms, max_iter, tol, allow_zero_toi, toi, stats);
     });
 }
@@ -757,6 +793,7 @@ extern "C" int sccd_ccd_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, in
         c->two_halves_off = (c->two_halves == 1 && (long long)m->nE + m->nF < SCCD_TWO_HALVES_MIN_ELEMENTS) ? 1 : 0;
         const double b = c->scalar_f32 ? (double)(float)bound : bound; // (the value the float build's kernels start from: ccd_on_mesh)
         double t = 1.0;
+        StepSpan span(c);
         ccd_on_mesh_from(c, m, ms, max_iter, tol, allow_zero_toi, max_iter < 0 ? b : 1.0, &t, stats, nullptr);
         c->toi_guess_mesh = nullptr; // (the context's own history knows nothing of this call)
         *toi = t;
@@ -771,7 +808,10 @@ extern "C" int sccd_ccd_mesh_dev(sccd_ctx* c, const sccd_mesh* m, double ms, int
     return guarded(c, [&] {
         SCCD_REQUIRE(m->ctx == c, "ccd: mesh belongs to another context");
         double t = toi ? *toi : 1.0;
-        ccd_on_mesh(c, m, ms, max_iter, tol, allow_zero_toi, &t, stats);
+        {
+            StepSpan span(c);
+            ccd_on_mesh(c, m, ms, max_iter, tol, allow_zero_toi, &t, stats);
+        }
         // (the slot is rewritten by the next call's end at the earliest: that call has synchronised with this stream by then)
         double* const slot = reinterpret_cast<double*>(c->h_scalars.as<char>() + TOI_OUT_MIRROR);
         *slot = t;
@@ -876,17 +916,22 @@ extern "C" int sccd_ccd_collisions(sccd_ctx* c, const double* V0, const double* 
 static void ipc_pass(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, bool vf, double ms, int max_iter, double tol,
                      double* earliest)
 {
-    pl->bp.cull.on = false; // (check limits: the reference's own list)
+    // THE PROJECTION CULL serves both runs of a chunk: the list kept for (ms, the slab [0, earliest]) is a superset of what the
+    // conservative re-run -- ms = 0, the same start -- could need: the cull's threshold grows with the minimum separation (ms itself
+    // and the larger error filter of root_finder.cu:97-113), so a pair beyond reach under ms is beyond reach without it
+    pass_cull_setup(c, &pl->bp, m, vf, ms, max_iter, tol, *earliest);
     if (vf) bp_build(&pl->bp, &pl->vb, &pl->fb);
     else bp_build(&pl->bp, &pl->eb, nullptr);
     while (pl->bp.cursor < pl->bp.total_rows) {
+        if (pl->bp.cull.on) // (every chunk's cull looks at what is left of the step)
+            pl->bp.cull.slabs = narrow_cull_slabs(c, narrow_params(c, m, nullptr, 0, vf ? 1 : 0, max_iter, tol, ms, 1), *earliest);
         bp_detect_partial(&pl->bp);
         const double before = *earliest;
-        run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, vf ? 1 : 0, max_iter, tol, ms,
+        run_narrow(c, m, pass_pairs(&pl->bp), pass_count(&pl->bp), vf ? 1 : 0, max_iter, tol, ms,
                    /*allow_zero_toi=*/1, earliest, nullptr);
         if (*earliest < 1e-6) { // :72-91: conservative re-run without minimum separation
             *earliest = before;
-            run_narrow(c, m, pl->bp.overlaps.as<int2>(), pl->bp.n_overlaps, vf ? 1 : 0, /*max_iter=*/-1, tol,
+            run_narrow(c, m, pass_pairs(&pl->bp), pass_count(&pl->bp), vf ? 1 : 0, /*max_iter=*/-1, tol,
                        /*ms=*/0.0, /*allow_zero_toi=*/0, earliest, nullptr);
             *earliest *= 0.8;
         }

@@ -697,6 +697,7 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
     SCCD_REQUIRE(*h_toi_inout >= 0, "narrow_phase: toi must be >= 0");
     c->np_limit_fast = false; // (context-sticky between begin and end: a begin whose end never came must not leave it set)
     c->np_pq_limit = false;
+    c->verdict_armed = false; // (... nor an early verdict of a launch nobody ended: its word is an OLD call's -- ADVICE r05)
     // pinned mirror: [8 KB, 12 KB) the counters handed to the caller, [12 KB, 16 KB) the upload source
     // (two halves of time, narrow_walk.inc: the counters start from 0.5, the walk kernel's second launch goes on from the caller's TOI)
     const double start_toi = narrow_start_toi(c, p, *h_toi_inout, d_per_query_toi != nullptr);
@@ -801,6 +802,7 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
         // between the halves has run.  It found its impact: that is the pass's result -- what is still enqueued behind that kernel
         // finds nothing to do and is not waited for (the stream orders the next call behind it).  It did not: the whole stream, as before.
         c->verdict_armed = false;
+        c->host_waits += 1;
         const char* const from = c->verdict.as<char>();
         const unsigned long long* const word = reinterpret_cast<const unsigned long long*>(from + 2048);
         const unsigned long long want = c->verdict_seq;
@@ -816,6 +818,9 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
         if (arrived) {
             std::memcpy(&h, from, sizeof h);
             have = h.second_go == 0u;
+            unsigned long long t_end; // (np_second_half_k's stamp: the step's end if this verdict is what the host returns on)
+            std::memcpy(&t_end, from + 2056, sizeof t_end);
+            if (have && t_end > c->step_t_last) c->step_t_last = t_end;
         }
     }
     if (!have) {
@@ -917,36 +922,50 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
             SCCD_HIP(hipMemcpyAsync(&h.toi_bits, &d_cnt->toi_bits, 8, hipMemcpyDeviceToHost, c->stream));
             SCCD_HIP(hipStreamSynchronize(c->stream));
         }
-        const unsigned cap = (unsigned)std::min<long long>(n, 1 << 20);
-        auto level_all = [&]() {
-            NarrowCounters h2;
-            std::memset(&h2, 0, sizeof h2);
-            h2.toi_bits = h.toi_bits; // (what was found so far stays valid)
-            SCCD_HIP(hipMemcpyAsync(d_cnt, &h2, sizeof h2, hipMemcpyHostToDevice, c->stream));
-            if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi);
-            else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi);
-        };
-        bool done = false;
-        {
+        // THE SECOND HALF'S OWN LIST (two halves of time with a cull per slab: run_walk).  Its launch was a plain one over
+        // p.second.kept -- pairs the first half's list need not hold -- and a query it dropped raised the same flag: that list is
+        // redone like the pass's own, from what is known by then (the fallback looked at p.pairs only, and a query
+        // that lived in the second list alone was never bisected to the end).
+        const bool second_ran = p.second.src != nullptr && h.second_go != 0u;
+        const bool no_list_yet = (h.overflow & NQ_OVF_INTERVAL) != 0u;
+        // one list of the pass: [bookkeeping pass that names the queries] -> those queries in level order -> (failing that) the whole
+        // list in level order; h carries the TOI reached and the checks counted so far in, and out
+        auto redo_list = [&](const NarrowParams& pl, long long nl, bool list_ready) {
+            if (nl <= 0) return;
+            const unsigned cap = (unsigned)std::min<long long>(nl, 1 << 20);
+            auto level_all = [&]() {
+                NarrowCounters h2;
+                std::memset(&h2, 0, sizeof h2);
+                h2.toi_bits = h.toi_bits; // (what was found so far stays valid)
+                SCCD_HIP(hipMemcpyAsync(d_cnt, &h2, sizeof h2, hipMemcpyHostToDevice, c->stream));
+                SCCD_HIP(hipStreamSynchronize(c->stream)); // (h2 is on the stack)
+                if (pl.is_vf) run_level_sync<true>(c, pl, d_cnt, nl, d_per_query_toi);
+                else run_level_sync<false>(c, pl, d_cnt, nl, d_per_query_toi);
+            };
+            bool done = false;
             c->np_scratch3_ovf.ensure(sizeof(int) * (size_t)cap);
             int* d_list = c->np_scratch3_ovf.as<int>();
             unsigned long long checks_so_far = h.n_checks;
-            if (h.overflow & NQ_OVF_INTERVAL) { // no usable list yet: the bookkeeping pass, seeded with the TOI reached
+            unsigned ovf = h.overflow, n_ovf = h.n_ovf;
+            if (!list_ready) { // no usable list yet: the bookkeeping pass, seeded with the TOI reached
                 NarrowCounters h2;
                 std::memset(&h2, 0, sizeof h2);
                 h2.toi_bits = h.toi_bits;
                 SCCD_HIP(hipMemcpyAsync(d_cnt, &h2, sizeof h2, hipMemcpyHostToDevice, c->stream));
-                run_walk(c, p, d_cnt, n, reinterpret_cast<unsigned long long*>(d_per_query_toi), d_list, cap);
+                SCCD_HIP(hipStreamSynchronize(c->stream)); // (h2 is on the stack)
+                run_walk(c, pl, d_cnt, nl, reinterpret_cast<unsigned long long*>(d_per_query_toi), d_list, cap);
                 SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
-                if (p.toi_word) SCCD_HIP(hipMemcpyAsync(&h.toi_bits, p.toi_word, 8, hipMemcpyDeviceToHost, c->stream));
+                if (pl.toi_word) SCCD_HIP(hipMemcpyAsync(&h.toi_bits, pl.toi_word, 8, hipMemcpyDeviceToHost, c->stream));
                 SCCD_HIP(hipStreamSynchronize(c->stream));
                 for (int k = 0; k < 8; k++) h.n_checks += h.checks_part[k].n;
                 h.n_checks += checks_so_far;
                 checks_so_far = h.n_checks;
+                ovf = h.overflow;
+                n_ovf = h.n_ovf;
             }
-            if (!h.overflow && h.n_ovf <= cap) {
-                if (h.n_ovf > 0) {
-                    std::vector<int> ids(h.n_ovf);
+            if (!ovf && n_ovf <= cap) {
+                if (n_ovf > 0) {
+                    std::vector<int> ids(n_ovf);
                     SCCD_HIP(hipMemcpyAsync(ids.data(), d_list, sizeof(int) * ids.size(), hipMemcpyDeviceToHost, c->stream));
                     SCCD_HIP(hipStreamSynchronize(c->stream));
                     std::sort(ids.begin(), ids.end()); // (a query shared among lanes is listed by each of them)
@@ -957,24 +976,43 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
                     h2.toi_bits = h.toi_bits;
                     SCCD_HIP(hipMemcpyAsync(d_cnt, &h2, sizeof h2, hipMemcpyHostToDevice, c->stream));
                     SCCD_HIP(hipStreamSynchronize(c->stream)); // (h2 and ids are on the stack)
-                    if (c->scalar_f32 && p.max_iter < 0) { // (the list holds at most 2^20 queries: 4 GB of stacks at the very most)
+                    if (c->scalar_f32 && pl.max_iter < 0) { // (the list holds at most 2^20 queries: 4 GB of stacks at the very most)
                         // the float build: the listed queries depth first on explicit float boxes (np_dfs_f32_k) -- no level of
                         // theirs has to fit anywhere
-                        run_dfs_f32(c, p, d_cnt, d_list, (unsigned)ids.size(), reinterpret_cast<unsigned long long*>(d_per_query_toi));
-                    } else if (p.is_vf) run_level_sync<true>(c, p, d_cnt, n, d_per_query_toi, d_list, (long long)ids.size());
-                    else run_level_sync<false>(c, p, d_cnt, n, d_per_query_toi, d_list, (long long)ids.size());
+                        run_dfs_f32(c, pl, d_cnt, d_list, (unsigned)ids.size(), reinterpret_cast<unsigned long long*>(d_per_query_toi));
+                    } else if (pl.is_vf) run_level_sync<true>(c, pl, d_cnt, nl, d_per_query_toi, d_list, (long long)ids.size());
+                    else run_level_sync<false>(c, pl, d_cnt, nl, d_per_query_toi, d_list, (long long)ids.size());
                     SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
                     SCCD_HIP(hipStreamSynchronize(c->stream));
                     h.n_checks += checks_so_far;
                 }
                 done = !h.overflow;
             }
-        }
-        if (!done) {
-            level_all();
-            SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            if (!done) {
+                level_all();
+                SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+                SCCD_HIP(hipStreamSynchronize(c->stream));
+                h.n_checks += checks_so_far;
+                if (h.overflow) throw SccdError { SCCD_E_OVERFLOW, "narrow phase: work queue capacity exhausted" };
+            }
+            h.overflow = 0;
+            h.n_ovf = 0;
+        };
+        long long n_second = 0;
+        if (second_ran) { // (how long the list behind the first half's got: its length stayed on the device -- run_walk)
+            unsigned long long k = 0;
+            SCCD_HIP(hipMemcpyAsync(&k, p.second.d_n_kept, sizeof k, hipMemcpyDeviceToHost, c->stream));
             SCCD_HIP(hipStreamSynchronize(c->stream));
-            if (h.overflow) throw SccdError { SCCD_E_OVERFLOW, "narrow phase: work queue capacity exhausted" };
+            n_second = (long long)std::min<unsigned long long>(k, (unsigned long long)std::max<long long>(p.second.capacity, 0));
+        }
+        NarrowParams p1 = p; // (the fallback's launches are single ones over a whole list: no second half of their own)
+        p1.second = NarrowParams::SecondHalf();
+        redo_list(p1, n, !no_list_yet);
+        if (second_ran && no_list_yet && n_second > 0) {
+            NarrowParams p2 = p1;
+            p2.pairs = p.second.kept;
+            p2.n_pairs = n_second;
+            redo_list(p2, n_second, false);
         }
     }
     if (c->np_pq_limit && d_per_query_toi && n > 0) {

@@ -46,6 +46,7 @@ OPT_CULL = 24  # 1 (default): ccd()'s passes drop pairs that provably have no im
 OPT_TWO_HALVES = 25  # 1 (default): plain narrow launches from a TOI above 0.5 run as two launches over the halves of time (see sccd.h)
 OPT_ALLOC_COUNT = 23  # read-only: device allocations made by the library's grow-only buffers (a step that allocates is a slow step)
 OPT_SPEC_HITS, OPT_SPEC_MISSES = 15, 16  # read-only counters of the speculative build (set: reset)
+OPT_DEVICE_SPAN_NS, OPT_HOST_WAITS = 26, 27  # read-only: the device's own span of the last ccd() call (ns); host waits (read-backs, verdicts) so far
 OPT_LIMIT_LEVEL_ORDER = 14  # 1: check limits always on the level-synchronous kernels; default: fast kernel + certificate (same result)
 PROF_NAMES = ["boxes", "sort", "cull", "sweep", "narrow_vf", "narrow_ee", "sweep_ee"]  # SCCD_PROF_* ("sweep_ee": a mesh's edge list; "sweep": every other sweep)
 
@@ -62,7 +63,9 @@ ABI_SYMBOLS = [
     "sccd_shard_bounds", "sccd_boxes_variance_axis", "sccd_selftest_lds_gather",
     "sccd_dev_alloc", "sccd_dev_free", "sccd_dev_upload", "sccd_dev_download", "sccd_dev_copy", "sccd_ccd_collisions",
     "sccd_ccd_mesh_dev", "sccd_get_stream", "sccd_query_cull", "sccd_query_cull_slab", "sccd_ccd_mesh_from",
+    "sccd_abi_sizeof_stats", "sccd_abi_prof_count",
 ]
+ABI_VERSION_PREFIX = "sccd-hip 0.4"  # what this binding was written against (sccd_version)
 
 
 class Stats(C.Structure):
@@ -108,6 +111,14 @@ def lib():
         L.sccd_broad_phase_destroy.restype = None
         L.sccd_free.restype = None
         L.sccd_free.argtypes = [C.c_void_p]
+        # a library built from another sccd.h writes sccd_stats / profile arrays of ANOTHER size into this binding's buffers: refuse it
+        ver = L.sccd_version().decode()
+        if not hasattr(L, "sccd_abi_sizeof_stats") or not ver.startswith(ABI_VERSION_PREFIX):
+            raise RuntimeError(f"{_LIB_PATH} is {ver!r}; this binding needs {ABI_VERSION_PREFIX!r} (rebuild: make)")
+        L.sccd_abi_sizeof_stats.restype = C.c_size_t
+        if L.sccd_abi_sizeof_stats() != C.sizeof(Stats) or L.sccd_abi_prof_count() != len(PROF_NAMES):
+            raise RuntimeError(f"{_LIB_PATH}: sccd_stats is {L.sccd_abi_sizeof_stats()} bytes / {L.sccd_abi_prof_count()} profile classes there, "
+                               f"{C.sizeof(Stats)} / {len(PROF_NAMES)} here")
         _lib = L
     return _lib
 

@@ -92,13 +92,22 @@ class GlobalPrior:
     bound (no rank found anything below it): every rank knows, and every rank redoes the step from 1.  Exact either way; one more
     collective only for a bound that broke."""
 
-    def __init__(self, group=None, device=None):
+    def __init__(self, group=None, device=None, scalar_f32=False):
         self.group, self.device = group, device
         self.bound = 1.0
         self.hits = self.misses = 0
+        # the float build (sccd.OPT_SCALAR = 1) starts its kernels from (float)bound and returns THAT value when nothing lies below it:
+        # the bound compared with the reduced result must be the rounded one, or a bound that rounded down reads as a hit (ADVICE r05)
+        self.scalar_f32 = bool(scalar_f32)
 
     def step(self, run):
         bound = self.bound
+        if self.scalar_f32:
+            import numpy as np
+
+            bound = float(np.float32(bound))
+            if not 0.0 < bound < 1.0:
+                bound = 1.0
         toi, st = run(bound)
         toi = allreduce_min(toi, group=self.group, device=self.device)
         if bound < 1.0:

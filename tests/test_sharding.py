@@ -172,6 +172,29 @@ def test_global_prior_two_ranks_gloo():
     assert h0 >= 2 and m0 >= 1
 
 
+def test_global_prior_rounds_its_bound_like_the_float_build():
+    """The float build starts from (float)bound and hands THAT back when nothing lies below it: with the unrounded bound a result that
+    is the rounded-down bound would read as an impact.  One rank, a fake run() that behaves like the library."""
+    from sccd import dist as sdist
+
+    t_true = float.fromhex("0x1.a1eb220000000p-2")  # the job's earliest impact, a float whose 1.125-fold rounds DOWN to float
+    seen = []
+
+    def run_f32(bound):  # min(float(bound), earliest impact below it) -- the earliest impact is beyond the second step's bound
+        b = float(np.float32(bound))
+        seen.append(bound)
+        hit = t_true if len(seen) == 1 else 0.47
+        return (hit if hit < b else b), {}
+
+    gp = sdist.GlobalPrior(scalar_f32=True)
+    assert gp.step(run_f32)[0] == t_true
+    assert gp.bound == 1.125 * t_true
+    bound_f32 = float(np.float32(gp.bound))
+    assert bound_f32 != gp.bound and bound_f32 < 0.47  # (the case: the double bound is no float)
+    toi, _ = gp.step(run_f32)
+    assert seen[1] == bound_f32 and seen[2] == 1.0 and toi == 0.47 and (gp.hits, gp.misses) == (0, 1)  # the rounded bound came back: redone from 1
+
+
 def test_single_rank_needs_no_process_group():
     from sccd import dist as sdist
 
