@@ -142,6 +142,9 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        * slow on from a step the host was late for (bench.py: device_span_ms) */
 #define SCCD_OPT_HOST_WAITS 27        /* read: how often the host has waited for the device (read-backs of counters, early verdicts) since the context
                                        * was made, its helper context included: the difference across a call is the number of host round trips in it */
+#define SCCD_OPT_READ_BACKS 28        /* read: of those waits, the read-back launches (a gather kernel + a polled word: ~10 us each on the call's critical
+                                       * path).  A default sccd_ccd_mesh step on a mesh the context has stepped before needs NONE: both passes' verdicts
+                                       * arrive in pinned memory behind their walk kernels, with everything the host has to look at (csrc/drivers.hip) */
 #define SCCD_OPT_SPEC_HITS 15   /* read: speculative builds (sort, records and sweep enqueued for the previous build's entry counts) whose */
 #define SCCD_OPT_SPEC_MISSES 16 /* guess held / broke and were redone, since the context was made; setting either resets both counters */
 int sccd_set_option(sccd_ctx* ctx, int option, int64_t value);

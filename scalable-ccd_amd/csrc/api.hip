@@ -146,7 +146,6 @@ void sccd_destroy(sccd_ctx* c)
     c->scratch_mesh = nullptr;
     sccd_collect_profile(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    if (c->rb_event) (void)hipEventDestroy(c->rb_event);
     if (c->side_event) (void)hipEventDestroy(c->side_event);
     if (c->side_event2) (void)hipEventDestroy(c->side_event2);
     if (c->side_event3) (void)hipEventDestroy(c->side_event3);
@@ -260,6 +259,7 @@ int64_t sccd_get_option(const sccd_ctx* c, int opt)
     case SCCD_OPT_SPEC_MISSES: return c->spec_misses + (c->side ? c->side->spec_misses : 0);
     case SCCD_OPT_DEVICE_SPAN_NS: return c->device_span_ns;
     case SCCD_OPT_HOST_WAITS: return c->host_waits + (c->side ? c->side->host_waits : 0);
+    case SCCD_OPT_READ_BACKS: return c->read_backs + (c->side ? c->side->read_backs : 0);
     default: return 0;
     }
 }

@@ -8,13 +8,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <condition_variable>
 #include <exception>
 #include <functional>
 #include <memory>
-#include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 // ------------------------------------------------------------------------------------------
@@ -41,73 +38,11 @@ template <class Fn> int guarded(sccd_ctx* c, Fn&& fn)
     }
 }
 
-// One persistent helper thread per context: ccd() hands it the construction of the edge-edge lists.
-struct Worker {
-    std::thread th;
-    std::mutex m;
-    std::condition_variable cv;
-    std::function<void()> job;
-    bool has_job = false, busy = false, quit = false;
-    std::exception_ptr err;
-    void submit(std::function<void()> f)
-    {
-        std::unique_lock<std::mutex> lk(m);
-        if (!th.joinable()) th = std::thread([this] { loop(); });
-        job = std::move(f);
-        has_job = busy = true;
-        err = nullptr;
-        cv.notify_all();
-    }
-    void wait() // rethrows what the job threw
-    {
-        std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [this] { return !busy; });
-        if (err) {
-            std::exception_ptr e = err;
-            err = nullptr;
-            std::rethrow_exception(e);
-        }
-    }
-    void loop()
-    {
-        for (;;) {
-            std::function<void()> f;
-            {
-                std::unique_lock<std::mutex> lk(m);
-                cv.wait(lk, [this] { return has_job || quit; });
-                if (quit) return;
-                f = std::move(job);
-                has_job = false;
-            }
-            std::exception_ptr e;
-            try {
-                f();
-            } catch (...) {
-                e = std::current_exception();
-            }
-            std::unique_lock<std::mutex> lk(m);
-            err = e;
-            busy = false;
-            cv.notify_all();
-        }
-    }
-    ~Worker()
-    {
-        {
-            std::unique_lock<std::mutex> lk(m);
-            quit = true;
-            cv.notify_all();
-        }
-        if (th.joinable()) th.join();
-    }
-};
-
 // pipeline objects cached in the context so that repeated ccd() calls allocate nothing
 struct Pipeline {
     sccd_boxes vb, eb, fb; // boxes in element order (raw)
     sccd_broad_phase bp;
     sccd_broad_phase bp_ee; // edge-edge lists of ccd(): belongs to the helper context c->side
-    Worker worker;
 };
 Pipeline* pipeline_of(sccd_ctx* c); // (api.hip)
 

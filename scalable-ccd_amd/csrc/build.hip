@@ -1,7 +1,6 @@
 // build.hip -- the C ABI of include/sccd.h, part 2: BroadPhase (broad_phase.cuh:15-92, broad_phase.cu:29-252) -- the cell
 // grid, the entry lists (one-pass append fill or count -> scan -> fill), the merged sort, the sorted records, the speculative
 // build, a rank's window of cells, and detect_overlaps_partial with its overflow rerun, cursor and memory limit.
-#include <chrono>
 #include "api_internal.hpp"
 
 extern "C" int sccd_broad_phase_create(sccd_ctx* c, sccd_broad_phase** out)
@@ -111,21 +110,16 @@ static void list_sort(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, in
 static void records_gate_signal(sccd_ctx* c)
 {
     StageGate* g = c->records_gate_signal;
-    if (!g || g->state.load(std::memory_order_relaxed) != 0) return;
+    if (!g || g->recorded) return;
     SCCD_HIP(hipEventRecord(g->ev, c->stream));
-    g->state.store(1, std::memory_order_release);
+    g->recorded = true;
 }
 static void records_gate_wait(sccd_ctx* c)
 {
+    // (one thread enqueues both chains, this stream's behind the other's: the event is recorded by now if that chain has a records
+    // kernel at all -- a build that took another path leaves the gate open)
     StageGate* g = c->records_gate_wait;
-    if (!g) return;
-    // (the caller's thread enqueues its chain at the same pace: microseconds; a build that takes another path opens the gate when it
-    // is through -- drivers.hip -- and the bound keeps a forgotten gate from ever costing more than this)
-    const auto t0 = std::chrono::steady_clock::now();
-    int st;
-    while ((st = g->state.load(std::memory_order_acquire)) == 0)
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) return;
-    if (st == 1) SCCD_HIP(hipStreamWaitEvent(c->stream, g->ev, 0));
+    if (g && g->recorded) SCCD_HIP(hipStreamWaitEvent(c->stream, g->ev, 0));
 }
 // the sorted records of the lists of a build whose (key, index) pairs are sorted, each list in its own arrays
 static void lists_records(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B, const GridParams* gp, SortedList* LA,
@@ -200,14 +194,6 @@ static void materialise(sccd_ctx* c, const sccd_boxes* b)
     m->lazy = false;
 }
 
-// the grid parameters and, right behind them, the two list totals of a build: ONE copy brings both back (two copies in a row
-// cost a 12 us bubble between them)
-struct GridReadBack {
-    GridParams gp;
-    uint32_t total[2];
-    uint32_t place; // (device only: the shared placement cursor of a merged two-list fill)
-    uint32_t ext_q; // (device only: list A's largest extent along the sort axis, quantised -- the one-class two-list sweep)
-};
 static bool speculate_env() { return lab_env().speculate; }
 static bool over_budget(uint32_t t, int n) { return (int64_t)t > std::max<int64_t>(3 * (int64_t)n, (int64_t)n + 4096); }
 
@@ -389,8 +375,12 @@ void bp_build(sccd_broad_phase* bp, const sccd_boxes* A, const sccd_boxes* B)
                     if (speculate_env() && gs.valid && fill_round == 0 && shrink == 0 && one_or_merged && (device_window || (!windowed_build && c->shard_count == 1))
                         && gs.n_a == A->n && gs.n_b == (B ? B->n : 0) && gs.axis == axis && gs.cell_factor == cf && c->max_overlap_cutoff == 0
                         && c->sweep_algo != 1) {
-                        const uint32_t ba = gs.total[0] + std::max<uint32_t>(4096u, gs.total[0] / 32u);
-                        const uint32_t bb = B ? gs.total[1] + std::max<uint32_t>(4096u, gs.total[1] / 32u) : 0u;
+                        // (the margin: 1/32 of the last build's count, at least 4,096 entries -- for lists of a few thousand entries
+                        // a quarter of the count: with 4,096 on top a small list's bound did not fit its buffers and it never
+                        // built speculatively)
+                        auto margin = [](uint32_t t) { return std::max<uint32_t>(t / 32u, std::min<uint32_t>(4096u, t / 4u + 64u)); };
+                        const uint32_t ba = gs.total[0] + margin(gs.total[0]);
+                        const uint32_t bb = B ? gs.total[1] + margin(gs.total[1]) : 0u;
                         if (gs.total[0] > 0 && (!B || gs.total[1] > 0) && (unsigned long long)ba + bb <= (want_merged ? 2 : 1) * cap) {
                             bp->spec_bound[0] = ba;
                             bp->spec_bound[1] = bb;
@@ -676,7 +666,14 @@ void bp_detect_partial(sccd_broad_phase* bp, int phase)
         SweepCounters h;
         GridReadBack built; // (speculative build: the grid and the entry counts it really had)
         ShardWindow hwin {}; // (... of a rank of a multi-GPU job: the cell window it was dealt on the device)
-        {
+        if (bp->pre_read && attempt == 0) { // (they came with the pass's verdict: sccd_broad_phase::pre_read)
+            h = bp->pre_read->h;
+            built = bp->pre_read->built;
+            hwin = bp->pre_read->hwin;
+            bp->pre_read = nullptr;
+            bp->rb_ctx = nullptr;
+        } else {
+            bp->pre_read = nullptr;
             sccd_ctx* const rc = (bp->rb_ctx && attempt == 0) ? bp->rb_ctx : c; // (see sccd_broad_phase::rb_ctx)
             if (rc != c) SCCD_HIP(hipStreamWaitEvent(rc->stream, bp->rb_after, 0));
             bp->rb_ctx = nullptr;

@@ -102,34 +102,24 @@ struct PinnedBuf {
 };
 
 // ------------------------------------------------------------------------------------------
-// The laboratory switches that are left (tools/README.md), read ONCE, when the first context is made.  Everything else that
-// used to be an environment variable is either gone with the path it selected (SCCD_SORT=classic, SCCD_SWEEP_CHUNK,
-// SCCD_MERGED_SORT, SCCD_NP_PERM, ...) or an option of the context (SCCD_OPT_CELL_FACTOR_MILLI, SCCD_OPT_BUILD_SCAN).
-// ccd()'s two build chains (drivers.hip): a point of the caller's chain a kernel of the helper's chain is ordered behind, on the
-// device.  The caller's thread records the event on its stream and THEN publishes state 1; state 2 = "go without waiting".
+// ccd()'s two build chains (drivers.hip): a point of the caller's chain (the end of its records kernel) that a kernel of the helper's
+// chain is ordered behind, on the device.  One thread enqueues both chains, the caller's first: `recorded` says the event is in.
 struct StageGate {
-    std::atomic<int> state { 0 }; // 0 closed, 1 open: wait for `ev` on the device, 2 open: no wait
     hipEvent_t ev = nullptr;
+    bool recorded = false;
 };
+// The laboratory switches that are left (tools/README.md), read ONCE, when the first context is made: diagnostics and the handful a
+// test or a soak uses.  Everything else that used to be an environment variable is either gone with the path it selected (round 6:
+// SCCD_OVERLAP, SCCD_PRESWEEP, SCCD_NARROW_BESIDE, SCCD_NARROW_ORDER, SCCD_EE_EARLY, SCCD_EARLY_VERDICT, SCCD_SPLIT_BOXES,
+// SCCD_EREC_LATE, SCCD_SYNC, SCCD_READBACK -- the step is enqueued by one thread and read back once) or an option of the context
+// (SCCD_OPT_PASSES_APART, SCCD_OPT_CELL_FACTOR_MILLI, SCCD_OPT_BUILD_SCAN).
 struct LabEnv {
     int np_diag = 0, sweep_diag = 0;   // SCCD_NP_DIAG / SCCD_SWEEP_DIAG: counters and cycle stamps of the narrow / sweep kernels
-    bool speculate = true;             // SCCD_SPECULATE=0: every build waits for its entry counts (no speculative build)
-    bool overlap = true;               // SCCD_OVERLAP=0: no helper context (the edge-edge lists after the vertex-face pass)
-    bool presweep = true;              // SCCD_PRESWEEP=0: the edge-edge sweep not beside the vertex-face narrow phase
-    bool narrow_beside = true;         // SCCD_NARROW_BESIDE=0: the edge-edge narrow kernel after, not beside, the vertex-face one
-    bool sync_block = false;           // SCCD_SYNC=block: read-backs wait with hipStreamSynchronize instead of polling an event
-    bool narrow_order = true;          // SCCD_NARROW_ORDER=0: the vertex-face narrow kernel not ordered behind the edge-edge sweep's start
-    bool readback_copy = false;        // SCCD_READBACK=copy: read-backs as copies + a polled event instead of one gather kernel + a polled word
+    bool speculate = true;             // SCCD_SPECULATE=0: every build waits for its entry counts (no speculative build), every ccd() starts from 1
     bool sort_tickets = false;         // SCCD_SORT_TICKETS=1: sort tiles by atomic ticket even when every tile has its block
-    long long level_budget_mb = 0;     // SCCD_LEVEL_BUDGET_MB: budget per level buffer of the level-synchronous narrow phase
-    bool early_verdict = true;         // SCCD_EARLY_VERDICT=0: a narrow phase in two halves waits for its whole stream, as before
-    bool split_boxes = true;           // SCCD_SPLIT_BOXES=0: ccd()'s edge and face boxes in one launch on the caller's stream (round 4)
+    long long level_budget_mb = 0;     // SCCD_LEVEL_BUDGET_MB: budget per level buffer of the level-synchronous narrow phase (soaks on shared machines)
     int np_waves = 3;                  // SCCD_NP_WAVES=1|2: the plain walk kernel's grid fills that many waves per SIMD at most (it is built for three)
     bool cull_slabs = true;            // SCCD_CULL_SLABS=0: the projection cull looks at the whole step whatever the launches ask (round 5's first cull)
-    int erec_late = 1;                 // SCCD_EREC_LATE=0: ccd()'s edge-list records kernel beside the vertex + face records kernel, not behind its end;
-                                       // 2: behind it whatever the mesh's size (1: from SCCD_RECORDS_GATE_MIN_ELEMENTS edges + faces)
-    bool ee_early = true;              // SCCD_EE_EARLY=0: ccd()'s edge-edge walk kernel launched by the host once it has the pair count (round 4)
-                                       // instead of right behind its sweep and cull with the count read on the device
     int spec_break_every = 0;          // SCCD_SPEC_BREAK=N: every N-th speculative build is declared a failed guess (measures what a miss costs)
     static int num(const char* name, int dflt)
     {
@@ -141,23 +131,11 @@ struct LabEnv {
         np_diag = num("SCCD_NP_DIAG", 0);
         sweep_diag = num("SCCD_SWEEP_DIAG", 0);
         speculate = num("SCCD_SPECULATE", 1) != 0;
-        overlap = num("SCCD_OVERLAP", 1) != 0;
-        presweep = num("SCCD_PRESWEEP", 1) != 0;
-        narrow_beside = num("SCCD_NARROW_BESIDE", 1) != 0;
         sort_tickets = num("SCCD_SORT_TICKETS", 0) != 0;
-        narrow_order = num("SCCD_NARROW_ORDER", 1) != 0;
         level_budget_mb = num("SCCD_LEVEL_BUDGET_MB", 0);
         spec_break_every = num("SCCD_SPEC_BREAK", 0);
-        ee_early = num("SCCD_EE_EARLY", 1) != 0;
         cull_slabs = num("SCCD_CULL_SLABS", 1) != 0;
         np_waves = (int)num("SCCD_NP_WAVES", 3);
-        split_boxes = num("SCCD_SPLIT_BOXES", 1) != 0;
-        early_verdict = num("SCCD_EARLY_VERDICT", 1) != 0;
-        erec_late = num("SCCD_EREC_LATE", 1);
-        const char* s = std::getenv("SCCD_SYNC");
-        sync_block = s && std::string(s) == "block";
-        const char* r = std::getenv("SCCD_READBACK");
-        readback_copy = r && std::string(r) == "copy";
     }
 };
 inline const LabEnv& lab_env()
@@ -251,7 +229,7 @@ struct sccd_ctx {
     // sequence word behind them.  mailbox_dev is the same memory as the device addresses it.
     PinnedBuf mailbox;
     char* mailbox_dev = nullptr;
-    // THE EARLY VERDICT of a narrow phase in two halves of time (narrow_walk.inc): np_second_half_k, the kernel between the two
+    // THE EARLY VERDICT of a narrow phase in two halves of time (narrow_walk.inc): np_verdict_k, the kernel between the two
     // launches, also leaves the pass's counters and a sequence word HERE (host-coherent pinned memory, like the mailbox); if the first
     // half found its impact the host has its result then and does not wait for what is still enqueued behind that kernel -- the
     // second half's cull, its launch and the read-back, three launches that find nothing to do.
@@ -262,19 +240,19 @@ struct sccd_ctx {
     unsigned long long rb_seq = 0;
     // THE DEVICE'S OWN ACCOUNT OF A ccd() STEP (SCCD_OPT_DEVICE_SPAN_NS): the first kernel of the step stores the device's real-time
     // clock into the mailbox's tail (boxes.hip vertex_boxes_k), every read-back kernel and early verdict stores it again behind its
-    // items (api.hip readback_gather_k, narrow_walk.inc np_second_half_k); the span between the first and the LAST of them, in this
+    // items (api.hip readback_gather_k, narrow_walk.inc np_verdict_k); the span between the first and the LAST of them, in this
     // context and its helper, is what the device spent on the step -- beside the host's clock it tells a step the chip was slow on
     // from a step the host was late for (bench.py device_span_ms)
     bool step_stamp_armed = false;          // the next vertex-box launch carries the first stamp
     unsigned long long step_t_last = 0;     // the latest end stamp a read-back of this context has seen since the step began
     long long device_span_ns = -1;          // of the last ccd() call on a mesh (-1: none yet)
     int wall_clock_khz = 100000;            // the rate of that clock (hipDeviceAttributeWallClockRate)
+    long long read_backs = 0;               // SCCD_OPT_READ_BACKS: ReadBack::sync calls (a launch + a polled word each) since the context was made
     long long host_waits = 0;               // SCCD_OPT_HOST_WAITS: read-backs and early verdicts the host has waited for since the context was made (its helper counts its own)
     DevBuf np_scratch0, np_scratch1, np_scratch2, np_scratch3, np_scratch4, np_scratch3_ovf;
     DevBuf tmp0, tmp1, tmp2;
     struct sccd_mesh* scratch_mesh = nullptr; // the mesh behind the host-matrix drivers (api.hip: scratch_mesh_from_host)
     void* pipeline = nullptr; // cached pipeline objects (api.hip)
-    hipEvent_t rb_event = nullptr; // ReadBack: polled, not waited for
     // ccd(): the edge-edge lists are built by a helper context (own stream, scratch and pinned mirror) on a worker
     // thread while this context does the vertex-face pass; side_event orders the helper's stream behind the boxes
     sccd_ctx* side = nullptr;
@@ -316,14 +294,13 @@ struct ProfScope {
 void sccd_collect_profile(sccd_ctx* c); // api.cpp
 
 
-// Small device -> host reads (counters, the grid, the TOI: a few hundred bytes, several times per step, each on the step's
-// critical path).  As copies they cost a copy kernel PER ITEM plus an event the host polls: ~14 us per read-back, and a
-// copy kernel needs more registers than a CU full of narrow-phase waves has left (168 x 3 of 512 per SIMD lane: 8 are free),
-// so a read-back issued beside the narrow phase sat in its queue until the first of those waves retired (165 us: DESIGN 5.6).
-// Now ONE single-wave kernel of <= 8 vector registers (readback_gather_k, api.hip) gathers every item into host-coherent
-// pinned memory (sccd_ctx::mailbox), fences at system scope and stores a sequence number behind the items; the host polls
-// that word.  No event, no copy engine, and the kernel fits beside resident narrow-phase waves.
-// SCCD_READBACK=copy restores copies + event (A/B); SCCD_SYNC=block waits on the stream instead of polling either way.
+// Small device -> host reads (counters, the grid, the TOI: a few hundred bytes, each on a call's critical path).  As copies they cost
+// a copy kernel PER ITEM plus an event the host polls: ~14 us per read-back, and a copy kernel needs more registers than a CU full of
+// narrow-phase waves has left (168 x 3 of 512 per SIMD lane: 8 are free), so a read-back issued beside the narrow phase sat in its
+// queue until the first of those waves retired (165 us: round 3).  Since round 4 ONE single-wave kernel of <= 8 vector registers
+// (readback_gather_k, api.hip) gathers every item into host-coherent pinned memory (sccd_ctx::mailbox), waits for its stores and stores
+// a sequence number behind the items; the host polls that word.  No event, no copy engine, and the kernel fits beside resident
+// narrow-phase waves.  (The default ccd() step needs none of these any more: its passes' verdicts bring everything -- drivers.hip.)
 constexpr size_t SCCD_MAILBOX_BYTES = 8192; // items; the sequence word sits right behind
 struct ReadBackItems { // by value into the gather kernel
     const unsigned* src[8];
@@ -341,61 +318,40 @@ struct ReadBack {
     Item items[8];
     ReadBackItems dev {};
     int n = 0;
-    bool gather;
-    explicit ReadBack(sccd_ctx* ctx) : c(ctx), gather(!lab_env().readback_copy && ctx->mailbox_dev != nullptr) {}
+    explicit ReadBack(sccd_ctx* ctx) : c(ctx) {}
     void add(void* dst, const void* src_dev, size_t bytes)
     {
-        if (n >= 8 || off + bytes > SCCD_MAILBOX_BYTES) throw SccdError { SCCD_E_INVALID, "ReadBack: too many items" }; // [0, 8 KB) of the mirror
-        if (gather && ((bytes & 3) || (reinterpret_cast<uintptr_t>(src_dev) & 3))) throw SccdError { SCCD_E_INVALID, "ReadBack: items are whole aligned words" };
-        if (gather) {
-            dev.src[n] = static_cast<const unsigned*>(src_dev);
-            dev.off_words[n] = (unsigned)(off / 4);
-            dev.n_words[n] = (unsigned)(bytes / 4);
-        } else {
-            SCCD_HIP(hipMemcpyAsync(c->h_scalars.as<char>() + off, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
-        }
+        if (n >= 8 || off + bytes > SCCD_MAILBOX_BYTES) throw SccdError { SCCD_E_INVALID, "ReadBack: too many items" };
+        if ((bytes & 3) || (reinterpret_cast<uintptr_t>(src_dev) & 3)) throw SccdError { SCCD_E_INVALID, "ReadBack: items are whole aligned words" };
+        dev.src[n] = static_cast<const unsigned*>(src_dev);
+        dev.off_words[n] = (unsigned)(off / 4);
+        dev.n_words[n] = (unsigned)(bytes / 4);
         items[n++] = Item { dst, off, bytes };
         off += (bytes + 15) & ~(size_t)15;
     }
     void sync()
     {
         c->host_waits += 1;
-        const char* from = c->h_scalars.as<char>();
-        if (gather) {
-            from = c->mailbox.as<char>();
-            dev.n = n;
-            const unsigned long long want = ++c->rb_seq;
-            readback_gather_launch(c, dev, want);
-            const unsigned long long* const word = reinterpret_cast<const unsigned long long*>(from + SCCD_MAILBOX_BYTES);
-            if (lab_env().sync_block) SCCD_HIP(hipStreamSynchronize(c->stream));
-            // (a stream that drained -- or failed -- without the word having arrived must not hang the caller: looked at now and then)
-            for (unsigned spins = 1; __atomic_load_n(word, __ATOMIC_ACQUIRE) != want; spins++) {
-                __builtin_ia32_pause(); // (the helper's worker thread may be this core's other hardware thread)
-                if ((spins & 0xFFFFu) != 0) continue;
-                const hipError_t e = hipStreamQuery(c->stream);
-                if (e == hipErrorNotReady) continue;
-                SCCD_HIP(e);
-                if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != want) throw SccdError { SCCD_E_HIP, "ReadBack: the stream drained without the mailbox word" };
-            }
-        } else if (lab_env().sync_block) {
-            SCCD_HIP(hipStreamSynchronize(c->stream));
-        } else {
-            // Poll an event instead of hipStreamSynchronize: the blocking wait puts the thread to sleep and the
-            // wake-up alone costs tens of microseconds -- with six of these per ccd() step that is ~10 % of it.
-            if (!c->rb_event) SCCD_HIP(hipEventCreateWithFlags(&c->rb_event, hipEventDisableTiming));
-            SCCD_HIP(hipEventRecord(c->rb_event, c->stream));
-            for (;;) {
-                const hipError_t e = hipEventQuery(c->rb_event);
-                if (e == hipSuccess) break;
-                if (e != hipErrorNotReady) SCCD_HIP(e);
-            }
+        c->read_backs += 1;
+        const char* const from = c->mailbox.as<char>();
+        dev.n = n;
+        const unsigned long long want = ++c->rb_seq;
+        readback_gather_launch(c, dev, want);
+        const unsigned long long* const word = reinterpret_cast<const unsigned long long*>(from + SCCD_MAILBOX_BYTES);
+        // (polled: a blocking wait puts the thread to sleep and the wake-up alone costs tens of microseconds.  A stream that drained --
+        // or failed -- without the word having arrived must not hang the caller: looked at now and then)
+        for (unsigned spins = 1; __atomic_load_n(word, __ATOMIC_ACQUIRE) != want; spins++) {
+            __builtin_ia32_pause();
+            if ((spins & 0xFFFFu) != 0) continue;
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e == hipErrorNotReady) continue;
+            SCCD_HIP(e);
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != want) throw SccdError { SCCD_E_HIP, "ReadBack: the stream drained without the mailbox word" };
         }
         for (int i = 0; i < n; i++) std::memcpy(items[i].dst, from + items[i].off, items[i].bytes);
-        if (gather) { // (the end stamp the gather kernel left in front of its sequence word: sccd_ctx::step_t_last)
-            unsigned long long t_end;
-            std::memcpy(&t_end, from + SCCD_MAILBOX_BYTES + 72, sizeof t_end);
-            if (t_end > c->step_t_last) c->step_t_last = t_end;
-        }
+        unsigned long long t_end; // (the end stamp the gather kernel left in front of its sequence word: sccd_ctx::step_t_last)
+        std::memcpy(&t_end, from + SCCD_MAILBOX_BYTES + 72, sizeof t_end);
+        if (t_end > c->step_t_last) c->step_t_last = t_end;
         n = 0;
         off = 0;
     }

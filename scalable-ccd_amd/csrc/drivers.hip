@@ -447,6 +447,31 @@ static void ccd_on_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter
     *toi_out = toi;
 }
 
+// One pass's share of a step's stats
+static void pass_stats(sccd_stats* st, bool vf, const sccd_broad_phase* bp, const NarrowResult& r)
+{
+    if (!st) return;
+    (vf ? st->n_vf_pairs : st->n_ee_pairs) += bp->n_overlaps;
+    (vf ? st->n_vf_culled : st->n_ee_culled) += bp->n_overlaps - pass_count(bp);
+    (vf ? st->n_vf_checks : st->n_ee_checks) += (int64_t)r.n_checks;
+    (vf ? st->n_vf_candidates : st->n_ee_candidates) = bp->candidates;
+}
+
+// THE STEP (round 6).  ccd() of ccd.cu:80-146 with NO HOST IN IT: one thread enqueues both passes' whole chains -- boxes, the two
+// speculative builds (build.hip), sweeps, culls, walk kernels -- on two streams ordered by events, and only then waits, for the two
+// passes' VERDICTS: np_verdict_k, the kernel behind each pass's (first) walk launch, leaves the launch's counters in host-coherent
+// pinned memory and, behind them, everything else the host used to read back one round trip at a time -- the sweep's counters (pair
+// count, overflow), the grid and entry counts the speculative build really had, a rank's cell window.  Every launch takes its sizes
+// from device memory (the sweep and records kernels since round 3, the edge-edge walk kernel since round 5, the vertex-face one since
+// round 6: np_walk_k walk_deal).  The host looks at the verdicts when both are in: a guess that held, a pair buffer that was large
+// enough, no query beyond the walk kernel's reach -- the common case -- and the step is over with zero read-backs; anything else and
+// the pass concerned is done again the slow way, from what is known (whatever a walk kernel put into a running TOI on the way is an
+// accepted domain of a true pair: a speculative build that fails emits only pairs of boxes that do overlap).
+// Rounds 3-5 grew this from the other end -- a worker thread for the edge-edge build, a flag between the threads for the records gate,
+// four read-backs per step, the vertex-face walk launched by the host once it knew the count -- and the host's share showed in the
+// driver's clock (20-step means 10-25 % above the median on a shared host).  One thread is enough: enqueueing is
+// ~150 us of host time at the front of a step the device needs 800 us for.
+// Paths with a host inside (check limits, chunked sweeps, the float build, level order): the same two chains, the passes in sequence.
 static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter, double tol, int allow_zero_toi, double toi0,
                              double* toi_out, sccd_stats* st, bool* lists_resident)
 {
@@ -454,299 +479,17 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
     Pipeline* pl = pipeline_of(c);
     if (st) std::memset(st, 0, sizeof *st);
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    double before[SCCD_PROF_COUNT];
     if (st && c->profile == 1) {
         SCCD_HIP(hipEventCreate(&e0));
         SCCD_HIP(hipEventCreate(&e1));
         SCCD_HIP(hipEventRecord(e0, c->stream));
-    }
-    double before[SCCD_PROF_COUNT];
-    if (st && c->profile == 1) {
         merge_side_profile(c);
         std::memcpy(before, c->prof_ms, sizeof before);
     }
-    // (a rank of a multi-GPU job builds the edge and face boxes of its window of cells only: see boxes_from_mesh)
-    const bool lazy_ef = c->shard_count > 1 && c->sort_axis >= 0 && c->max_overlap_cutoff == 0 && !c->build_scan;
-    const bool overlap_env = lab_env().overlap;
-    const bool with_helper = overlap_env && !c->passes_apart && m->nE > 0;
-    if (with_helper && !c->side) {
-        if (sccd_create(c->device, &c->side) != SCCD_OK) throw SccdError { SCCD_E_NOMEM, "ccd: cannot create the helper context" };
-        SCCD_HIP(hipEventCreateWithFlags(&c->side_event, hipEventDisableTiming));
-        SCCD_HIP(hipEventCreateWithFlags(&c->side_event2, hipEventDisableTiming));
-        SCCD_HIP(hipEventCreateWithFlags(&c->side_event3, hipEventDisableTiming));
-        pl->bp_ee.ctx = c->side;
-        // (the helper's stream with the lowest / highest queue priority was measured in round 3: no effect)
-    }
-    // (with the helper: the edge boxes are its stream's first kernel, beside the face boxes on this one -- boxes_from_mesh)
-    const bool split_boxes = with_helper && !lazy_ef && lab_env().split_boxes;
-    boxes_from_mesh(c, m, ms, pl, true, true, true, lazy_ef, split_boxes ? c->side_event : nullptr); // inflation radius = min_distance (ccd.cu:112)
-    double toi = toi0; // ccd.cu:125 starts from 1; ccd_on_mesh may hand a bound over
-    // The edge-edge lists do not depend on the vertex-face pass: a helper context (own stream, scratch, pinned mirror)
-    // builds them on a worker thread meanwhile.  Both builds are chains of short, latency-bound kernels with host
-    // round trips in between, so two of them interleave almost for free (2.23 instead of 2.34 ms per step on the
-    // 1M-triangle cloth; 1.99 instead of 2.11 with the round-2 kernels).  On by default since the whole GPU suite
-    // and the soak run with it; SCCD_OVERLAP=0 keeps the passes apart.
-    bool helper = false, presweep_done = false;
-    const bool presweep_env = lab_env().presweep;
-    // The helper's records kernel behind the END of this stream's (build.hip: records_gate_*).  Whatever way this call ends, the gate
-    // is open when it is left.
-    struct GateOpen {
-        StageGate* g;
-        void open() const
-        {
-            int closed = 0;
-            if (g) g->state.compare_exchange_strong(closed, 2, std::memory_order_release, std::memory_order_relaxed);
-        }
-        ~GateOpen() { open(); }
-    } gate_open { nullptr };
-    if (with_helper) {
-        sccd_ctx* const sc = c->side;
-        c->records_gate_signal = sc->records_gate_wait = nullptr;
-        // (a rank of a multi-GPU job: its share of the mesh counts)
-        if (lab_env().erec_late >= 2 || (lab_env().erec_late == 1 && ((long long)m->nE + m->nF) / std::max(1, c->shard_count) >= SCCD_RECORDS_GATE_MIN_ELEMENTS)) {
-            if (!c->records_gate.ev) SCCD_HIP(hipEventCreateWithFlags(&c->records_gate.ev, hipEventDisableTiming));
-            c->records_gate.state.store(0, std::memory_order_relaxed);
-            c->records_gate_signal = sc->records_gate_wait = gate_open.g = &c->records_gate;
-        }
-        sc->sort_axis = c->sort_axis;
-        sc->sweep_algo = c->sweep_algo;
-        sc->cell_factor_milli = c->cell_factor_milli;
-        sc->build_scan = c->build_scan;
-        sc->shard_rank = c->shard_rank;
-        sc->shard_count = c->shard_count;
-        sc->overlap_capacity = c->overlap_capacity;
-        sc->max_overlap_cutoff = c->max_overlap_cutoff;
-        sc->memory_limit_mb = c->memory_limit_mb;
-        sc->profile = c->profile;
-        if (!split_boxes) SCCD_HIP(hipEventRecord(c->side_event, c->stream)); // the boxes are complete behind this point
-        const int device = c->device;
-        hipEvent_t const ev = c->side_event;
-        sccd_broad_phase* const bp_ee = &pl->bp_ee;
-        const sccd_boxes* const eb = &pl->eb;
-        sc->arith = c->arith;
-        sc->scalar_f32 = c->scalar_f32;
-        sc->narrow_algo = c->narrow_algo;
-        sc->two_halves = c->two_halves;
-        sc->two_halves_off = c->two_halves_off;
-        const double toi_start = narrow_start_toi(sc, narrow_params(sc, m, nullptr, 0, 0, max_iter, tol, ms, allow_zero_toi), toi, false);
-        pl->worker.submit([=] {
-            SCCD_HIP(hipSetDevice(device));
-            SCCD_HIP(hipStreamWaitEvent(sc->stream, ev, 0));
-            if (split_boxes) edge_boxes_on(sc, m, pl);
-            sc->np_init_pending = true; // (the build's grid kernel starts the counters of the edge-edge narrow launch too)
-            sc->np_init_toi = toi_start;
-            bp_build(bp_ee, eb, nullptr);
-            sc->np_init_pending = false;
-        });
-        helper = true;
-    }
-    // The edge-edge SWEEP runs beside the vertex-face NARROW phase: it is enqueued on the helper's stream right before
-    // that kernel is launched, with half a CU's worth of blocks (they are resident first, the narrow kernel's blocks
-    // take the rest and, being ticket-driven, make do with what they get).  The sweep waits on dependent gathers most
-    // of the time, the narrow phase is bound by vector issue: sharing the CUs, the two take little longer than the
-    // narrow phase alone.  SCCD_PRESWEEP=0 keeps them apart.
-    std::function<void()> start_ee_sweep;
-    if (helper && presweep_env)
-        start_ee_sweep = [&] {
-            gate_open.open();  // (a vertex-face build that came another way than by its two-list records kernel)
-            pl->worker.wait(); // the lists are built (long since: the build is shorter than the vertex-face broad phase)
-            // ... behind whatever this context's stream holds now (the vertex-face sweep): ordered on the DEVICE, so the
-            // edge-edge sweep starts the moment that sweep ends -- not a host round trip later
-            SCCD_HIP(hipEventRecord(c->side_event, c->stream));
-            SCCD_HIP(hipStreamWaitEvent(c->side->stream, c->side_event, 0));
-            // ... and the vertex-face narrow kernel is ordered behind THAT point of the helper's stream (below): the sweep's
-            // blocks must be resident first.  Left to the race -- a host round trip against an event wait -- the narrow kernel
-            // sometimes won, filled every SIMD, and the sweep (78 KB of LDS per block) waited for its waves to retire: the
-            // step went from 1.17 to 1.25-1.30 ms the day the read-backs became 10 us faster.
-            SCCD_HIP(hipEventRecord(c->side_event2, c->side->stream));
-            c->side->sweep_blocks_per_cu = 0; // (the sweep kernel's own choice: a full CU)
-            c->side->cull_on = c->cull_on;
-            c->side->scalar_f32 = c->scalar_f32;
-            c->side->narrow_algo = c->narrow_algo;
-            pass_cull_setup(c->side, &pl->bp_ee, m, false, ms, max_iter, tol, toi);
-            try {
-                bp_detect_partial(&pl->bp_ee, 1);
-            } catch (...) {
-                c->side->sweep_blocks_per_cu = 0;
-                throw;
-            }
-            c->side->sweep_blocks_per_cu = 0;
-            SCCD_HIP(hipEventRecord(c->side_event3, c->side->stream)); // (sweep and cull are complete behind this point)
-            presweep_done = true;
-        };
-    // ... and the edge-edge NARROW kernel starts on the helper's stream the moment that sweep is done, beside the tail of
-    // the vertex-face kernel (a wave-step of a deep query is a long dependent chain: the last part of a narrow launch
-    // keeps few lanes busy).  The two kernels share ONE running TOI (the vertex-face launch's word), so each prunes with
-    // what the other finds -- the final minimum does not depend on the order (Appendix A.20).  Only when both passes are
-    // served by the walk kernel in one chunk each; SCCD_NARROW_BESIDE=0 turns it off.
-    const bool beside_env = lab_env().narrow_beside;
-    bool both_done = false;
-    try {
-        // (a check limit: each pass proves on its own that the limit did not matter -- narrow.hip, the certificate -- which needs
-        // the pass's own running TOI: the passes stay in sequence)
-        if (helper && presweep_env && beside_env && c->max_overlap_cutoff == 0 && max_iter < 0) {
-            sccd_ctx* const sc = c->side;
-            sc->arith = c->arith;
-            sc->scalar_f32 = c->scalar_f32;
-            sc->narrow_algo = c->narrow_algo;
-            sc->limit_level_order = c->limit_level_order;
-            c->np_init_pending = true; // (the counters of the vertex-face narrow launch: started by the build's grid kernel)
-            c->np_init_toi = narrow_start_toi(c, narrow_params(c, m, nullptr, 0, 1, max_iter, tol, ms, allow_zero_toi), toi, false);
-            pass_cull_setup(c, &pl->bp, m, true, ms, max_iter, tol, toi);
-            bp_build(&pl->bp, &pl->vb, &pl->fb);
-            c->np_init_pending = false;
-            // the vertex-face sweep is enqueued, the edge-edge sweep behind it (on the helper's stream, by an event), and only
-            // then does the host wait for the vertex-face pairs: the narrow kernel it launches next finds the edge-edge
-            // sweep's blocks resident already and takes the rest of the chip
-            // (the edge-edge sweep is released by the END OF THE VERTEX-FACE SWEEP, not of its cull: the event goes into the
-            // stream between the two -- 20 us of the step's critical path)
-            pl->bp.after_sweep = [&] { start_ee_sweep(); };
-            try {
-                bp_detect_partial(&pl->bp, 1);
-            } catch (...) {
-                pl->bp.after_sweep = nullptr;
-                throw;
-            }
-            if (pl->bp.after_sweep) { // (no sweep was launched -- nothing to sweep in the vertex-face lists)
-                pl->bp.after_sweep = nullptr;
-                start_ee_sweep();
-            }
-            start_ee_sweep = nullptr;
-            bp_detect_partial(&pl->bp, 2);
-            const bool vf_one_chunk = pl->bp.cursor >= pl->bp.total_rows;
-            NarrowParams pv = narrow_params(c, m, nullptr, 0, 1, max_iter, tol, ms, allow_zero_toi);
-            pass_lists(&pl->bp, &pv);
-            if (vf_one_chunk && narrow_uses_walk_kernel(c, pv, false)) {
-                double toi_vf = toi, toi_ee = toi;
-                if (lab_env().narrow_order) SCCD_HIP(hipStreamWaitEvent(c->stream, c->side_event2, 0)); // (start_ee_sweep)
-                narrow_phase_begin(c, pv, narrow_counters(c), &toi_vf, nullptr); // (asynchronous)
-                // THE EDGE-EDGE WALK KERNEL GOES INTO ITS STREAM NOW, right behind the pass's sweep and cull, before the host
-                // knows how long their list is: the kernel reads the length on the device and derives its deal there (np_walk_k,
-                // walk_deal).  Waiting for the count first left the chip idle for 20-30 us between the cull's end and the
-                // kernel's start -- on the step's critical path, at its end.  The host reads the sweep's counters behind the
-                // kernel (same stream): if the first attempt did not stand after all (the pair buffer overflowed, the
-                // speculative build's guess broke), the kernel has run on a prefix of the true list or on nothing -- whatever it
-                // put into the running TOI is an accepted domain of a true pair -- and the pass is done again as before.
-                NarrowParams pe = narrow_params(sc, m, nullptr, 0, 0, max_iter, tol, ms, allow_zero_toi);
-                pass_lists(&pl->bp_ee, &pe); // (the buffers; the counts are on the device)
-                // (the two kernels share ONE running TOI -- unless a pass runs its two halves of time: its word then holds the bound
-                // 0.5 for a while, which the other pass must not prune by; each keeps its own word, the minimum is taken below)
-                if (narrow_start_toi(c, pv, toi_vf, false) == toi_vf && narrow_start_toi(sc, pe, toi_ee, false) == toi_ee)
-                    pe.toi_word = &narrow_counters(c)->toi_bits;
-                bool early = false;
-                if (lab_env().ee_early && presweep_done && pl->bp_ee.sweeps_in_call == 1 && toi_ee > 0 && !sc->scalar_f32 && narrow_uses_walk_kernel(sc, pe, false)) {
-                    const SweepCounters* const sw = sc->scalars.as<SweepCounters>();
-                    c->np_peer_stream = sc->stream;
-                    try {
-                        narrow_phase_begin(sc, pe, narrow_counters(sc), &toi_ee, nullptr, pl->bp_ee.cull.on ? &sw->n_kept : &sw->n_pairs,
-                                           (long long)pl->bp_ee.capacity);
-                    } catch (...) {
-                        c->np_peer_stream = nullptr;
-                        throw;
-                    }
-                    early = true;
-                    // (the sweep's counters come back through THIS context's stream, behind the vertex-face kernel, while the
-                    // edge-edge kernel runs: queued in the helper's stream they would come when that kernel has ended -- three
-                    // read-backs in a row at the end of the step instead of one)
-                    pl->bp_ee.rb_ctx = c;
-                    pl->bp_ee.rb_after = c->side_event3;
-                }
-                try {
-                    bp_detect_partial(&pl->bp_ee, 2); // waits for the edge-edge sweep and its cull
-                } catch (...) {
-                    pl->bp_ee.rb_ctx = nullptr;
-                    c->np_peer_stream = nullptr;
-                    throw;
-                }
-                pl->bp_ee.rb_ctx = nullptr;
-                const bool early_stands = early && pl->bp_ee.sweeps_in_call == 1;
-                if (pl->bp_ee.cursor >= pl->bp_ee.total_rows) {
-                    pass_lists(&pl->bp_ee, &pe);
-                    c->np_peer_stream = sc->stream; // (the helper's counters were started by its build: narrow_phase_begin uploads only if not)
-                    try {
-                        if (!early_stands) narrow_phase_begin(sc, pe, narrow_counters(sc), &toi_ee, nullptr);
-                        narrow_phase_end(c, pv, narrow_counters(c), &toi_vf, nullptr);
-                    } catch (...) {
-                        c->np_peer_stream = nullptr;
-                        throw;
-                    }
-                    c->np_peer_stream = nullptr;
-                    const NarrowResult rv = narrow_result(c);
-                    narrow_phase_end(sc, pe, narrow_counters(sc), &toi_ee, nullptr);
-                    const NarrowResult re = narrow_result(sc);
-                    toi = std::min(toi_vf, toi_ee);
-                    if (st) {
-                        st->n_vf_pairs += pl->bp.n_overlaps;
-                        st->n_vf_culled += pl->bp.n_overlaps - pass_count(&pl->bp);
-                        st->n_vf_checks += (int64_t)rv.n_checks;
-                        st->n_vf_candidates = pl->bp.candidates;
-                        st->n_ee_pairs += pl->bp_ee.n_overlaps;
-                        st->n_ee_culled += pl->bp_ee.n_overlaps - pass_count(&pl->bp_ee);
-                        st->n_ee_checks += (int64_t)re.n_checks;
-                        st->n_ee_candidates = pl->bp_ee.candidates;
-                    }
-                    both_done = true;
-                } else { // (the edge-edge overlaps come in chunks: finish the vertex-face pass, then chunk by chunk as usual)
-                    c->np_peer_stream = nullptr;
-                    if (early) {
-                        // the walk kernel that went into the helper's stream ahead of the count is still there, on a list that is
-                        // about to be made again chunk by chunk (same buffers, same counters): let it drain, and forget its verdict
-                        // (whatever it put into a running TOI is an accepted domain of a true pair -- nothing to take back)
-                        SCCD_HIP(hipStreamSynchronize(sc->stream));
-                        sc->verdict_armed = false;
-                    }
-                    narrow_phase_end(c, pv, narrow_counters(c), &toi_vf, nullptr);
-                    const NarrowResult rv = narrow_result(c);
-                    toi = toi_vf;
-                    if (st) {
-                        st->n_vf_pairs += pl->bp.n_overlaps;
-                        st->n_vf_culled += pl->bp.n_overlaps - pass_count(&pl->bp);
-                        st->n_vf_checks += (int64_t)rv.n_checks;
-                        st->n_vf_candidates = pl->bp.candidates;
-                    }
-                    // the first edge-edge chunk is swept already: its narrow phase, then the rest of the loop
-                    const NarrowResult re = run_narrow_pass(c, m, &pl->bp_ee, 0, max_iter, tol, ms, allow_zero_toi, &toi);
-                    if (st) {
-                        st->n_ee_pairs += pl->bp_ee.n_overlaps;
-                        st->n_ee_culled += pl->bp_ee.n_overlaps - pass_count(&pl->bp_ee);
-                        st->n_ee_checks += (int64_t)re.n_checks;
-                    }
-                    presweep_done = false; // (consumed)
-                }
-            } else { // not this time: the vertex-face pass as usual (its lists are built and its first chunk swept)
-                const NarrowResult rv = run_narrow_pass(c, m, &pl->bp, 1, max_iter, tol, ms, allow_zero_toi, &toi);
-                if (st) {
-                    st->n_vf_pairs += pl->bp.n_overlaps;
-                    st->n_vf_culled += pl->bp.n_overlaps - pass_count(&pl->bp);
-                    st->n_vf_checks += (int64_t)rv.n_checks;
-                }
-                ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true);
-            }
-        } else {
-            ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st, false, false, &start_ee_sweep);
-        }
-    } catch (...) {
-        if (helper) {
-            gate_open.open();
-            try {
-                pl->worker.wait();
-            } catch (...) {
-            }
-            (void)hipStreamSynchronize(c->side->stream);
-        }
-        throw;
-    }
-    if (both_done) {
-        // (both passes are behind us; each pair list was swept in one chunk and is still on the device)
-        if (lists_resident) *lists_resident = true;
-    } else if (helper) {
-        gate_open.open();
-        pl->worker.wait();
-        ccd_pass(c, m, pl, &pl->bp_ee, false, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true, /*swept=*/presweep_done);
-    } else {
-        ccd_pass(c, m, pl, &pl->bp, false, ms, max_iter, tol, allow_zero_toi, &toi, st);
-    }
-    *toi_out = toi;
-    if (st && c->profile == 1) {
+    auto finish = [&](double toi) {
+        *toi_out = toi;
+        if (!(st && c->profile == 1)) return;
         SCCD_HIP(hipEventRecord(e1, c->stream));
         SCCD_HIP(hipEventSynchronize(e1));
         float msf = 0;
@@ -760,7 +503,228 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
         st->ms_sweep = (c->prof_ms[SCCD_PROF_SWEEP] - before[SCCD_PROF_SWEEP]) + (c->prof_ms[SCCD_PROF_SWEEP_EE] - before[SCCD_PROF_SWEEP_EE]);
         st->ms_narrow = (c->prof_ms[SCCD_PROF_NARROW_VF] - before[SCCD_PROF_NARROW_VF])
             + (c->prof_ms[SCCD_PROF_NARROW_EE] - before[SCCD_PROF_NARROW_EE]) + (c->prof_ms[SCCD_PROF_CULL] - before[SCCD_PROF_CULL]);
+    };
+    // (a rank of a multi-GPU job builds the edge and face boxes of its window of cells only: see boxes_from_mesh)
+    const bool lazy_ef = c->shard_count > 1 && c->sort_axis >= 0 && c->max_overlap_cutoff == 0 && !c->build_scan;
+    // TWO STREAMS: the edge-edge chain on a helper context (own stream, scratch, counters and pinned mailboxes) beside the
+    // vertex-face chain.  Both build chains are short, latency-bound kernels, so two of them interleave almost for free; the edge-edge
+    // sweep runs beside the vertex-face narrow phase (dependent gathers against vector issue), the edge-edge walk kernel beside the tail
+    // of the vertex-face one.  SCCD_OPT_PASSES_APART: one stream, the passes one after the other (measurements).
+    const bool two_streams = !c->passes_apart && m->nE > 0;
+    if (two_streams && !c->side) {
+        if (sccd_create(c->device, &c->side) != SCCD_OK) throw SccdError { SCCD_E_NOMEM, "ccd: cannot create the helper context" };
+        SCCD_HIP(hipEventCreateWithFlags(&c->side_event, hipEventDisableTiming));
+        SCCD_HIP(hipEventCreateWithFlags(&c->side_event2, hipEventDisableTiming));
+        SCCD_HIP(hipEventCreateWithFlags(&c->side_event3, hipEventDisableTiming));
+        pl->bp_ee.ctx = c->side;
     }
+    // (two streams: the edge boxes are the helper stream's first kernel, beside the face boxes on this one -- boxes_from_mesh)
+    const bool split_boxes = two_streams && !lazy_ef;
+    boxes_from_mesh(c, m, ms, pl, true, true, true, lazy_ef, split_boxes ? c->side_event : nullptr); // inflation radius = min_distance (ccd.cu:112)
+    double toi = toi0; // ccd.cu:125 starts from 1; ccd_on_mesh may hand a bound over
+    if (!two_streams) {
+        ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st);
+        ccd_pass(c, m, pl, &pl->bp, false, ms, max_iter, tol, allow_zero_toi, &toi, st);
+        finish(toi);
+        return;
+    }
+    sccd_ctx* const sc = c->side;
+    sc->sort_axis = c->sort_axis;
+    sc->sweep_algo = c->sweep_algo;
+    sc->cell_factor_milli = c->cell_factor_milli;
+    sc->build_scan = c->build_scan;
+    sc->shard_rank = c->shard_rank;
+    sc->shard_count = c->shard_count;
+    sc->overlap_capacity = c->overlap_capacity;
+    sc->max_overlap_cutoff = c->max_overlap_cutoff;
+    sc->memory_limit_mb = c->memory_limit_mb;
+    sc->profile = c->profile;
+    sc->arith = c->arith;
+    sc->scalar_f32 = c->scalar_f32;
+    sc->narrow_algo = c->narrow_algo;
+    sc->limit_level_order = c->limit_level_order;
+    sc->two_halves = c->two_halves;
+    sc->two_halves_off = c->two_halves_off;
+    sc->cull_on = c->cull_on;
+    sc->sweep_blocks_per_cu = 0;
+    // THE RECORDS GATE (build.hip records_gate_*): the helper stream's records kernel (the edge list) is ordered, on the device, behind
+    // the END of this stream's (vertices + faces) -- two bandwidth-bound kernels side by side take twice their time each, and only this
+    // stream's is on the way to the first sweep; the edge list's then runs beside the vertex-face sweep.  From a mesh size on (a rank
+    // of a multi-GPU job: its share of the mesh counts): below it the cross-queue wait costs what the gate gains.
+    c->records_gate_signal = sc->records_gate_wait = nullptr;
+    if (((long long)m->nE + m->nF) / std::max(1, c->shard_count) >= SCCD_RECORDS_GATE_MIN_ELEMENTS) {
+        if (!c->records_gate.ev) SCCD_HIP(hipEventCreateWithFlags(&c->records_gate.ev, hipEventDisableTiming));
+        c->records_gate.recorded = false;
+        c->records_gate_signal = sc->records_gate_wait = &c->records_gate;
+    }
+    if (!split_boxes) SCCD_HIP(hipEventRecord(c->side_event, c->stream)); // the boxes are complete behind this point
+    const NarrowParams pv0 = narrow_params(c, m, nullptr, 0, 1, max_iter, tol, ms, allow_zero_toi);
+    const NarrowParams pe0 = narrow_params(sc, m, nullptr, 0, 0, max_iter, tol, ms, allow_zero_toi);
+    // ---- both build chains, this thread: the vertex-face lists on this stream (their grid kernel also starts the counters of the
+    // pass's sweep and narrow launch), then the edge boxes and the edge-edge lists on the helper's
+    c->np_init_pending = true;
+    c->np_init_toi = narrow_start_toi(c, pv0, toi, false);
+    pass_cull_setup(c, &pl->bp, m, true, ms, max_iter, tol, toi);
+    bp_build(&pl->bp, &pl->vb, &pl->fb);
+    c->np_init_pending = false;
+    SCCD_HIP(hipStreamWaitEvent(sc->stream, c->side_event, 0));
+    if (split_boxes) edge_boxes_on(sc, m, pl);
+    sc->np_init_pending = true;
+    sc->np_init_toi = narrow_start_toi(sc, pe0, toi, false);
+    pass_cull_setup(sc, &pl->bp_ee, m, false, ms, max_iter, tol, toi);
+    bp_build(&pl->bp_ee, &pl->eb, nullptr);
+    sc->np_init_pending = false;
+    c->records_gate_signal = sc->records_gate_wait = nullptr;
+    // The edge-edge SWEEP goes into the helper's stream behind the END OF THE VERTEX-FACE SWEEP (an event between that sweep and its
+    // cull: bp->after_sweep), and the vertex-face walk kernel behind the point where the helper's stream has passed that wait: the
+    // sweep's blocks (78 KB of LDS each) must be resident before the walk kernel fills every SIMD (round 4: left to a race, the walk
+    // kernel sometimes won and the whole edge-edge chain slipped by 100 us).
+    bool ee_swept = false;
+    auto start_ee_sweep = [&] {
+        SCCD_HIP(hipEventRecord(c->side_event, c->stream));
+        SCCD_HIP(hipStreamWaitEvent(sc->stream, c->side_event, 0));
+        SCCD_HIP(hipEventRecord(c->side_event2, sc->stream));
+        bp_detect_partial(&pl->bp_ee, 1);
+        SCCD_HIP(hipEventRecord(c->side_event3, sc->stream)); // (sweep and cull are complete behind this point)
+        ee_swept = true;
+    };
+    // (a check limit: each pass proves on its own that the limit did not matter -- narrow.hip, the certificate -- which needs the
+    // pass's own running TOI: the passes stay in sequence; so do chunked sweeps, the float build, level order, diagnostics)
+    const bool enqueue_all = c->max_overlap_cutoff == 0 && max_iter < 0 && !c->scalar_f32 && narrow_uses_walk_kernel(c, pv0, false)
+        && narrow_uses_walk_kernel(sc, pe0, false) && lab_env().np_diag == 0 && c->verdict_dev && sc->verdict_dev;
+    if (!enqueue_all) {
+        std::function<void()> hook = start_ee_sweep;
+        ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true, /*swept=*/false, &hook);
+        ccd_pass(c, m, pl, &pl->bp_ee, false, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true, /*swept=*/ee_swept);
+        finish(toi);
+        return;
+    }
+    // ---- the sweeps and culls
+    pl->bp.after_sweep = start_ee_sweep;
+    try {
+        bp_detect_partial(&pl->bp, 1);
+    } catch (...) {
+        pl->bp.after_sweep = nullptr;
+        throw;
+    }
+    pl->bp.after_sweep = nullptr;
+    if (!ee_swept) start_ee_sweep(); // (nothing to sweep in the vertex-face lists)
+    // ---- the walk kernels, each right behind its pass's cull, reading the list's length on the device; each followed by its verdict
+    auto extras_of = [](const sccd_broad_phase* bp) {
+        VerdictExtras x {};
+        sccd_ctx* const bc = bp->ctx;
+        x.src[0] = bc->scalars.as<unsigned>();
+        x.off_words[0] = VERDICT_SWEEP_AT / 4;
+        x.n_words[0] = (unsigned)(sizeof(SweepCounters) / 4);
+        x.n = 1;
+        if (bp->speculative) {
+            x.src[1] = reinterpret_cast<const unsigned*>(bp->grid.as<char>() + 512);
+            x.off_words[1] = VERDICT_BUILT_AT / 4;
+            x.n_words[1] = (unsigned)(sizeof(GridReadBack) / 4);
+            x.n = 2;
+            if (bp->spec_window) {
+                x.src[2] = reinterpret_cast<const unsigned*>(bp->grid.as<char>() + 1024);
+                x.off_words[2] = VERDICT_WINDOW_AT / 4;
+                x.n_words[2] = (unsigned)(sizeof(ShardWindow) / 4);
+                x.n = 3;
+            }
+        }
+        return x;
+    };
+    static_assert(VERDICT_SWEEP_AT + sizeof(SweepCounters) <= VERDICT_BUILT_AT && VERDICT_BUILT_AT + sizeof(GridReadBack) <= VERDICT_WINDOW_AT
+                      && VERDICT_WINDOW_AT + sizeof(ShardWindow) <= 4096 && sizeof(NarrowCounters) <= 2048,
+                  "the verdict buffer's layout");
+    NarrowParams pv = pv0, pe = pe0;
+    double toi_vf = toi, toi_ee = toi;
+    const bool vf_launched = pl->bp.sweeps_in_call == 1, ee_launched = pl->bp_ee.sweeps_in_call == 1; // (else: no rows, no pairs, nothing to walk)
+    // (the two kernels share ONE running TOI -- each prunes with what the other finds, the final minimum does not depend on the
+    // order, Appendix A.20 -- unless a pass runs its two halves of time: its word then holds the bound 0.5 for a while, which the
+    // other pass must not prune by; each keeps its own word then, the minimum is taken below)
+    const bool share_word = vf_launched && ee_launched && narrow_start_toi(c, pv, toi_vf, false) == toi_vf && narrow_start_toi(sc, pe, toi_ee, false) == toi_ee;
+    struct PeerGuard { // (fallback paths of this context wait for the other stream's launch before they reset a word it shares)
+        sccd_ctx* c;
+        ~PeerGuard() { c->np_peer_stream = nullptr; }
+    } peer_guard { c };
+    if (vf_launched) {
+        pass_lists(&pl->bp, &pv); // (the buffers; the counts are on the device)
+        const SweepCounters* const sw = c->scalars.as<SweepCounters>();
+        const VerdictExtras x = extras_of(&pl->bp);
+        SCCD_HIP(hipStreamWaitEvent(c->stream, c->side_event2, 0)); // (the edge-edge sweep first: above)
+        narrow_phase_begin(c, pv, narrow_counters(c), &toi_vf, nullptr, pl->bp.cull.on ? &sw->n_kept : &sw->n_pairs, (long long)pl->bp.capacity, &x);
+    }
+    if (ee_launched) {
+        pass_lists(&pl->bp_ee, &pe);
+        if (share_word) pe.toi_word = &narrow_counters(c)->toi_bits;
+        const SweepCounters* const sw = sc->scalars.as<SweepCounters>();
+        const VerdictExtras x = extras_of(&pl->bp_ee);
+        c->np_peer_stream = sc->stream;
+        narrow_phase_begin(sc, pe, narrow_counters(sc), &toi_ee, nullptr, pl->bp_ee.cull.on ? &sw->n_kept : &sw->n_pairs, (long long)pl->bp_ee.capacity, &x);
+    }
+    // ---- everything is enqueued.  The verdicts: the first attempt's counters come with them (bp_detect_partial settles the
+    // speculative build and the pair buffer on those; only a pass whose first attempt did NOT stand waits for anything else)
+    auto settle = [&](sccd_ctx* pc, sccd_broad_phase* bp, bool launched) -> bool { // -> the walk launch that is in the stream stands
+        SweepFirstRead first;
+        bool have_first = false;
+        if (launched && pc->verdict_armed) {
+            if (const char* const from = narrow_verdict_wait(pc)) {
+                std::memcpy(&first.h, from + VERDICT_SWEEP_AT, sizeof first.h);
+                std::memcpy(&first.built, from + VERDICT_BUILT_AT, sizeof first.built);
+                std::memcpy(&first.hwin, from + VERDICT_WINDOW_AT, sizeof first.hwin);
+                have_first = true;
+            }
+        }
+        bp->pre_read = have_first ? &first : nullptr;
+        try {
+            bp_detect_partial(bp, 2);
+        } catch (...) {
+            bp->pre_read = nullptr;
+            throw;
+        }
+        bp->pre_read = nullptr;
+        return launched && bp->sweeps_in_call == 1 && bp->cursor >= bp->total_rows;
+    };
+    auto redo_pass = [&](sccd_ctx* pc, sccd_broad_phase* bp, bool vf, double* t) {
+        // the walk kernel that went into the stream ahead of the verdict ran on a list that has been made again since: let it drain,
+        // forget its verdict, and do the pass's narrow phase(s) the host's way, chunk by chunk if need be
+        SCCD_HIP(hipStreamSynchronize(pc->stream));
+        pc->verdict_armed = false;
+        NarrowResult r = run_narrow_pass(pc, m, bp, vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi, t);
+        pass_stats(st, vf, bp, r);
+        while (bp->cursor < bp->total_rows) {
+            if (bp->cull.on) bp->cull.slabs = narrow_cull_slabs(pc, narrow_params(pc, m, nullptr, 0, vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi), *t);
+            bp_detect_partial(bp, 0);
+            r = run_narrow_pass(pc, m, bp, vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi, t);
+            pass_stats(st, vf, bp, r);
+        }
+    };
+    const bool vf_stands = settle(c, &pl->bp, vf_launched);
+    const bool ee_stands = settle(sc, &pl->bp_ee, ee_launched);
+    if (vf_stands) {
+        pass_lists(&pl->bp, &pv); // (now with the counts)
+        narrow_phase_end(c, pv, narrow_counters(c), &toi_vf, nullptr);
+        pass_stats(st, true, &pl->bp, narrow_result(c));
+    } else if (vf_launched || pl->bp.n_overlaps > 0 || pl->bp.cursor < pl->bp.total_rows) {
+        if (ee_launched) SCCD_HIP(hipStreamSynchronize(sc->stream)); // (it may share this pass's word)
+        redo_pass(c, &pl->bp, true, &toi_vf);
+    } else if (st) {
+        st->n_vf_candidates = pl->bp.candidates;
+    }
+    c->np_peer_stream = nullptr;
+    if (ee_stands) {
+        pass_lists(&pl->bp_ee, &pe);
+        if (share_word) pe.toi_word = &narrow_counters(c)->toi_bits;
+        narrow_phase_end(sc, pe, narrow_counters(sc), &toi_ee, nullptr);
+        pass_stats(st, false, &pl->bp_ee, narrow_result(sc));
+    } else if (ee_launched || pl->bp_ee.n_overlaps > 0 || pl->bp_ee.cursor < pl->bp_ee.total_rows) {
+        toi_ee = std::min(toi_ee, toi_vf); // (the vertex-face result seeds the pass that is done again: ccd.cu:125-143)
+        redo_pass(sc, &pl->bp_ee, false, &toi_ee);
+    } else if (st) {
+        st->n_ee_candidates = pl->bp_ee.candidates;
+    }
+    toi = std::min(toi_vf, toi_ee);
+    // (both passes are behind us; if each pair list was swept in one chunk it is still on the device)
+    if (lists_resident) *lists_resident = vf_stands && ee_stands;
+    finish(toi);
 }
 
 extern "C" int sccd_ccd_mesh(sccd_ctx* c, const sccd_mesh* m, double ms, int max_iter, double tol, int allow_zero_toi,

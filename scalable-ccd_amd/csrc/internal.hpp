@@ -85,6 +85,15 @@ struct CullSlabs {
     bool two = false;
     double t_mid = 0.5, t_end = 1.0;
 };
+// the grid parameters and, right behind them, the two list totals of a build: ONE copy brings both back (two copies in a row
+// cost a 12 us bubble between them)
+struct GridReadBack {
+    GridParams gp;
+    uint32_t total[2];
+    uint32_t place; // (device only: the shared placement cursor of a merged two-list fill)
+    uint32_t ext_q; // (device only: list A's largest extent along the sort axis, quantised -- the one-class two-list sweep)
+};
+struct ShardWindow;
 struct sccd_broad_phase {
     sccd_ctx* ctx = nullptr;
     const sccd_boxes* A = nullptr;
@@ -130,6 +139,10 @@ struct sccd_broad_phase {
     // object's stream already, and a read-back queued behind that kernel would come at the very end of the step.  Used once.
     sccd_ctx* rb_ctx = nullptr;
     hipEvent_t rb_after = nullptr;
+    // ... or finds the first attempt's counters READ ALREADY (ccd(): they came with the pass's verdict -- narrow_walk.inc
+    // np_verdict_k -- at the end of the step): {SweepCounters, GridReadBack, ShardWindow} in host memory, consumed by the next
+    // bp_detect_partial(bp, 2); no read-back of its own for the first attempt then
+    const struct SweepFirstRead* pre_read = nullptr;
     DevBuf kept, kept_b; // int2[capacity]: the cull's list; kept_b: the list of the second half of time (cull.slabs.two), made on
                          // the device only when that half is asked for at all (run_walk) -- its length stays there
     int64_t n_kept = 0;
@@ -221,6 +234,11 @@ struct SweepCounters { // lives in device memory (ctx->scalars)
     unsigned long long pad2[23];       // 512 bytes: hipMemsetAsync clears an aligned size with ONE fill kernel (280 B took two)
 };
 static_assert(sizeof(SweepCounters) == 512, "SweepCounters: keep the size a multiple of 256 bytes");
+struct SweepFirstRead { // what bp_detect_partial(bp, 2) reads back of a first attempt (sccd_broad_phase::pre_read)
+    SweepCounters h;
+    GridReadBack built;
+    ShardWindow hwin;
+};
 // rows [row_begin, row_end) of `rows` against the columns of `cols` (rows == cols: one list)
 void launch_sweep(sccd_ctx* c, const SortedList* rows, const SortedList* cols, const GridParams* gp, int row_begin,
                   int row_end, int emit, int2* out, int64_t capacity, SweepCounters* d_cnt, const uint32_t* d_m_rows = nullptr,
@@ -271,7 +289,7 @@ struct NarrowCounters {
     unsigned int n_ovf; // queries np_walk_k handed to the level-synchronous path (entries of its overflow list)
     unsigned long long toi_level; // level-synchronous kernels with a check limit: the TOI as of the start of the level
     unsigned int n_arg;           // np_walk_k with a check limit: (query, time) records of the lanes that lowered the TOI (narrow.hip: the certificate)
-    unsigned int second_go;       // "two halves of time" (narrow_walk.inc): 1 = the second launch has work (np_second_half_k)
+    unsigned int second_go;       // "two halves of time" (narrow_walk.inc): 1 = the second launch has work (np_verdict_k)
     unsigned long long pad3[12];
     // occupancy diagnostics of np_walk_k (SCCD_NP_DIAG=1 prints them)
     unsigned long long wave_steps;   // check steps executed by waves
@@ -296,8 +314,18 @@ struct NarrowCounters {
 static_assert(sizeof(NarrowCounters) <= 2048, "NarrowCounters must fit its slot of the scalars block");
 constexpr int SCCD_QUEUE_MIN_MAX_ITER = 4096; // smaller check limits are served by the level-synchronous kernel
 // runs the narrow phase on the stream; *toi in/out lives in d_cnt->toi_bits
+// what else a pass's verdict carries behind its counters (np_verdict_k): up to three runs of device words, copied to the given word
+// offsets of the pinned verdict buffer (sccd_ctx::verdict) -- ccd() puts the pass's sweep counters, grid and cell window there
+struct VerdictExtras {
+    const unsigned* src[3];
+    unsigned off_words[3], n_words[3];
+    int n;
+};
+constexpr unsigned VERDICT_SWEEP_AT = 2560, VERDICT_BUILT_AT = 3072, VERDICT_WINDOW_AT = 3200; // byte offsets of ccd()'s extras
 void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, const double* h_toi_inout,
-                        double* d_per_query_toi, const unsigned long long* d_n = nullptr, long long capacity = 0);
+                        double* d_per_query_toi, const unsigned long long* d_n = nullptr, long long capacity = 0,
+                        const VerdictExtras* vx = nullptr);
+const char* narrow_verdict_wait(sccd_ctx* c);
 void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
                       double* d_per_query_toi);
 void narrow_phase_run(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,

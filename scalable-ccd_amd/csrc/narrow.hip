@@ -605,6 +605,108 @@ static void run_dfs_f32(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
     SCCD_HIP(hipGetLastError());
 }
 
+// THE DOUBLE BUILD'S TWIN (round 6): the queries np_walk_k LISTED -- a bisection that passes level 31 in some dimension, or a tolerance
+// without an exact reciprocal: scenes measured in millimetres, tolerances many orders below the scene -- depth first on explicit
+// (lo, hi) boxes, ti_step on them being the reference's kernel body operation for operation (mid = (lo + hi) / 2, Condition 4 where
+// an interval cannot be halved).  Until round 6 these queries went to the level-synchronous kernels, whose live domains grow without
+// bound on contact-rich ones (a resting contact under a tolerance of 1e-15 of the scene: every cell of a 2-D patch passes until the
+// last level) -- SCCD_E_NOMEM where the oracle's depth-first walk returns at once.  Without a check limit the traversal cannot change
+// the result (Appendix A.20).  A query that exhausts NF_DFS_BUDGET checks or its stack raises the overflow flag: level order takes
+// the call over, as before.
+constexpr int ND_STACK = 208; // (a depth-first stack holds at most one box per level: three dimensions down to one ulp and a margin)
+struct NDBox {
+    double lo[3], hi[3];
+};
+template <bool VF, int ARITH, bool PQ>
+__global__ __launch_bounds__(64) void np_dfs_f64_k(const double* __restrict__ V, const int2* __restrict__ E, const int4* __restrict__ F,
+                                                   const int2* __restrict__ pairs, const int* __restrict__ sel, unsigned n_sel, double ms,
+                                                   double tol, bool use_ms, bool allow_zero_toi, NarrowCounters* __restrict__ cnt,
+                                                   unsigned long long* __restrict__ per_query, NDBox* __restrict__ stacks,
+                                                   unsigned long long* __restrict__ toi_word)
+{
+    const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_sel) return;
+    const int qid = sel[j];
+    TIQuery q;
+    ti_gather<VF>(V, E, F, pairs[qid], q.v);
+    ti_tolerance<VF>(q.v, tol, q.tol);
+    ti_error<VF>(q.v, use_ms, q.err);
+    NDBox* const st = stacks + (size_t)j * ND_STACK;
+    int top = 0;
+    st[top++] = NDBox { { 0.0, 0.0, 0.0 }, { 1.0, 1.0, 1.0 } };
+    double toi = toi_load(toi_word);
+    double qtoi = PQ ? __longlong_as_double((long long)per_query[qid]) : __builtin_huge_val(); // (what the first pass found stays valid)
+    unsigned step = 0;
+    unsigned long long checks = 0;
+    while (top > 0) {
+        if ((++step & 15u) == 0u) toi = toi_load(toi_word);
+        if (step > NF_DFS_BUDGET) { // (one lane cannot finish this query in reasonable time: level order takes the call over)
+            atomicOr(&cnt->overflow, 1u);
+            break;
+        }
+        const NDBox d = st[--top];
+        const TIStep s = ti_step<VF, ARITH>(q, d.lo, d.hi, ms, tol, allow_zero_toi, PQ ? qtoi : toi);
+        checks += s.checked ? 1u : 0u;
+        if (s.accept) {
+            if (PQ && d.lo[0] < qtoi) {
+                qtoi = d.lo[0];
+                atomicMin(&per_query[qid], (unsigned long long)__double_as_longlong(d.lo[0]));
+            }
+            if (d.lo[0] < toi) {
+                toi = d.lo[0];
+                toi_min(toi_word, d.lo[0]);
+            }
+        }
+        if (s.nk >= 1) {
+            if (top + 2 > ND_STACK) { // (never write past the stack)
+                atomicOr(&cnt->overflow, 1u);
+                break;
+            }
+            // later half first, so that the earlier half is popped first (the walk kernels' order)
+            if (s.nk == 2) {
+                NDBox c2 = d;
+                if (s.split == 0) c2.lo[0] = s.mid;
+                else if (s.split == 1) c2.lo[1] = s.mid;
+                else c2.lo[2] = s.mid;
+                st[top++] = c2;
+            }
+            NDBox c1 = d;
+            if (s.split == 0) c1.hi[0] = s.mid;
+            else if (s.split == 1) c1.hi[1] = s.mid;
+            else c1.hi[2] = s.mid;
+            st[top++] = c1;
+        }
+    }
+    if (checks) atomicAdd(&cnt->n_checks, checks);
+}
+static void run_dfs_f64(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, const int* d_sel, unsigned n_sel,
+                        unsigned long long* per_query)
+{
+    if (n_sel == 0) return;
+    c->np_scratch1.ensure(sizeof(NDBox) * (size_t)ND_STACK * n_sel);
+    NDBox* const stacks = c->np_scratch1.as<NDBox>();
+    const dim3 grid((n_sel + 63) / 64), block(64);
+    unsigned long long* const tw = &d_cnt->toi_bits; // (seeded by the caller with the TOI reached so far, like the level-order rerun)
+#define SCCD_LAUNCH_DD(VF_, AR_, PQ_)                                                                                      \
+    hipLaunchKernelGGL((np_dfs_f64_k<VF_, AR_, PQ_>), grid, block, 0, c->stream, p.V, p.E, p.F, p.pairs, d_sel, n_sel, p.ms, \
+                       p.tol, p.ms > 0, (bool)p.allow_zero_toi, d_cnt, per_query, stacks, tw)
+#define SCCD_LAUNCH_DD2(VF_, AR_)                      \
+    do {                                               \
+        if (per_query) SCCD_LAUNCH_DD(VF_, AR_, true); \
+        else SCCD_LAUNCH_DD(VF_, AR_, false);          \
+    } while (0)
+    if (p.is_vf) {
+        if (p.arith == 1) SCCD_LAUNCH_DD2(true, 1);
+        else SCCD_LAUNCH_DD2(true, 0);
+    } else {
+        if (p.arith == 1) SCCD_LAUNCH_DD2(false, 1);
+        else SCCD_LAUNCH_DD2(false, 0);
+    }
+#undef SCCD_LAUNCH_DD2
+#undef SCCD_LAUNCH_DD
+    SCCD_HIP(hipGetLastError());
+}
+
 // ovf_list / ovf_cap: where queries beyond level NF_MAX_LEVEL are listed (always given: narrow_phase_end redoes them in level order)
 static void run_walk_f32(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, long long n, unsigned long long* per_query,
                          int* ovf_list, unsigned ovf_cap)
@@ -690,8 +792,9 @@ double narrow_start_toi(const sccd_ctx* c, const NarrowParams& p, double toi, bo
 // d_n / capacity: the list's length is still being made on the device when this is called (ccd(): the launch goes into the stream
 // right behind the pass's sweep and cull) -- p.n_pairs is ignored, the walk kernel takes min(*d_n, capacity); plain launches of
 // the double build only (no check limit, no per-query output), the caller's business
+// vx (may be null; with d_n only): the pass's verdict is wanted in pinned memory behind the first launch, with these extras (run_walk)
 void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, const double* h_toi_inout,
-                        double* d_per_query_toi, const unsigned long long* d_n, long long capacity)
+                        double* d_per_query_toi, const unsigned long long* d_n, long long capacity, const VerdictExtras* vx)
 {
     // toi is in/out and must be >= 0 (narrow_phase.cu:126)
     SCCD_REQUIRE(*h_toi_inout >= 0, "narrow_phase: toi must be >= 0");
@@ -713,7 +816,7 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
                      "narrow_phase: a list whose length is on the device is served by the plain walk kernel only");
         if (run) {
             ProfScope ps(c, p.is_vf ? SCCD_PROF_NARROW_VF : SCCD_PROF_NARROW_EE);
-            run_walk(c, p, d_cnt, 0, nullptr, nullptr, 0, d_n, capacity, two_halves_from);
+            run_walk(c, p, d_cnt, 0, nullptr, nullptr, 0, d_n, capacity, two_halves_from, vx);
         }
         return;
     }
@@ -791,6 +894,25 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
     }
 }
 
+// The verdict a launch of this context armed (run_walk: sccd_ctx::verdict_seq is its number): waits for its word and returns the pinned
+// buffer -- the pass's counters at 0, the extras where the caller put them -- or nullptr if the stream drained or failed without it.
+// Polls (like ReadBack::sync); may be called again for the same verdict: the word stays.
+const char* narrow_verdict_wait(sccd_ctx* c)
+{
+    const char* const from = c->verdict.as<char>();
+    const unsigned long long* const word = reinterpret_cast<const unsigned long long*>(from + 2048);
+    const unsigned long long want = c->verdict_seq;
+    for (unsigned spins = 1; __atomic_load_n(word, __ATOMIC_ACQUIRE) != want; spins++) {
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFFu) != 0) continue;
+        const hipError_t e = hipStreamQuery(c->stream); // (a stream that drained or failed without the word: the caller's read-back finds out)
+        if (e == hipErrorNotReady) continue;
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != want) return nullptr;
+        break;
+    }
+    return from;
+}
+
 void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, double* h_toi_inout,
                       double* d_per_query_toi)
 {
@@ -798,27 +920,17 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
     const long long n = p.n_pairs;
     bool have = false;
     if (c->verdict_armed) {
-        // THE EARLY VERDICT (sccd_ctx::verdict, np_second_half_k): the first half's counters are on the host the moment the kernel
-        // between the halves has run.  It found its impact: that is the pass's result -- what is still enqueued behind that kernel
-        // finds nothing to do and is not waited for (the stream orders the next call behind it).  It did not: the whole stream, as before.
+        // THE EARLY VERDICT (sccd_ctx::verdict, np_verdict_k): the first launch's counters are on the host the moment the kernel
+        // behind it has run.  One launch, or a first half that found its impact: that is the pass's result -- what is still enqueued
+        // behind that kernel finds nothing to do and is not waited for (the stream orders the next call behind it).  A second half
+        // that has work: the whole stream, as before.
         c->verdict_armed = false;
         c->host_waits += 1;
-        const char* const from = c->verdict.as<char>();
-        const unsigned long long* const word = reinterpret_cast<const unsigned long long*>(from + 2048);
-        const unsigned long long want = c->verdict_seq;
-        bool arrived = true;
-        for (unsigned spins = 1; __atomic_load_n(word, __ATOMIC_ACQUIRE) != want; spins++) {
-            __builtin_ia32_pause();
-            if ((spins & 0xFFFFu) != 0) continue;
-            const hipError_t e = hipStreamQuery(c->stream); // (a stream that drained or failed without the word: the read-back below finds out)
-            if (e == hipErrorNotReady) continue;
-            arrived = __atomic_load_n(word, __ATOMIC_ACQUIRE) == want;
-            break;
-        }
-        if (arrived) {
+        const char* const from = narrow_verdict_wait(c);
+        if (from) {
             std::memcpy(&h, from, sizeof h);
             have = h.second_go == 0u;
-            unsigned long long t_end; // (np_second_half_k's stamp: the step's end if this verdict is what the host returns on)
+            unsigned long long t_end; // (np_verdict_k's stamp: the step's end if this verdict is what the host returns on)
             std::memcpy(&t_end, from + 2056, sizeof t_end);
             if (have && t_end > c->step_t_last) c->step_t_last = t_end;
         }
@@ -932,7 +1044,11 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
         // list in level order; h carries the TOI reached and the checks counted so far in, and out
         auto redo_list = [&](const NarrowParams& pl, long long nl, bool list_ready) {
             if (nl <= 0) return;
-            const unsigned cap = (unsigned)std::min<long long>(nl, 1 << 20);
+            // (room for the list: a query is listed by EVERY lane that holds a part of it when the part passes level 31 -- in the tail
+            // of a launch a deep query's deferred halves are spread over the wave's idle lanes, and a scene whose every query goes deep
+            // -- static edges under the reference's edge-edge tolerances: tests, "static" at 1e-12 -- listed each of its 4,000 queries
+            // thirty times over: with room for one entry per query the list overflowed and the call went to level order, and out of memory)
+            const unsigned cap = (unsigned)std::min<long long>(64 * nl + 4096, 1 << 22);
             auto level_all = [&]() {
                 NarrowCounters h2;
                 std::memset(&h2, 0, sizeof h2);
@@ -976,10 +1092,11 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
                     h2.toi_bits = h.toi_bits;
                     SCCD_HIP(hipMemcpyAsync(d_cnt, &h2, sizeof h2, hipMemcpyHostToDevice, c->stream));
                     SCCD_HIP(hipStreamSynchronize(c->stream)); // (h2 and ids are on the stack)
-                    if (c->scalar_f32 && pl.max_iter < 0) { // (the list holds at most 2^20 queries: 4 GB of stacks at the very most)
-                        // the float build: the listed queries depth first on explicit float boxes (np_dfs_f32_k) -- no level of
-                        // theirs has to fit anywhere
-                        run_dfs_f32(c, pl, d_cnt, d_list, (unsigned)ids.size(), reinterpret_cast<unsigned long long*>(d_per_query_toi));
+                    if (pl.max_iter < 0) { // (the list holds at most 2^20 queries: 4 / 10 GB of stacks at the very most)
+                        // the listed queries depth first on explicit boxes (np_dfs_f32_k / np_dfs_f64_k) -- no level of theirs
+                        // has to fit anywhere; a query that is too much for one lane raises the overflow flag (level order below)
+                        if (c->scalar_f32) run_dfs_f32(c, pl, d_cnt, d_list, (unsigned)ids.size(), reinterpret_cast<unsigned long long*>(d_per_query_toi));
+                        else run_dfs_f64(c, pl, d_cnt, d_list, (unsigned)ids.size(), reinterpret_cast<unsigned long long*>(d_per_query_toi));
                     } else if (pl.is_vf) run_level_sync<true>(c, pl, d_cnt, nl, d_per_query_toi, d_list, (long long)ids.size());
                     else run_level_sync<false>(c, pl, d_cnt, nl, d_per_query_toi, d_list, (long long)ids.size());
                     SCCD_HIP(hipMemcpyAsync(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));

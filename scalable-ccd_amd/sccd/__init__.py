@@ -46,6 +46,7 @@ OPT_CULL = 24  # 1 (default): ccd()'s passes drop pairs that provably have no im
 OPT_TWO_HALVES = 25  # 1 (default): plain narrow launches from a TOI above 0.5 run as two launches over the halves of time (see sccd.h)
 OPT_ALLOC_COUNT = 23  # read-only: device allocations made by the library's grow-only buffers (a step that allocates is a slow step)
 OPT_SPEC_HITS, OPT_SPEC_MISSES = 15, 16  # read-only counters of the speculative build (set: reset)
+OPT_READ_BACKS = 28  # read-only: ReadBack launches so far (a default step on a warm context needs none)
 OPT_DEVICE_SPAN_NS, OPT_HOST_WAITS = 26, 27  # read-only: the device's own span of the last ccd() call (ns); host waits (read-backs, verdicts) so far
 OPT_LIMIT_LEVEL_ORDER = 14  # 1: check limits always on the level-synchronous kernels; default: fast kernel + certificate (same result)
 PROF_NAMES = ["boxes", "sort", "cull", "sweep", "narrow_vf", "narrow_ee", "sweep_ee"]  # SCCD_PROF_* ("sweep_ee": a mesh's edge list; "sweep": every other sweep)
