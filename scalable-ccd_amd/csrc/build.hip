@@ -130,10 +130,12 @@ static void lists_records(sccd_ctx* c, const sccd_boxes* A, const sccd_boxes* B,
         records_gate_wait(c);
         launch_entry_records(c, A->raw.as<sccd_aabb>(), LA->key.as<uint32_t>(), LA->idx.as<uint32_t>(), LA->m, gp, 0, nullptr,
                              0, false, false, LA, d_tot, expect_bits);
+        records_gate_signal(c);
         return;
     }
     SCCD_REQUIRE(!d_tot, "broad phase: device-side counts serve the one-list and the merged two-list build");
     if (LA->m == 0 || LB->m == 0) return;
+    records_gate_wait(c);
     launch_entry_records_two(c, A->raw.as<sccd_aabb>(), LA->key.as<uint32_t>(), LA->idx.as<uint32_t>(), LA->m,
                              B->raw.as<sccd_aabb>(), LB->key.as<uint32_t>(), LB->idx.as<uint32_t>(), LB->m, /*b_tagged=*/false, gp, LA, LB);
     records_gate_signal(c);
@@ -176,6 +178,7 @@ static void lists_finish_merged(sccd_ctx* c, const sccd_boxes* A, const sccd_box
         ProfScope ps(c, SCCD_PROF_BOXES);
         const uint32_t* keys = LA->key.as<uint32_t>();
         const uint32_t* idx = LA->idx.as<uint32_t>();
+        records_gate_wait(c);
         launch_entry_records_two(c, A->raw.as<sccd_aabb>(), keys, idx, (int)ma, B->raw.as<sccd_aabb>(), keys + ma, idx + ma, (int)mb,
                                  /*b_tagged=*/true, gp, LA, LB, d_tot, key_bits, d_extq);
         records_gate_signal(c);

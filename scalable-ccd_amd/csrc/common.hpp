@@ -203,6 +203,8 @@ struct sccd_ctx {
     // a narrow-phase call with a check limit that runs on the fast kernel (narrow.hip: the certificate): the TOI it started from
     bool np_limit_fast = false;
     double np_toi_init = 0;
+    unsigned np_limit_cap = 0; // ... and the room its (query, time) records were given
+    bool np_cert_in_verdict = false; // ... and: the certificate's inputs come with the launch's verdict (run_walk: np_cert_k ran behind it)
     // per-query output WITH a check limit, served by the fast kernel without the limit: narrow_phase_end redoes the queries that
     // reported an impact -- and only those -- in the reference's level order with the limit (narrow.hip)
     bool np_pq_limit = false;

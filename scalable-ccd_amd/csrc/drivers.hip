@@ -547,75 +547,109 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
     sc->two_halves_off = c->two_halves_off;
     sc->cull_on = c->cull_on;
     sc->sweep_blocks_per_cu = 0;
-    // THE RECORDS GATE (build.hip records_gate_*): the helper stream's records kernel (the edge list) is ordered, on the device, behind
-    // the END of this stream's (vertices + faces) -- two bandwidth-bound kernels side by side take twice their time each, and only this
-    // stream's is on the way to the first sweep; the edge list's then runs beside the vertex-face sweep.  From a mesh size on (a rank
-    // of a multi-GPU job: its share of the mesh counts): below it the cross-queue wait costs what the gate gains.
-    c->records_gate_signal = sc->records_gate_wait = nullptr;
+    const NarrowParams pv0 = narrow_params(c, m, nullptr, 0, 1, max_iter, tol, ms, allow_zero_toi);
+    const NarrowParams pe0 = narrow_params(sc, m, nullptr, 0, 0, max_iter, tol, ms, allow_zero_toi);
+    // (chunked sweeps, the float build, level order -- SCCD_OPT_NARROW_ALGO = 1, check limits below 4,096 or under
+    // SCCD_OPT_LIMIT_LEVEL_ORDER -- and diagnostics keep the passes in sequence, with the host between them)
+    // A CHECK LIMIT the fast kernel serves (narrow.hip, the certificate: the kernel runs WITHOUT the limit, the host proves afterwards
+    // that the limit could not have changed the answer) goes the same way since round 6 -- each pass on a running TOI of ITS OWN (the
+    // proof is about the pass's own earliest accept: no shared word, no peer), both from the TOI the call started with; the
+    // edge-edge pass's proof then starts from the vertex-face pass's result, as the reference's second pass does (end_pass below).
+    const bool enqueue_all = c->max_overlap_cutoff == 0 && !c->scalar_f32 && narrow_uses_walk_kernel(c, pv0, false)
+        && narrow_uses_walk_kernel(sc, pe0, false) && lab_env().np_diag == 0 && c->verdict_dev && sc->verdict_dev;
+    // WHICH PASS GOES FIRST.  The second sweep waits for the first (two sweeps at once gain nothing: both are bound by instruction issue),
+    // so the step's critical path is one pass's whole chain plus the other pass's tail -- and the edge-edge tail is the long one (5.1 M
+    // pairs against 1.5 M on the 1M-triangle cloth).  Leading with the EDGE-EDGE chain was measured in round 6 (this code runs either
+    // way: A leads, B follows): 0.797-0.807 against 0.797-0.812 ms per step, three interleaved rounds, and 2 % WORSE where the earliest
+    // impact comes late (profiles/r06/ab_which_pass_leads.log) -- the step is work-conserving, the chip is busy either way.  The
+    // vertex-face chain leads, as in the reference (ccd.cu:125-143; the order never decides the minimum: Appendix A.20).
+    const bool ee_first = false;
+    struct PassRun {
+        sccd_ctx* ctx;
+        sccd_broad_phase* bp;
+        bool vf;
+        NarrowParams p;
+        double toi;
+        bool launched = false, stands = false;
+    };
+    PassRun run_vf { c, &pl->bp, true, pv0, toi }, run_ee { sc, &pl->bp_ee, false, pe0, toi };
+    PassRun& A = ee_first ? run_ee : run_vf; // the chain that leads
+    PassRun& B = ee_first ? run_vf : run_ee;
+    // THE RECORDS GATE (build.hip records_gate_*): the second chain's records kernel is ordered, on the device, behind the END of the
+    // leading chain's -- two bandwidth-bound kernels side by side take twice their time each, and only the leading one is on the way to
+    // the first sweep; the other then runs beside that sweep (instruction issue).  From a mesh size on (a rank of a multi-GPU job: its
+    // share of the mesh counts): below it the cross-queue wait costs what the gate gains.
+    c->records_gate_signal = c->records_gate_wait = sc->records_gate_signal = sc->records_gate_wait = nullptr;
     if (((long long)m->nE + m->nF) / std::max(1, c->shard_count) >= SCCD_RECORDS_GATE_MIN_ELEMENTS) {
         if (!c->records_gate.ev) SCCD_HIP(hipEventCreateWithFlags(&c->records_gate.ev, hipEventDisableTiming));
         c->records_gate.recorded = false;
-        c->records_gate_signal = sc->records_gate_wait = &c->records_gate;
+        A.ctx->records_gate_signal = B.ctx->records_gate_wait = &c->records_gate;
     }
+    struct GateOff {
+        sccd_ctx *c, *sc;
+        ~GateOff() { c->records_gate_signal = c->records_gate_wait = sc->records_gate_signal = sc->records_gate_wait = nullptr; }
+    } gate_off { c, sc };
     if (!split_boxes) SCCD_HIP(hipEventRecord(c->side_event, c->stream)); // the boxes are complete behind this point
-    const NarrowParams pv0 = narrow_params(c, m, nullptr, 0, 1, max_iter, tol, ms, allow_zero_toi);
-    const NarrowParams pe0 = narrow_params(sc, m, nullptr, 0, 0, max_iter, tol, ms, allow_zero_toi);
-    // ---- both build chains, this thread: the vertex-face lists on this stream (their grid kernel also starts the counters of the
-    // pass's sweep and narrow launch), then the edge boxes and the edge-edge lists on the helper's
-    // (... and, where the two walk kernels will keep a word each -- a pass in two halves of time -- each other's word as the PEER to
-    // publish accepted times to: narrow_walk.inc; the launches that share one word need none)
-    const bool enqueue_all = c->max_overlap_cutoff == 0 && max_iter < 0 && !c->scalar_f32 && narrow_uses_walk_kernel(c, pv0, false)
-        && narrow_uses_walk_kernel(sc, pe0, false) && lab_env().np_diag == 0 && c->verdict_dev && sc->verdict_dev;
-    const bool peers = enqueue_all && !(narrow_start_toi(c, pv0, toi, false) == toi && narrow_start_toi(sc, pe0, toi, false) == toi);
-    c->np_init_pending = true;
-    c->np_init_toi = narrow_start_toi(c, pv0, toi, false);
-    c->np_init_peer = peers ? &narrow_counters(sc)->toi_bits : nullptr;
-    pass_cull_setup(c, &pl->bp, m, true, ms, max_iter, tol, toi);
-    bp_build(&pl->bp, &pl->vb, &pl->fb);
-    c->np_init_pending = false;
-    c->np_init_peer = nullptr;
-    SCCD_HIP(hipStreamWaitEvent(sc->stream, c->side_event, 0));
-    if (split_boxes) edge_boxes_on(sc, m, pl);
-    sc->np_init_pending = true;
-    sc->np_init_toi = narrow_start_toi(sc, pe0, toi, false);
-    sc->np_init_peer = peers ? &narrow_counters(c)->toi_bits : nullptr;
-    pass_cull_setup(sc, &pl->bp_ee, m, false, ms, max_iter, tol, toi);
-    bp_build(&pl->bp_ee, &pl->eb, nullptr);
-    sc->np_init_pending = false;
-    sc->np_init_peer = nullptr;
-    c->records_gate_signal = sc->records_gate_wait = nullptr;
-    // The edge-edge SWEEP goes into the helper's stream behind the END OF THE VERTEX-FACE SWEEP (an event between that sweep and its
-    // cull: bp->after_sweep), and the vertex-face walk kernel behind the point where the helper's stream has passed that wait: the
-    // sweep's blocks (78 KB of LDS each) must be resident before the walk kernel fills every SIMD (round 4: left to a race, the walk
-    // kernel sometimes won and the whole edge-edge chain slipped by 100 us).
-    bool ee_swept = false;
-    auto start_ee_sweep = [&] {
-        SCCD_HIP(hipEventRecord(c->side_event, c->stream));
-        SCCD_HIP(hipStreamWaitEvent(sc->stream, c->side_event, 0));
-        SCCD_HIP(hipEventRecord(c->side_event2, sc->stream));
-        bp_detect_partial(&pl->bp_ee, 1);
-        SCCD_HIP(hipEventRecord(c->side_event3, sc->stream)); // (sweep and cull are complete behind this point)
-        ee_swept = true;
+    // ---- both build chains, this thread, the leading chain first: a chain's grid kernel also starts the counters of its pass's sweep
+    // and narrow launch -- and, where the two walk kernels will keep a word each (a pass in two halves of time), leaves the other
+    // pass's word there as the PEER to publish accepted times to (narrow_walk.inc; launches that share one word need none)
+    const bool peers = enqueue_all && max_iter < 0 && !(narrow_start_toi(c, pv0, toi, false) == toi && narrow_start_toi(sc, pe0, toi, false) == toi);
+    auto build_vf = [&] {
+        c->np_init_pending = true;
+        c->np_init_toi = narrow_start_toi(c, pv0, toi, false);
+        c->np_init_peer = peers ? &narrow_counters(sc)->toi_bits : nullptr;
+        pass_cull_setup(c, &pl->bp, m, true, ms, max_iter, tol, toi);
+        bp_build(&pl->bp, &pl->vb, &pl->fb);
+        c->np_init_pending = false;
+        c->np_init_peer = nullptr;
     };
-    // (a check limit: each pass proves on its own that the limit did not matter -- narrow.hip, the certificate -- which needs the
-    // pass's own running TOI: the passes stay in sequence; so do chunked sweeps, the float build, level order, diagnostics)
-    if (!enqueue_all) {
-        std::function<void()> hook = start_ee_sweep;
+    auto build_ee = [&] {
+        SCCD_HIP(hipStreamWaitEvent(sc->stream, c->side_event, 0));
+        if (split_boxes) edge_boxes_on(sc, m, pl);
+        sc->np_init_pending = true;
+        sc->np_init_toi = narrow_start_toi(sc, pe0, toi, false);
+        sc->np_init_peer = peers ? &narrow_counters(c)->toi_bits : nullptr;
+        pass_cull_setup(sc, &pl->bp_ee, m, false, ms, max_iter, tol, toi);
+        bp_build(&pl->bp_ee, &pl->eb, nullptr);
+        sc->np_init_pending = false;
+        sc->np_init_peer = nullptr;
+    };
+    if (ee_first) {
+        build_ee();
+        build_vf();
+    } else {
+        build_vf();
+        build_ee();
+    }
+    // The second pass's SWEEP goes into its stream behind the END OF THE LEADING SWEEP (an event between that sweep and its cull:
+    // bp->after_sweep), and the leading walk kernel behind the point where the other stream has passed that wait: a sweep's blocks
+    // (78 KB of LDS each) must be resident before a walk kernel fills every SIMD (round 4: left to a race, the walk kernel sometimes
+    // won and the whole second chain slipped by 100 us).
+    bool b_swept = false;
+    auto start_b_sweep = [&] {
+        SCCD_HIP(hipEventRecord(c->side_event3, A.ctx->stream));
+        SCCD_HIP(hipStreamWaitEvent(B.ctx->stream, c->side_event3, 0));
+        SCCD_HIP(hipEventRecord(c->side_event2, B.ctx->stream));
+        bp_detect_partial(B.bp, 1);
+        b_swept = true;
+    };
+    if (!enqueue_all) { // (A is the vertex-face pass on this context, B the edge-edge pass on the helper's)
+        std::function<void()> hook = start_b_sweep;
         ccd_pass(c, m, pl, &pl->bp, true, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true, /*swept=*/false, &hook);
-        ccd_pass(c, m, pl, &pl->bp_ee, false, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true, /*swept=*/ee_swept);
+        ccd_pass(c, m, pl, &pl->bp_ee, false, ms, max_iter, tol, allow_zero_toi, &toi, st, /*built=*/true, /*swept=*/b_swept);
         finish(toi);
         return;
     }
     // ---- the sweeps and culls
-    pl->bp.after_sweep = start_ee_sweep;
+    A.bp->after_sweep = start_b_sweep;
     try {
-        bp_detect_partial(&pl->bp, 1);
+        bp_detect_partial(A.bp, 1);
     } catch (...) {
-        pl->bp.after_sweep = nullptr;
+        A.bp->after_sweep = nullptr;
         throw;
     }
-    pl->bp.after_sweep = nullptr;
-    if (!ee_swept) start_ee_sweep(); // (nothing to sweep in the vertex-face lists)
+    A.bp->after_sweep = nullptr;
+    if (!b_swept) start_b_sweep(); // (nothing to sweep in the leading lists)
     // ---- the walk kernels, each right behind its pass's cull, reading the list's length on the device; each followed by its verdict
     auto extras_of = [](const sccd_broad_phase* bp) {
         VerdictExtras x {};
@@ -641,96 +675,104 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
     static_assert(VERDICT_SWEEP_AT + sizeof(SweepCounters) <= VERDICT_BUILT_AT && VERDICT_BUILT_AT + sizeof(GridReadBack) <= VERDICT_WINDOW_AT
                       && VERDICT_WINDOW_AT + sizeof(ShardWindow) <= 4096 && sizeof(NarrowCounters) <= 2048,
                   "the verdict buffer's layout");
-    NarrowParams pv = pv0, pe = pe0;
-    double toi_vf = toi, toi_ee = toi;
-    const bool vf_launched = pl->bp.sweeps_in_call == 1, ee_launched = pl->bp_ee.sweeps_in_call == 1; // (else: no rows, no pairs, nothing to walk)
-    // (the two kernels share ONE running TOI -- each prunes with what the other finds, the final minimum does not depend on the
-    // order, Appendix A.20 -- unless a pass runs its two halves of time: its word then holds the bound 0.5 for a while, which the
-    // other pass must not prune by; each keeps its own word then, the minimum is taken below)
-    const bool share_word = vf_launched && ee_launched && narrow_start_toi(c, pv, toi_vf, false) == toi_vf && narrow_start_toi(sc, pe, toi_ee, false) == toi_ee;
-    struct PeerGuard { // (fallback paths of this context wait for the other stream's launch before they reset a word it shares)
+    A.launched = A.bp->sweeps_in_call == 1; // (else: no rows, no pairs, nothing to walk)
+    B.launched = B.bp->sweeps_in_call == 1;
+    // (the two kernels share ONE running TOI -- the leading pass's word: each prunes with what the other finds, the final minimum does
+    // not depend on the order, Appendix A.20 -- unless a pass runs its two halves of time: its word then holds the bound 0.5 for a
+    // while, which the other pass must not prune by; each keeps its own word then and publishes what it ACCEPTS to its peer's)
+    const bool share_word = A.launched && B.launched && !peers && max_iter < 0;
+    struct PeerGuard { // (fallback paths of the leading context wait for the other stream's launch before they reset a word it shares)
         sccd_ctx* c;
         ~PeerGuard() { c->np_peer_stream = nullptr; }
-    } peer_guard { c };
-    if (vf_launched) {
-        pass_lists(&pl->bp, &pv); // (the buffers; the counts are on the device)
-        const SweepCounters* const sw = c->scalars.as<SweepCounters>();
-        const VerdictExtras x = extras_of(&pl->bp);
-        SCCD_HIP(hipStreamWaitEvent(c->stream, c->side_event2, 0)); // (the edge-edge sweep first: above)
-        narrow_phase_begin(c, pv, narrow_counters(c), &toi_vf, nullptr, pl->bp.cull.on ? &sw->n_kept : &sw->n_pairs, (long long)pl->bp.capacity, &x);
+    } peer_guard { A.ctx };
+    auto begin_walk = [&](PassRun& R) {
+        pass_lists(R.bp, &R.p); // (the buffers; the counts are on the device)
+        if (&R == &B && share_word) R.p.toi_word = &narrow_counters(A.ctx)->toi_bits;
+        const SweepCounters* const sw = R.ctx->scalars.as<SweepCounters>();
+        const VerdictExtras x = extras_of(R.bp);
+        narrow_phase_begin(R.ctx, R.p, narrow_counters(R.ctx), &R.toi, nullptr, R.bp->cull.on ? &sw->n_kept : &sw->n_pairs, (long long)R.bp->capacity, &x);
+    };
+    if (A.launched) {
+        SCCD_HIP(hipStreamWaitEvent(A.ctx->stream, c->side_event2, 0)); // (the second sweep first: above)
+        begin_walk(A);
     }
-    if (ee_launched) {
-        pass_lists(&pl->bp_ee, &pe);
-        if (share_word) pe.toi_word = &narrow_counters(c)->toi_bits;
-        const SweepCounters* const sw = sc->scalars.as<SweepCounters>();
-        const VerdictExtras x = extras_of(&pl->bp_ee);
-        c->np_peer_stream = sc->stream;
-        narrow_phase_begin(sc, pe, narrow_counters(sc), &toi_ee, nullptr, pl->bp_ee.cull.on ? &sw->n_kept : &sw->n_pairs, (long long)pl->bp_ee.capacity, &x);
+    if (B.launched) {
+        A.ctx->np_peer_stream = B.ctx->stream;
+        if (max_iter >= 0 && A.launched) {
+            // a check limit: the second pass starts from the first one's RESULT, as the reference's does -- its word is seeded on the
+            // device, behind the first pass's walk kernel (which ends before the second pass's cull does: nothing waits long)
+            SCCD_HIP(hipEventRecord(c->side_event, A.ctx->stream));
+            SCCD_HIP(hipStreamWaitEvent(B.ctx->stream, c->side_event, 0));
+            narrow_seed_word(B.ctx, narrow_counters(B.ctx), narrow_counters(A.ctx));
+        }
+        begin_walk(B);
     }
     // ---- everything is enqueued.  The verdicts: the first attempt's counters come with them (bp_detect_partial settles the
     // speculative build and the pair buffer on those; only a pass whose first attempt did NOT stand waits for anything else)
-    auto settle = [&](sccd_ctx* pc, sccd_broad_phase* bp, bool launched) -> bool { // -> the walk launch that is in the stream stands
+    auto settle = [&](PassRun& R) { // -> R.stands: the walk launch that is in the stream stands
         SweepFirstRead first;
         bool have_first = false;
-        if (launched && pc->verdict_armed) {
-            if (const char* const from = narrow_verdict_wait(pc)) {
+        if (R.launched && R.ctx->verdict_armed) {
+            if (const char* const from = narrow_verdict_wait(R.ctx)) {
                 std::memcpy(&first.h, from + VERDICT_SWEEP_AT, sizeof first.h);
                 std::memcpy(&first.built, from + VERDICT_BUILT_AT, sizeof first.built);
                 std::memcpy(&first.hwin, from + VERDICT_WINDOW_AT, sizeof first.hwin);
                 have_first = true;
             }
         }
-        bp->pre_read = have_first ? &first : nullptr;
+        R.bp->pre_read = have_first ? &first : nullptr;
         try {
-            bp_detect_partial(bp, 2);
+            bp_detect_partial(R.bp, 2);
         } catch (...) {
-            bp->pre_read = nullptr;
+            R.bp->pre_read = nullptr;
             throw;
         }
-        bp->pre_read = nullptr;
-        return launched && bp->sweeps_in_call == 1 && bp->cursor >= bp->total_rows;
+        R.bp->pre_read = nullptr;
+        R.stands = R.launched && R.bp->sweeps_in_call == 1 && R.bp->cursor >= R.bp->total_rows;
     };
-    auto redo_pass = [&](sccd_ctx* pc, sccd_broad_phase* bp, bool vf, double* t) {
+    auto redo_pass = [&](PassRun& R) {
         // the walk kernel that went into the stream ahead of the verdict ran on a list that has been made again since: let it drain,
         // forget its verdict, and do the pass's narrow phase(s) the host's way, chunk by chunk if need be
-        SCCD_HIP(hipStreamSynchronize(pc->stream));
-        pc->verdict_armed = false;
-        NarrowResult r = run_narrow_pass(pc, m, bp, vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi, t);
-        pass_stats(st, vf, bp, r);
-        while (bp->cursor < bp->total_rows) {
-            if (bp->cull.on) bp->cull.slabs = narrow_cull_slabs(pc, narrow_params(pc, m, nullptr, 0, vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi), *t);
-            bp_detect_partial(bp, 0);
-            r = run_narrow_pass(pc, m, bp, vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi, t);
-            pass_stats(st, vf, bp, r);
+        SCCD_HIP(hipStreamSynchronize(R.ctx->stream));
+        R.ctx->verdict_armed = false;
+        NarrowResult r = run_narrow_pass(R.ctx, m, R.bp, R.vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi, &R.toi);
+        pass_stats(st, R.vf, R.bp, r);
+        while (R.bp->cursor < R.bp->total_rows) {
+            if (R.bp->cull.on) R.bp->cull.slabs = narrow_cull_slabs(R.ctx, narrow_params(R.ctx, m, nullptr, 0, R.vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi), R.toi);
+            bp_detect_partial(R.bp, 0);
+            r = run_narrow_pass(R.ctx, m, R.bp, R.vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi, &R.toi);
+            pass_stats(st, R.vf, R.bp, r);
         }
     };
-    const bool vf_stands = settle(c, &pl->bp, vf_launched);
-    const bool ee_stands = settle(sc, &pl->bp_ee, ee_launched);
-    if (vf_stands) {
-        pass_lists(&pl->bp, &pv); // (now with the counts)
-        narrow_phase_end(c, pv, narrow_counters(c), &toi_vf, nullptr);
-        pass_stats(st, true, &pl->bp, narrow_result(c));
-    } else if (vf_launched || pl->bp.n_overlaps > 0 || pl->bp.cursor < pl->bp.total_rows) {
-        if (ee_launched) SCCD_HIP(hipStreamSynchronize(sc->stream)); // (it may share this pass's word)
-        redo_pass(c, &pl->bp, true, &toi_vf);
-    } else if (st) {
-        st->n_vf_candidates = pl->bp.candidates;
-    }
-    c->np_peer_stream = nullptr;
-    if (ee_stands) {
-        pass_lists(&pl->bp_ee, &pe);
-        if (share_word) pe.toi_word = &narrow_counters(c)->toi_bits;
-        narrow_phase_end(sc, pe, narrow_counters(sc), &toi_ee, nullptr);
-        pass_stats(st, false, &pl->bp_ee, narrow_result(sc));
-    } else if (ee_launched || pl->bp_ee.n_overlaps > 0 || pl->bp_ee.cursor < pl->bp_ee.total_rows) {
-        toi_ee = std::min(toi_ee, toi_vf); // (the vertex-face result seeds the pass that is done again: ccd.cu:125-143)
-        redo_pass(sc, &pl->bp_ee, false, &toi_ee);
-    } else if (st) {
-        st->n_ee_candidates = pl->bp_ee.candidates;
-    }
-    toi = std::min(toi_vf, toi_ee);
-    // (both passes are behind us; if each pair list was swept in one chunk it is still on the device)
-    if (lists_resident) *lists_resident = vf_stands && ee_stands;
+    auto end_pass = [&](PassRun& R, PassRun& other, bool other_still_running) {
+        if (R.stands) {
+            pass_lists(R.bp, &R.p); // (now with the counts)
+            if (&R == &B && share_word) R.p.toi_word = &narrow_counters(A.ctx)->toi_bits;
+            // (a check limit: the second pass of the reference starts from the first one's RESULT, ccd.cu:125-143 -- its certificate,
+            // and its level-order fallback, start from there; the launch itself started from the call's TOI, a looser bound, under
+            // which a query's level-order count can only be larger: what it certifies holds from the tighter start as well)
+            if (&R == &B && max_iter >= 0 && R.ctx->np_limit_fast) R.ctx->np_toi_init = std::min(R.ctx->np_toi_init, A.toi);
+            narrow_phase_end(R.ctx, R.p, narrow_counters(R.ctx), &R.toi, nullptr);
+            if (&R == &B && max_iter >= 0) R.toi = std::min(R.toi, A.toi);
+            pass_stats(st, R.vf, R.bp, narrow_result(R.ctx));
+        } else if (R.launched || R.bp->n_overlaps > 0 || R.bp->cursor < R.bp->total_rows) {
+            if (other_still_running && other.launched) SCCD_HIP(hipStreamSynchronize(other.ctx->stream)); // (it may share this pass's word, or publish to it)
+            else R.toi = std::min(R.toi, other.toi); // (the other pass's result seeds the pass that is done again: ccd.cu:125-143)
+            redo_pass(R);
+        } else if (st) {
+            (R.vf ? st->n_vf_candidates : st->n_ee_candidates) = R.bp->candidates;
+        }
+    };
+    // (the leading pass is settled and ended while the other's walk kernel still runs: whatever its end costs the host -- the
+    // certificate of a check limit is ~100 us of bisection on the host -- lies in that kernel's shade)
+    settle(A);
+    end_pass(A, B, /*other_still_running=*/true);
+    A.ctx->np_peer_stream = nullptr;
+    settle(B);
+    end_pass(B, A, /*other_still_running=*/false);
+    toi = std::min(A.toi, B.toi);
+    // (both passes are behind us; if each pair list was swept once, in one chunk, it is still on the device)
+    if (lists_resident) *lists_resident = A.stands && B.stands;
     finish(toi);
 }
 

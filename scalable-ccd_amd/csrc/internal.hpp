@@ -277,6 +277,7 @@ struct NarrowParams {
 };
 struct NarrowCounters;
 void narrow_counters_upload(sccd_ctx* c, NarrowCounters* d_cnt, double toi);
+void narrow_seed_word(sccd_ctx* c, NarrowCounters* dst, const NarrowCounters* src); // dst's TOI = min(dst's, src's), on c->stream
 struct NarrowCounters {
     // The three hot words sit on separate 128-byte lines: sharing one line, the ticket atomics
     // queued behind every wave's TOI polls and cost tens of microseconds each.
@@ -320,11 +321,14 @@ constexpr int SCCD_QUEUE_MIN_MAX_ITER = 4096; // smaller check limits are served
 // what else a pass's verdict carries behind its counters (np_verdict_k): up to three runs of device words, copied to the given word
 // offsets of the pinned verdict buffer (sccd_ctx::verdict) -- ccd() puts the pass's sweep counters, grid and cell window there
 struct VerdictExtras {
-    const unsigned* src[3];
-    unsigned off_words[3], n_words[3];
+    const unsigned* src[4];
+    unsigned off_words[4], n_words[4];
     int n;
 };
 constexpr unsigned VERDICT_SWEEP_AT = 2560, VERDICT_BUILT_AT = 3072, VERDICT_WINDOW_AT = 3200; // byte offsets of ccd()'s extras
+// ... and of what a launch with a check limit adds itself (run_walk): {the query that holds the earliest accept, its record count, its
+// 24 coordinates} -- the inputs of the certificate (narrow.hip np_cert_k), so that the host's proof needs no read-back either
+constexpr unsigned VERDICT_CERT_AT = 3232, VERDICT_CERT_WORDS = 2 + 48;
 void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, const double* h_toi_inout,
                         double* d_per_query_toi, const unsigned long long* d_n = nullptr, long long capacity = 0,
                         const VerdictExtras* vx = nullptr);

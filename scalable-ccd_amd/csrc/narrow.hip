@@ -349,6 +349,35 @@ __global__ void np_fetch_query_k(const double* __restrict__ V, const int2* __res
         for (int k = 0; k < 3; k++) out[3 * a + k] = v[a][k];
 }
 
+// both in ONE launch behind a walk kernel that recorded (run_walk: a check limit on ccd()'s step, where the host reads nothing back):
+// out = {the query, the record count, its 24 coordinates}; the launch's verdict carries them to the host (VERDICT_CERT_AT)
+template <bool VF>
+__global__ __launch_bounds__(1024) void np_cert_k(const double* __restrict__ V, const int2* __restrict__ E, const int4* __restrict__ F,
+                                                  const int2* __restrict__ pairs, const NarrowCounters* __restrict__ cnt,
+                                                  const int* __restrict__ rec, unsigned cap, const unsigned long long* __restrict__ toi_word,
+                                                  unsigned* __restrict__ out)
+{
+    __shared__ unsigned s_best;
+    if (threadIdx.x == 0) s_best = 0xFFFFFFFFu;
+    __syncthreads();
+    const unsigned n_all = cnt->n_arg, n_rec = n_all < cap ? n_all : cap;
+    const unsigned long long t = __hip_atomic_load(toi_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned best = 0xFFFFFFFFu;
+    for (unsigned i = threadIdx.x; i < n_rec; i += 1024u)
+        if ((unsigned)rec[3 * i + 1] == (unsigned)t && (unsigned)rec[3 * i + 2] == (unsigned)(t >> 32)) best = min(best, (unsigned)rec[3 * i]);
+    if (best != 0xFFFFFFFFu) atomicMin(&s_best, best);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    out[0] = s_best;
+    out[1] = n_all;
+    if (s_best == 0xFFFFFFFFu) return;
+    double v[8][3];
+    ti_gather<VF>(V, E, F, pairs[s_best], v);
+    double* const o = reinterpret_cast<double*>(out + 2);
+    for (int a = 0; a < 8; a++)
+        for (int k = 0; k < 3; k++) o[3 * a + k] = v[a][k];
+}
+
 // per-query output with a check limit: the queries whose unlimited bisection reported an impact (finite per-query TOI) ...
 __global__ void np_select_finite_k(const double* __restrict__ per_query, long long n, int* __restrict__ list, unsigned* __restrict__ count)
 {
@@ -744,6 +773,17 @@ __global__ __launch_bounds__(256) void np_counters_init_k(unsigned long long* __
 {
     for (int k = threadIdx.x; k < words; k += 256) cnt[k] = k == 0 ? toi_bits : 0ull;
 }
+// *dst = min(*dst, *src) on c->stream: one pass's running TOI seeded with another's result, on the device (ccd() with a check limit:
+// the second pass starts from the first one's result, ccd.cu:125-143, without the host having seen it)
+__global__ void np_seed_word_k(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src)
+{
+    atomicMin(dst, __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+void narrow_seed_word(sccd_ctx* c, NarrowCounters* dst, const NarrowCounters* src)
+{
+    hipLaunchKernelGGL(np_seed_word_k, dim3(1), dim3(1), 0, c->stream, &dst->toi_bits, &src->toi_bits);
+    SCCD_HIP(hipGetLastError());
+}
 void narrow_counters_upload(sccd_ctx* c, NarrowCounters* d_cnt, double toi)
 {
     static_assert(offsetof(NarrowCounters, toi_bits) == 0 && sizeof(NarrowCounters) % 8 == 0, "np_counters_init_k: the TOI is word 0");
@@ -785,7 +825,10 @@ CullSlabs narrow_cull_slabs(const sccd_ctx* c, const NarrowParams& p, double toi
 double narrow_start_toi(const sccd_ctx* c, const NarrowParams& p, double toi, bool per_query)
 {
     // (exactly the launches narrow_phase_begin serves with the plain walk kernel; diagnostics builds count one launch)
-    const bool two = c->two_halves && !c->two_halves_off && !per_query && p.max_iter < 0 && !c->scalar_f32 && c->narrow_algo != 1 && lab_env().np_diag == 0 && toi > 0.5;
+    // (round 6: a check limit the fast kernel serves too -- the kernel runs WITHOUT the limit either way and the certificate is about
+    // the TOI the CALL started with, whichever way the kernel got to its earliest accept: narrow_phase_begin)
+    const bool limit_ok = p.max_iter < 0 || (!c->limit_level_order && p.max_iter >= SCCD_QUEUE_MIN_MAX_ITER);
+    const bool two = c->two_halves && !c->two_halves_off && !per_query && limit_ok && !c->scalar_f32 && c->narrow_algo != 1 && lab_env().np_diag == 0 && toi > 0.5;
     return two ? 0.5 : toi;
 }
 
@@ -812,11 +855,22 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
     const bool run = (*h_toi_inout > 0) || d_per_query_toi != nullptr;
     const long long n = p.n_pairs;
     if (d_n) {
-        SCCD_REQUIRE(!d_per_query_toi && p.max_iter < 0 && !c->scalar_f32 && narrow_uses_walk_kernel(c, p, false),
+        SCCD_REQUIRE(!d_per_query_toi && !c->scalar_f32 && narrow_uses_walk_kernel(c, p, false),
                      "narrow_phase: a list whose length is on the device is served by the plain walk kernel only");
         if (run) {
             ProfScope ps(c, p.is_vf ? SCCD_PROF_NARROW_VF : SCCD_PROF_NARROW_EE);
-            run_walk(c, p, d_cnt, 0, nullptr, nullptr, 0, d_n, capacity, two_halves_from, vx);
+            if (p.max_iter >= 0) { // a check limit: the fast kernel WITHOUT it, recording who lowered the TOI (below; narrow_phase_end: the certificate)
+                const unsigned cap = 1u << 20; // (the list's length is not known here: room for the most records a certificate looks at)
+                c->np_scratch3_ovf.ensure(sizeof(int) * 4 * (size_t)cap + 256);
+                NarrowParams pn = p;
+                pn.max_iter = -2;
+                c->np_toi_init = *h_toi_inout;
+                c->np_limit_cap = cap;
+                run_walk(c, pn, d_cnt, 0, nullptr, c->np_scratch3_ovf.as<int>(), cap, d_n, capacity, two_halves_from, vx);
+                c->np_limit_fast = true;
+            } else {
+                run_walk(c, p, d_cnt, 0, nullptr, nullptr, 0, d_n, capacity, two_halves_from, vx);
+            }
         }
         return;
     }
@@ -881,7 +935,8 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
                 NarrowParams pn = p;
                 pn.max_iter = -2;
                 c->np_toi_init = *h_toi_inout;
-                run_walk(c, pn, d_cnt, n, nullptr, c->np_scratch3_ovf.as<int>(), cap);
+                c->np_limit_cap = cap;
+                run_walk(c, pn, d_cnt, n, nullptr, c->np_scratch3_ovf.as<int>(), cap, nullptr, 0, two_halves_from);
                 c->np_limit_fast = true; // (only once the launch is enqueued)
             } else if (d_per_query_toi) { // (bookkeeping kernels: they can list queries beyond level 31 themselves)
                 const unsigned cap = (unsigned)std::min<long long>(n, 1 << 20);
@@ -919,6 +974,9 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
     NarrowCounters h;
     const long long n = p.n_pairs;
     bool have = false;
+    const char* verdict_from = nullptr;
+    const bool cert_in_verdict = c->np_cert_in_verdict;
+    c->np_cert_in_verdict = false;
     if (c->verdict_armed) {
         // THE EARLY VERDICT (sccd_ctx::verdict, np_verdict_k): the first launch's counters are on the host the moment the kernel
         // behind it has run.  One launch, or a first half that found its impact: that is the pass's result -- what is still enqueued
@@ -927,6 +985,7 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
         c->verdict_armed = false;
         c->host_waits += 1;
         const char* const from = narrow_verdict_wait(c);
+        verdict_from = from;
         if (from) {
             std::memcpy(&h, from, sizeof h);
             have = h.second_go == 0u;
@@ -955,11 +1014,23 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
         const double toi_init = c->np_toi_init;
         double t_star;
         std::memcpy(&t_star, &h.toi_bits, 8);
-        const unsigned cap = (unsigned)std::min<long long>(std::max<long long>(n, 1024), 1 << 20);
+        const unsigned cap = c->np_limit_cap; // (what the launch was given room for: narrow_phase_begin)
         bool certified = false;
         if (!h.overflow && !h.n_ovf) {
             if (!(t_star < toi_init)) certified = true; // nothing was accepted below the TOI the call started with
-            else if (h.n_arg <= cap && h.n_arg > 0) {
+            else if (h.n_arg <= cap && h.n_arg > 0 && have && cert_in_verdict && verdict_from) {
+                // (the holder and its coordinates came with the verdict: np_cert_k ran behind the launch -- no read-back)
+                unsigned best = 0xFFFFFFFFu;
+                double v[8][3];
+                std::memcpy(&best, verdict_from + VERDICT_CERT_AT, sizeof best);
+                std::memcpy(&v[0][0], verdict_from + VERDICT_CERT_AT + 8, sizeof v);
+                if (best < (unsigned long long)n) {
+                    bool gave_up = false;
+                    const double alone = ti_census_level_order(v, p.is_vf, p.arith, p.ms, p.tol, p.max_iter, p.allow_zero_toi, toi_init,
+                                                               /*max_live=*/1 << 22, &gave_up);
+                    certified = !gave_up && alone == t_star;
+                }
+            } else if (h.n_arg <= cap && h.n_arg > 0) {
                 int* const rec = c->np_scratch3_ovf.as<int>() + cap;
                 unsigned* const d_best = reinterpret_cast<unsigned*>(c->np_scratch3_ovf.as<int>() + 4 * (size_t)cap);
                 double* const d_v = reinterpret_cast<double*>(d_best + 2);
