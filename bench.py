@@ -54,15 +54,26 @@ def _pmc_file(name):
     return None
 
 
+def _pmc_latest(kind, workload):
+    """(file name, contents) of the newest profiles/rNN_pmc_<kind>_<workload>.json that was taken on THIS build's kernels, else (None, None)"""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_%s_%s.json" % (kind, workload))), reverse=True):
+        tj = _pmc_file(os.path.basename(path))
+        if tj:
+            return os.path.basename(path), tj
+    return None, None
+
+
 def pmc_kernels(workload):
-    """per-kernel HBM bytes of profiles/r05_pmc_traffic_<workload>.json if that profile is of THIS build's kernels, else None"""
-    tj = _pmc_file("r05_pmc_traffic_%s.json" % workload)
+    """per-kernel HBM bytes of the newest profiles/rNN_pmc_traffic_<workload>.json that is of THIS build's kernels, else None"""
+    tj = _pmc_latest("traffic", workload)[1]
     return tj["kernels"] if tj else None
 
 
 def pmc_sq(workload):
-    """SQ counters per kernel of profiles/r05_pmc_sq_<workload>.json (tools/pmc_sq.sh) if taken on THIS build's kernels, else None"""
-    tj = _pmc_file("r05_pmc_sq_%s.json" % workload)
+    """SQ counters per kernel of the newest profiles/rNN_pmc_sq_<workload>.json (tools/pmc_sq.sh) taken on THIS build's kernels, else None"""
+    tj = _pmc_latest("sq", workload)[1]
     return tj["kernels"] if tj else None
 
 
@@ -158,6 +169,7 @@ def parse():
     ap.add_argument("--cull", type=int, default=None, help="SCCD_OPT_CULL: 1 (library default) the projection cull in front of the bisection, 0: every pair is bisected")
     ap.add_argument("--two-halves", type=int, default=None, help="SCCD_OPT_TWO_HALVES: 1 (library default) plain narrow launches from a TOI above 0.5 run as two launches over the halves of time, 0: one launch")
     ap.add_argument("--clock-warmup", type=float, default=1.0, help="seconds of untimed steps before the W warm-up steps (GPU clocks, first touches); 0: none")
+    ap.add_argument("--passes-apart", action="store_true", help="SCCD_OPT_PASSES_APART for the whole run: one stream, the passes one after the other (kernel profiles: one kernel at a time on the chip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="cloth side of the CPU sample (0 = auto)")
     return ap.parse_args()
@@ -206,6 +218,8 @@ def main():
         ctx.set_option(sccd.OPT_CULL, args.cull)
     if args.two_halves is not None:
         ctx.set_option(sccd.OPT_TWO_HALVES, args.two_halves)
+    apart_run = 1 if args.passes_apart else 0
+    ctx.set_option(sccd.OPT_PASSES_APART, apart_run)
 
     def barrier():
         ctx.synchronize()
@@ -292,7 +306,7 @@ def main():
         prof_apart_raw = ctx.profile()
         prof_apart = {k: v[0] / n_prof for k, v in prof_apart_raw.items()}
         ctx.set_option(sccd.OPT_PROFILE, 0)
-        ctx.set_option(sccd.OPT_PASSES_APART, 0)
+        ctx.set_option(sccd.OPT_PASSES_APART, apart_run)
         for _ in range(N_SETTLE):
             step()
         ctx.set_option(sccd.OPT_PROFILE, 1)
@@ -401,14 +415,14 @@ def main():
         traffic, traffic_note = None, "no PMC profile of this workload"
         try:
             defaults = args.cull is None and args.two_halves is None and args.max_iter < 0 and args.jitter == 0.0  # (the profile is of the default step)
-            if defaults and args.workload == "cloth1m" and args.cloth_n == 708 and world == 1 and os.path.exists(os.path.join(ROOT, "profiles", "r05_pmc_traffic_cloth1m.json")):
-                tj = _pmc_file("r05_pmc_traffic_cloth1m.json")
+            if defaults and args.workload == "cloth1m" and args.cloth_n == 708 and world == 1:
+                fn, tj = _pmc_latest("traffic", "cloth1m")
                 if tj:
                     traffic = tj["kernels"][units[dom][2]]["hbm_bytes_per_launch_corrected"]
-                    traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build's kernels (profiles/r05_pmc_traffic_cloth1m.json: "
+                    traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this build's kernels (profiles/%s: " % fn
                                     + ("same library" if tj.get("lib_sha256") == lib_sha256() else "same device code, host code changed since") + ")")
                 else:
-                    traffic_note = "profiles/r05_pmc_traffic_cloth1m.json was taken on other kernels than this library's: dropped"
+                    traffic_note = "no profiles/rNN_pmc_traffic_cloth1m.json taken on this library's kernels: dropped"
         except Exception:
             pass
         checks = float(c_vf + c_ee)

@@ -883,17 +883,21 @@ extern "C" int sccd_ccd(sccd_ctx* c, const double* V0, const double* V1, int nV,
 static void ccd_pass_collisions(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, bool vf, double ms, int max_iter, double tol,
                                 int allow_zero_toi, double* toi, std::vector<sccd_collision>& acc)
 {
-    pl->bp.cull.on = false; // (per-query output: every pair keeps its place in the list)
+    // THE PROJECTION CULL serves the collision list too (round 6): a culled pair has no accepted domain, hence no per-query impact and
+    // no record (narrow_phase.cu:84-103 lists toi < 1 only) -- under any check limit as well.  Per-query output prunes a query by its
+    // OWN earliest impact alone (root_finder.cu:297): the slab is the whole step, whatever the running TOI is.
+    pass_cull_setup(c, &pl->bp, m, vf, ms, max_iter, tol, 1.0);
+    pl->bp.cull.slabs = CullSlabs(); // ([0, 1], one list)
     if (vf) bp_build(&pl->bp, &pl->vb, &pl->fb);
     else bp_build(&pl->bp, &pl->eb, nullptr);
     DevBuf& pq = c->col_pq;
     while (pl->bp.cursor < pl->bp.total_rows) {
         bp_detect_partial(&pl->bp);
-        const int64_t n = pl->bp.n_overlaps;
+        const int64_t n = pass_count(&pl->bp);
         if (n > 0) pq.ensure(sizeof(double) * (size_t)n);
-        run_narrow(c, m, pl->bp.overlaps.as<int2>(), n, vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi, toi,
+        run_narrow(c, m, pass_pairs(&pl->bp), n, vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi, toi,
                    n > 0 ? pq.as<double>() : nullptr);
-        copy_out_collisions(c, pl->bp.overlaps.as<int2>(), pq.as<double>(), n, acc);
+        copy_out_collisions(c, pass_pairs(&pl->bp), pq.as<double>(), n, acc);
     }
 }
 

@@ -1119,7 +1119,9 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
             // of a launch a deep query's deferred halves are spread over the wave's idle lanes, and a scene whose every query goes deep
             // -- static edges under the reference's edge-edge tolerances: tests, "static" at 1e-12 -- listed each of its 4,000 queries
             // thirty times over: with room for one entry per query the list overflowed and the call went to level order, and out of memory)
-            const unsigned cap = (unsigned)std::min<long long>(64 * nl + 4096, 1 << 22);
+            // (a list that IS there was made by the call's own launch, in the room narrow_phase_begin gave it: the buffer must not be
+            // grown now -- DevBuf::ensure does not keep contents -- and holds min(nl, 2^20) entries)
+            const unsigned cap = list_ready ? (unsigned)std::min<long long>(nl, 1 << 20) : (unsigned)std::min<long long>(64 * nl + 4096, 1 << 22);
             auto level_all = [&]() {
                 NarrowCounters h2;
                 std::memset(&h2, 0, sizeof h2);
@@ -1130,7 +1132,7 @@ void narrow_phase_end(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt,
                 else run_level_sync<false>(c, pl, d_cnt, nl, d_per_query_toi);
             };
             bool done = false;
-            c->np_scratch3_ovf.ensure(sizeof(int) * (size_t)cap);
+            if (!list_ready) c->np_scratch3_ovf.ensure(sizeof(int) * (size_t)cap);
             int* d_list = c->np_scratch3_ovf.as<int>();
             unsigned long long checks_so_far = h.n_checks;
             unsigned ovf = h.overflow, n_ovf = h.n_ovf;

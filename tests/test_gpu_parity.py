@@ -1179,6 +1179,17 @@ def test_ccd_with_collisions(sccd, ctx, orc):
     got_ee = sorted((int(r["aid"]), int(r["bid"]), float(r["toi"])) for r in col[n_vf:])
     assert got_vf == want[0] and got_ee == want[1]
     assert len(col) and min(float(r["toi"]) for r in col) == toi
+    # (round 6) the projection cull in front of the per-query narrow phase: a culled pair has no impact, hence no record -- the same
+    # list, forced on this small mesh, with and without a check limit that no query reaches
+    try:
+        ctx.set_option(sccd.OPT_CULL, 2)
+        for limit in (-1, 10_000_000):
+            toi2, col2 = sccd.ccd(V0, V1, E, F, 0.0, limit, 1e-6, True, ctx=ctx, want_collisions=True)
+            assert toi2 == toi and len(col2) == len(col)
+            assert sorted((int(r["aid"]), int(r["bid"]), float(r["toi"])) for r in col2[:n_vf]) == want[0]
+            assert sorted((int(r["aid"]), int(r["bid"]), float(r["toi"])) for r in col2[n_vf:]) == want[1]
+    finally:
+        ctx.set_option(sccd.OPT_CULL, 1)
 
 
 @pytest.mark.parametrize("tol", [1e-9, 1e-11, 1e-13])
@@ -1830,6 +1841,35 @@ def test_cull_keeps_a_query_the_reference_accepts_by_condition_4(sccd, ctx, orc)
         assert len(sccd.query_cull(mesh, pair, False, 0.0, co)) == 0  # (and the bound is no blanket keep: 1e-2 away is culled)
     finally:
         mesh.close()
+
+
+def test_a_list_of_queries_survives_the_fallback_that_reads_it(sccd, orc):
+    """Soak seed 60120 (round 6): the float build's walk kernel LISTS the queries it cannot finish, in a buffer sized for this call;
+    the fallback that redoes them asked for a larger buffer before it had read the list -- a grow-only buffer does not keep its
+    contents -- and redid whatever the new allocation held: the first float call on a context whose earlier calls had left the
+    buffer small returned a later TOI (or faulted), the next one, buffer grown, was right.  A fresh context, one double call, then
+    the float build at a tolerance of 1e-6 of the scene: the oracle's float twin on the first call."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import soak
+
+    V0, V1, E, F, kind, scale, shift, ms, allow_zero, arith, *_ = soak.scene_of(60120)
+    tol = 1e-6 * scale
+    want = orc.ccd(V0, V1, E, F, ms, -1, tol, allow_zero, arith=arith, nthreads=8, scalar="f32")[0]
+    for apart in (0, 1):
+        c = sccd.Context(0)
+        try:
+            c.set_option(sccd.OPT_ARITH, arith)
+            c.set_option(sccd.OPT_PASSES_APART, apart)
+            mesh = sccd.Mesh(V0, V1, E, F, ctx=c)
+            assert sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero) == orc.ccd(V0, V1, E, F, ms, -1, 1e-6, allow_zero, arith=arith, nthreads=8)[0]
+            c.set_option(sccd.OPT_SCALAR, 1)
+            for _ in range(2):
+                assert sccd.ccd_mesh(mesh, ms, -1, tol, allow_zero) == want
+            mesh.close()
+        finally:
+            c.close()
 
 
 def test_float_build_is_bounded_on_a_query_that_explodes(sccd, ctx):

@@ -1,7 +1,7 @@
-# Refresh profiles/ for the CURRENT build (run on the GPU box): bash tools/collect_profiles.sh [round tag, default r05]
+# Refresh profiles/ for the CURRENT build (run on the GPU box): bash tools/collect_profiles.sh [round tag, default r06]
 # Everything lands in gpurun_out/prof/; copy what is to be kept into profiles/ afterwards (the PMC traffic files carry
 # the hash of the library they were taken on: bench.py quotes them only for that very build).
-R=${1:-r05}
+R=${1:-r06}
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
@@ -12,14 +12,14 @@ for W in cloth1m boxes1m sort16m; do
 done
 # (the default step overlaps two streams: each kernel's own duration, one kernel at a time on the chip, is in this trace)
 rm -rf gpurun_out/prof/ks_cloth1m_apart
-SCCD_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_cloth1m_apart --output-format csv -- python3 bench.py --workload cloth1m --steps 5 --warmup 2 --clock-warmup 0.2 --no-cpu-baseline > gpurun_out/prof/ks_cloth1m_apart.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks_cloth1m_apart --output-format csv -- python3 bench.py --workload cloth1m --steps 5 --warmup 2 --clock-warmup 0.2 --no-cpu-baseline --passes-apart > gpurun_out/prof/ks_cloth1m_apart.log 2>&1
 cp $(ls gpurun_out/prof/ks_cloth1m_apart/*/*kernel_stats.csv | tail -1) gpurun_out/prof/${R}_cloth1m_passes_apart_kernel_stats.csv
 for W in cloth1m sort16m boxes1m; do
   bash tools/pmc_traffic.sh $W > gpurun_out/prof/pmc_traffic_$W.txt 2>&1
   cp gpurun_out/pmc_traffic_$W.json gpurun_out/prof/${R}_pmc_traffic_$W.json
 done
 # (the SQ counters belong to one kernel at a time on the chip: the passes apart)
-SCCD_OVERLAP=0 bash tools/pmc_sq.sh cloth1m > gpurun_out/prof/pmc_sq_cloth1m.txt 2>&1
+bash tools/pmc_sq.sh cloth1m --passes-apart > gpurun_out/prof/pmc_sq_cloth1m.txt 2>&1
 cp gpurun_out/pmc_sq_cloth1m.json gpurun_out/prof/${R}_pmc_sq_cloth1m.json
 bash tools/pmc_sq.sh boxes1m > gpurun_out/prof/pmc_sq_boxes1m.txt 2>&1
 cp gpurun_out/pmc_sq_boxes1m.json gpurun_out/prof/${R}_pmc_sq_boxes1m.json
@@ -29,7 +29,7 @@ cp gpurun_out/prof/${R}_pmc_traffic_*.json gpurun_out/prof/${R}_pmc_sq_*.json pr
 for W in cloth1m boxes1m sort16m clothball10k; do
   timeout 600 python3 bench.py --workload $W 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_$W.json.log
 done
-SCCD_OVERLAP=0 timeout 600 python3 bench.py --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_passes_apart.json.log
+timeout 600 python3 bench.py --no-cpu-baseline --passes-apart 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_passes_apart.json.log
 timeout 600 python3 bench.py --no-cpu-baseline --max-iter 10000000 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_max_iter_1e7.json.log
 # every round: the strict contract, the step without the cull / with one narrow launch per pass, the cliffs, a mesh that moves
 timeout 600 python3 bench.py --no-cpu-baseline --arith 0 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_strict.json.log
@@ -41,7 +41,7 @@ for J in 1e-4 1e-3 3e-3; do
 done
 timeout 900 python3 bench.py --no-cpu-baseline --jitter 1e-3 --jitter-alternate 0.05 --steps 1000 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_cloth1m_jitter_alternating.json.log
 # the driver's command five times, then its 100-step line
-bash tools/jobs/r05_bench5.sh prof/${R}_driver_shaped > gpurun_out/prof/${R}_driver_shaped_lines.txt 2>&1
+bash tools/jobs/driver_shaped5.sh prof/${R}_driver_shaped > gpurun_out/prof/${R}_driver_shaped_lines.txt 2>&1
 timeout 600 python3 bench.py --workload boxes1m --boxes-variant thin 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_boxes1m_thin.json.log
 timeout 600 python3 bench.py --workload boxes1m --boxes-n 16000000 --steps 10 2>/dev/null | tail -1 > gpurun_out/prof/${R}_bench_boxes16m.json.log
 # SURVEY 8d's other C3 shapes: kernel stats and HBM traffic

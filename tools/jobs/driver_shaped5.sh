@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, task 1: the driver's command (fresh process, 20 steps, 5 warm-up) five times, then the 100-step line
+# the driver's command (fresh process, 20 steps, 5 warm-up) five times, then the 100-step line
 out=gpurun_out/${1:-r05a}; mkdir -p $out
 for i in 1 2 3 4 5; do
   python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $out/bench20_$i.json 2> $out/bench20_$i.err

@@ -2,8 +2,8 @@
 # SQ_INSTS_CBRANCH(_TAKEN) (profiles/r02_counters_available_gfx950.txt is `rocprofv3 -L` of the box): branch behaviour is
 # read from SQ_INSTS_BRANCH, lane utilisation from SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU), occupancy from
 # 4 x SQ_WAVE_CYCLES / (SIMDs x GRBM_GUI_ACTIVE / 8):
-#   bash tools/pmc_sq.sh [workload]
-W=${1:-cloth1m}
+#   bash tools/pmc_sq.sh [workload] [extra bench.py arguments, e.g. --passes-apart]
+W=${1:-cloth1m}; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
 for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
@@ -23,7 +23,7 @@ for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
          "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
   rm -rf gpurun_out/pmcsq_$i
-  timeout 600 rocprofv3 --pmc $G -d gpurun_out/pmcsq_$i --output-format csv -- python3 bench.py --workload $W --steps 2 --warmup 1 --clock-warmup 0 --no-cpu-baseline > gpurun_out/pmcsq_$i.log 2>&1 || tail -3 gpurun_out/pmcsq_$i.log
+  timeout 600 rocprofv3 --pmc $G -d gpurun_out/pmcsq_$i --output-format csv -- python3 bench.py --workload $W --steps 2 --warmup 1 --clock-warmup 0 --no-cpu-baseline "$@" > gpurun_out/pmcsq_$i.log 2>&1 || tail -3 gpurun_out/pmcsq_$i.log
 done
 python3 - <<PY
 import csv,glob,collections,json

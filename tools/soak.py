@@ -35,6 +35,17 @@ def scene_of(seed):
     return V0, V1, E, F, kind, scale, shift, ms, allow_zero, arith, world, sweep_algo, scan_build, narrow_algo
 
 
+def tol_of(seed, scale, ms):
+    """the co-domain tolerance of a soak seed: 1e-6 as in the reference's tests (tests/test_narrow_phase.cu:41-45) for the seeds of
+    rounds 1-5; from 2,000,000 on a RANDOM one, relative to the scene's scale -- 1e-3 down to 1e-9 of it (1e-7 under a minimum
+    separation: a shell of resting contacts under a tolerance far below it is hours of bisection for the oracle).  VERDICT r05, task 4:
+    the projection cull's bound depends on the tolerance."""
+    if seed < 2_000_000:
+        return 1e-6
+    rng = np.random.default_rng(991_000 + seed)
+    return float(scale * 10.0 ** rng.uniform(-7.0 if ms > 0 else -9.0, -3.0))
+
+
 def srt(p):
     p = np.asarray(p, np.int32).reshape(-1, 2)
     return p[np.lexsort((p[:, 1], p[:, 0]))] if len(p) else p
@@ -59,10 +70,6 @@ def supervise(cases, first):
     for b0 in range(first, first + cases, BATCH):
         n = min(BATCH, first + cases - b0)
         env = dict(os.environ, SCCD_SOAK_CHILD="1", SCCD_LEVEL_BUDGET_MB=os.environ.get("SCCD_LEVEL_BUDGET_MB", "1024"))
-        # every second batch with the records gate on whatever the mesh's size (the library reads its switches once per process;
-        # the default's size rule would leave these small meshes without it)
-        if "SCCD_EREC_LATE" not in os.environ and (b0 // BATCH) % 2 == 1:
-            env["SCCD_EREC_LATE"] = "2"
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), str(n), str(b0)], env=env, timeout=CHILD_TIMEOUT)
             rc = r.returncode
@@ -104,14 +111,15 @@ def main():
     t0 = time.time()
     for seed in range(first, first + cases):
         V0, V1, E, F, kind, scale, shift, ms, allow_zero, arith, world, sweep_algo, scan_build, narrow_algo = scene_of(seed)
-        tag = f"seed {seed} kind {kind} nF {len(F)} scale {scale:.3g} shift {shift:.3g} ms {ms:.3g} zero {allow_zero} arith {arith} world {world} sweep {sweep_algo} scan {scan_build} narrow {narrow_algo}"
+        tol = tol_of(seed, scale, ms)
+        tag = f"seed {seed} kind {kind} nF {len(F)} tol {tol:.3g} scale {scale:.3g} shift {shift:.3g} ms {ms:.3g} zero {allow_zero} arith {arith} world {world} sweep {sweep_algo} scan {scan_build} narrow {narrow_algo}"
         vb, eb, fb = orc.build_boxes(V0, V1, E, F, ms)
         want_vf, _, _ = orc.sort_and_sweep(vb, fb, nthreads=8)
         want_ee, _, _ = orc.sort_and_sweep(eb, nthreads=8)
         if seed in ORACLE_TOI:
             want = float.fromhex(ORACLE_TOI[seed])
         else:
-            want, _, _ = orc.ccd(V0, V1, E, F, ms, -1, 1e-6, allow_zero, arith=arith, nthreads=8)
+            want, _, _ = orc.ccd(V0, V1, E, F, ms, -1, tol, allow_zero, arith=arith, nthreads=8)
         ctx.set_option(sccd.OPT_BUILD_SCAN, 1 if scan_build else 0)
         ok = False
         tois, got_vf, got_ee = [float("nan")], [np.zeros((0, 2), np.int32)], [np.zeros((0, 2), np.int32)]
@@ -135,16 +143,16 @@ def main():
                 got_vf.append(bp.detect_overlaps().reshape(-1, 2))
                 bp.build(de)
                 got_ee.append(bp.detect_overlaps().reshape(-1, 2))
-                tois.append(sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero))
+                tois.append(sccd.ccd_mesh(mesh, ms, -1, tol, allow_zero))
             ok = (np.array_equal(srt(np.concatenate(got_vf)), want_vf) and np.array_equal(srt(np.concatenate(got_ee)), want_ee)
                   and min(tois) == want)
             if ok and seed % 3 == 0:  # the float build (SCCD_OPT_SCALAR = 1: np_walk_f32_k, level order for what it lists) against the oracle's float twin
                 ctx.set_option(sccd.OPT_SHARD_COUNT, 1)
                 ctx.set_option(sccd.OPT_SHARD_RANK, 0)
                 try:
-                    want_f = orc.ccd(V0, V1, E, F, ms, -1, 1e-6, allow_zero, arith=arith, nthreads=8, scalar="f32")[0]
+                    want_f = orc.ccd(V0, V1, E, F, ms, -1, max(tol, 1e-6 * scale), allow_zero, arith=arith, nthreads=8, scalar="f32")[0]
                     ctx.set_option(sccd.OPT_SCALAR, 1)
-                    got_f = sccd.ccd_mesh(mesh, ms, -1, 1e-6, allow_zero)
+                    got_f = sccd.ccd_mesh(mesh, ms, -1, max(tol, 1e-6 * scale), allow_zero)
                     ok = got_f == want_f
                     if not ok:
                         print("FLOAT MISMATCH", tag, got_f, want_f, flush=True)
@@ -156,12 +164,12 @@ def main():
                 ctx.set_option(sccd.OPT_SHARD_COUNT, 1)
                 ctx.set_option(sccd.OPT_SHARD_RANK, 0)
                 try:
-                    _, want_pq, _ = orc.narrow_phase(V0, V1, E, F, want_ee, False, ms=ms, allow_zero_toi=allow_zero,
+                    _, want_pq, _ = orc.narrow_phase(V0, V1, E, F, want_ee, False, ms=ms, tol=tol, allow_zero_toi=allow_zero,
                                                      per_query=True, arith=arith)
                 except MemoryError:  # (level order without a global bound: contact-rich scenes outgrow any budget)
                     print("SKIP per-query", tag, flush=True)
                     continue
-                _, col = sccd.narrow_phase(mesh, want_ee, False, ms=ms, allow_zero_toi=allow_zero, want_collisions=True)
+                _, col = sccd.narrow_phase(mesh, want_ee, False, tol=tol, ms=ms, allow_zero_toi=allow_zero, want_collisions=True)
                 hits = want_pq < 1
                 got = {(int(a), int(b)): float(x) for a, b, x in zip(col["aid"], col["bid"], col["toi"])}
                 ok = len(col) == int(hits.sum()) and all(got.get((int(a), int(b))) == x for (a, b), x in zip(want_ee[hits], want_pq[hits]))

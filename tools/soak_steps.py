@@ -24,10 +24,6 @@ def supervise(cases, first):
     for b0 in range(first, first + cases, BATCH):
         n = min(BATCH, first + cases - b0)
         env = dict(os.environ, SCCD_SOAK_CHILD="1")
-        # every second batch with the records gate on whatever the mesh's size (the library reads its switches once per process;
-        # the default's size rule would leave these small meshes without it)
-        if "SCCD_EREC_LATE" not in os.environ and (b0 // BATCH) % 2 == 1:
-            env["SCCD_EREC_LATE"] = "2"
         try:
             rc = subprocess.run([sys.executable, os.path.abspath(__file__), str(n), str(b0)], env=env, timeout=CHILD_TIMEOUT).returncode
         except subprocess.TimeoutExpired:
