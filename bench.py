@@ -32,7 +32,7 @@ BYTES_PER_QUERY = 220.0       # narrow phase: pair 8 + element indices 12/16 + 2
 BYTES_SWEEP_PER_BOX = 64.0    # sweep: sorted box record, + 8 B per emitted pair
 BYTES_SORT_PER_KEY_PASS = 16  # one radix pass over (u32 key, u32 index): read 8 + write 8
 FLOP_PER_CHECK = 520.0        # one inclusion-function check = 8 corners x 57 FLOP + min/max/tests (the REFERENCE's form)
-FLOP_PER_CHECK_EXECUTED = 156.0  # what np_walk_k executes per check: the min/max form of ti_inclusion_mm (DESIGN.md 5.5)
+FLOP_PER_CHECK_EXECUTED = 156.0  # what np_walk_k executes per check: the min/max form of ti_inclusion_mm (DESIGN.md 5.6)
 FP64_VALU_PEAK_TFLOPS = 78.6  # AMD's MI355X specification: 78.6 TFLOP/s FP64 vector (= 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz)
 N_SETTLE = 3                  # untimed steps behind every change of an option, before anything is timed
 BYTES_BROAD_PER_BOX = 548.0   # box build 124 + radix sort 204 + payload gather 128 + counts/scan 28 + sweep 64, + 8 B per pair
@@ -345,7 +345,7 @@ def main():
             toi = dev_min.value()  # (the reduced word of the last step; every step of this frozen mesh has the same)
         prof = ctx.profile()
         ctx.set_option(sccd.OPT_PROFILE, 0)
-        # the speculative TOI bound (DESIGN 5.6: a step of a mesh whose previous step found an impact at T starts from 1.125 T, verified):
+        # the speculative TOI bound (DESIGN 2: a step of a mesh whose previous step found an impact at T starts from 1.125 T, verified):
         # the same steps WITH it, 20 of them behind settling steps -- hits, misses, ms per step
         ctx.set_option(sccd.OPT_TOI_GUESS, 1)
         for _ in range(N_SETTLE):
@@ -389,7 +389,7 @@ def main():
 
         # roofline of the dominant kernel class of this rank, measured live with hipEvents on the context's stream
         # (SCCD_OPT_PROFILE).  Broad-phase classes are HBM-bound: algorithmic bytes / device time against
-        # 8 TB/s.  The narrow phase is bound by FP64 vector issue (SURVEY 8d, DESIGN 5.5): inclusion checks x 520 FLOP
+        # 8 TB/s.  The narrow phase is bound by FP64 vector issue (SURVEY 8d, DESIGN 5.6): inclusion checks x 520 FLOP
         # (the survey's per-check figure: 8 corners x 57 + min/max/tests) / device time against the 78.6 TFLOP/s FP64
         # vector peak; its HBM figure (220 B per query) is kept beside it as `hbm`.
         n_boxes = len(V0) + len(F) + len(E)
@@ -458,7 +458,7 @@ def main():
                         "algorithmic_bytes_per_launch": units[dom][0] / launches_per_step}
             if dom.startswith("sweep"):
                 roofline["note"] = ("since round 5 the longest kernel of the step is a sweep, not a narrow launch (the projection cull took 95 % of the bisection's work: "
-                                    "DESIGN 5.7).  SURVEY 8d prices a sweep in bytes -- 64 B per sorted box + 8 B per emitted pair -- against HBM; the kernel itself is bound "
+                                    "DESIGN 5.5).  SURVEY 8d prices a sweep in bytes -- 64 B per sorted box + 8 B per emitted pair -- against HBM; the kernel itself is bound "
                                     "by instruction issue (filter, queue and confirm stages per candidate column: DESIGN 5.4), which is why `frac` is low and has been since round 3")
             if prof_apart.get(dom, 0) > 0:
                 a_alone = units[dom][0] / launches_per_step / (prof_apart[dom] / launches_per_step * 1e-3) / 1e9
@@ -476,7 +476,7 @@ def main():
         broad_ms = prof_apart["boxes"] + prof_apart["sort"] + prof_apart["sweep"] + prof_apart.get("sweep_ee", 0.0)
         if dom.startswith("narrow") and prof_apart.get(dom, 0) > 0:
             # `achieved` above is the contract's figure: the launch's own duration in the timed region.  Since round 4's read-back
-            # mailbox the edge-edge launch STARTS ~120 us earlier -- in the SIMD slots its sweep left, beside the
+            # mailbox (profiles/HISTORY.md 5.6) the edge-edge launch STARTS ~120 us earlier -- in the SIMD slots its sweep left, beside the
             # vertex-face kernel, taking over as that kernel's waves retire -- so its duration now holds ~150 us in which it has
             # a fraction of the chip: the step got shorter, the launch longer, `frac` lower.  The same launch with the chip to
             # itself (passes apart, same process, untimed) is the kernel's own figure:
@@ -488,7 +488,7 @@ def main():
                 "executed_frac": round(a_alone * FLOP_PER_CHECK_EXECUTED / FLOP_PER_CHECK / FP64_VALU_PEAK_TFLOPS, 5),
                 "note": "the dominant launch with nothing beside it (SCCD_OPT_PASSES_APART, %d untimed steps in this process); `frac` above "
                         "is the same launch as it runs in the timed steps, where it shares the SIMDs with the vertex-face kernel for "
-                        "its first ~150 us (DESIGN 5.6 / 7)" % n_prof,
+                        "its first ~150 us (DESIGN 5.7)" % n_prof,
             }
         # the slowest rank's device time per phase (passes apart): narrow-phase scaling is readable on its own
         mx = torch.tensor([broad_ms, prof_apart["narrow_vf"] + prof_apart["narrow_ee"] + prof_apart["cull"]], dtype=torch.float64, device=red_dev)

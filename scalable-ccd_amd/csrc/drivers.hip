@@ -603,6 +603,8 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
         c->np_init_pending = false;
         c->np_init_peer = nullptr;
     };
+    // (the edge boxes enqueued AHEAD of the vertex-face build -- the helper's chain 40 us earlier on the device -- were measured in
+    // round 6: 0.794-0.798 against 0.789-0.803 ms, nothing: profiles/r06/ab_edge_boxes_before_the_vertex_face_build.log)
     auto build_ee = [&] {
         SCCD_HIP(hipStreamWaitEvent(sc->stream, c->side_event, 0));
         if (split_boxes) edge_boxes_on(sc, m, pl);

@@ -67,7 +67,7 @@ def test_no_kernel_uses_scratch_memory(tmp_path):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_readback_gather_kernel_fits_beside_narrow_phase_waves(tmp_path):
     # three np_walk_k waves of 168 VGPRs leave 8 of a SIMD lane's 512: the read-back's gather kernel (api.hip) must fit into
-    # those, or a read-back issued beside the narrow phase waits for a wave to retire
+    # those, or a read-back issued beside the narrow phase waits for a wave to retire (profiles/HISTORY.md 5.6)
     ks = {k: v for k, v in _kernels("api", tmp_path).items() if "readback_gather_k" in k}
     # ... and so must the kernel that starts a narrow launch's counters (the helper issues it beside the vertex-face kernel)
     ks.update({k: v for k, v in _kernels("narrow", tmp_path).items() if "np_counters_init_k" in k})
@@ -78,7 +78,7 @@ def test_readback_gather_kernel_fits_beside_narrow_phase_waves(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_edge_records_kernel_fits_beside_the_vertex_face_sweep(tmp_path):
-    # ccd() runs the edge list's records kernel beside the vertex-face sweep (the records gate, DESIGN 5.6): a block of it must fit
+    # ccd() runs the edge list's records kernel beside the vertex-face sweep (the records gate, DESIGN 5.7): a block of it must fit
     # on a CU that holds two sweep waves per SIMD -- 512 registers per SIMD lane minus the sweep's two waves, shared by the block's
     # waves on that SIMD (ER_THREADS / 256); with blocks that do not fit the gate costs 15 us instead of gaining 20
     boxes = _kernels("boxes", tmp_path)
@@ -97,7 +97,7 @@ def test_edge_records_kernel_fits_beside_the_vertex_face_sweep(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_sort_pass_keeps_two_blocks_per_cu(tmp_path):
-    # os_pass_k's tile is ranked by eight waves (DESIGN 5.2); radix_sort_pairs_u32 launches a block per tile, tiles by block index, while
+    # os_pass_k's tile is ranked by eight waves (DESIGN 5.3); radix_sort_pairs_u32 launches a block per tile, tiles by block index, while
     # num_tiles <= 2 blocks per CU (`pass_blocks`) -- which assumes two 512-thread blocks ARE resident per CU: four waves per SIMD
     # (<= 128 registers), <= 80 KB of LDS each
     ks = {k: v for k, v in _kernels("sort", tmp_path).items() if "os_pass_k" in k}

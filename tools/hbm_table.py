@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Achieved HBM GB/s per kernel: PMC bytes per launch (profiles/<tag>_pmc_traffic_<w>.json) over the kernel's
 average duration in the rocprofv3 kernel trace of the same build (profiles/<tag>_<w>_kernel_stats.csv).
-    python tools/hbm_table.py [tag, default r03]      -> a markdown table (DESIGN.md section 7)"""
+    python tools/hbm_table.py [tag, default r03]      -> a markdown table"""
 import csv, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
