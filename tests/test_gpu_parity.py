@@ -1550,9 +1550,13 @@ def test_a_warm_default_step_reads_nothing_back(sccd, orc, scene, halves):
         mesh = sccd.Mesh(V0, V1, E, F, ctx=c)
         for _ in range(3):  # (the first call builds the slow way and allocates; the second meets buffers sized by the first)
             assert sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True) == want
+        # (laboratory switches that make builds wait for their counts, or break every third guess on purpose: results only)
+        counted = os.environ.get("SCCD_SPECULATE") != "0" and not os.environ.get("SCCD_SPEC_BREAK")
         for _ in range(4):
             rb0, w0, sp0 = c.get_option(sccd.OPT_READ_BACKS), c.get_option(sccd.OPT_HOST_WAITS), c.get_option(sccd.OPT_SPEC_MISSES)
             assert sccd.ccd_mesh(mesh, 0.0, -1, 1e-6, True) == want
+            if not counted:
+                continue
             rb, w = c.get_option(sccd.OPT_READ_BACKS) - rb0, c.get_option(sccd.OPT_HOST_WAITS) - w0
             assert c.get_option(sccd.OPT_SPEC_MISSES) == sp0
             second_half = halves == 2 and want >= 0.5  # (both passes start from 1: each runs its second half iff nothing lies before 0.5)
