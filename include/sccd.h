@@ -99,8 +99,8 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        (values travel widened in the same double-typed interfaces); narrow phase on a depth-first
                                        kernel of its own (np_walk_f32_k; check limits on the level-synchronous kernels), bit-equal to the
                                        oracle's float twin on the GPU (tests/test_gpu_parity.py) */
-#define SCCD_OPT_PASSES_APART 13      /* ccd(): 1 = the vertex-face and the edge-edge pass one after the other on one stream (what
-                                       * SCCD_OVERLAP=0 does for the whole process): measurements of the passes' own durations */
+#define SCCD_OPT_PASSES_APART 13      /* ccd(): 1 = the vertex-face and the edge-edge pass one after the other on one stream, the host between
+                                       * them: measurements of the passes' own durations (bench.py --passes-apart) */
 /* id 12 is RETIRED (it was SCCD_OPT_MAX_ITER_FAST in 0.1 with the opposite sense: setting it now fails with SCCD_E_INVALID) */
 #define SCCD_OPT_LIMIT_LEVEL_ORDER 14 /* check limits (max_iter >= 0, root_finder.cu:287-305): 0 (default) the fast kernel runs
                                        * without the limit and the library proves that the limit would not have changed the

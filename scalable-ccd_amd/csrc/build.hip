@@ -104,7 +104,7 @@ static void list_sort(sccd_ctx* c, const sccd_boxes* b, const GridParams* gp, in
         }
     }
 }
-// SCCD_EREC_LATE (drivers.hip, ccd()): the two record kernels of a step -- vertices + faces on the caller's stream, edges on the
+// THE RECORDS GATE (drivers.hip, ccd()): the two record kernels of a step -- vertices + faces on the caller's stream, edges on the
 // helper's -- are bandwidth-bound and side by side each takes twice its time, but only the first is on the way to the first sweep.
 // The helper's kernel is ordered behind the END of the caller's: it then runs beside the vertex-face sweep (instruction issue).
 static void records_gate_signal(sccd_ctx* c)

@@ -192,7 +192,7 @@ struct sccd_ctx {
     hipEvent_t side_event2 = nullptr; // ccd(): "the helper's stream has reached its sweep" (drivers.hip)
     hipEvent_t side_event3 = nullptr; // ccd(): "the helper's sweep and cull are done" (their counters are read through this context's stream)
     // ccd(): the helper's records kernel (edge list) is ordered behind the END of this context's two-list records kernel (vertices +
-    // faces) -- build.hip: records_gate_signal / records_gate_wait; SCCD_EREC_LATE=0 leaves them side by side
+    // faces) -- build.hip: records_gate_signal / records_gate_wait (from a mesh size on: drivers.hip)
     StageGate records_gate;                    // the caller's context owns it
     StageGate* records_gate_signal = nullptr;  // caller's context: its own gate while a ccd() call uses it
     StageGate* records_gate_wait = nullptr;    // helper context: the gate in front of its one-list records kernel
