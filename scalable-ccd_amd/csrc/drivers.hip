@@ -624,15 +624,28 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
         build_ee();
     }
     // The second pass's SWEEP goes into its stream behind the END OF THE LEADING SWEEP (an event between that sweep and its cull:
-    // bp->after_sweep), and the leading walk kernel behind the point where the other stream has passed that wait: a sweep's blocks
-    // (78 KB of LDS each) must be resident before a walk kernel fills every SIMD (round 4: left to a race, the walk kernel sometimes
-    // won and the whole second chain slipped by 100 us).
-    bool b_swept = false;
+    // bp->after_sweep), and the LEADING WALK KERNEL behind the END OF THE SECOND SWEEP (the same way): it then runs beside the second
+    // pass's cull, which lives on gather latency, instead of beside its sweep, which is bound by instruction issue like the walk kernel
+    // itself.  (Rounds 4-5 started the walk kernel as soon as the second sweep's blocks were resident -- side by side, the two took
+    // little longer than the longer one alone, it was thought; measured in round 6, three interleaved rounds of 100 steps: 0.786 /
+    // 0.790 / 0.795 ms per step against 0.805 / 0.801 / 0.811, and 0.822 against 0.841 where the earliest impact comes late;
+    // behind the second pass's CULL as well: no better than before -- profiles/r06/ab_leading_walk_behind_the_other_sweep.log.)
+    bool b_swept = false, b_sweep_event = false;
     auto start_b_sweep = [&] {
         SCCD_HIP(hipEventRecord(c->side_event3, A.ctx->stream));
         SCCD_HIP(hipStreamWaitEvent(B.ctx->stream, c->side_event3, 0));
-        SCCD_HIP(hipEventRecord(c->side_event2, B.ctx->stream));
-        bp_detect_partial(B.bp, 1);
+        if (enqueue_all)
+            B.bp->after_sweep = [&] {
+                SCCD_HIP(hipEventRecord(c->side_event2, B.ctx->stream)); // (the second sweep is complete behind this point)
+                b_sweep_event = true;
+            };
+        try {
+            bp_detect_partial(B.bp, 1);
+        } catch (...) {
+            B.bp->after_sweep = nullptr;
+            throw;
+        }
+        B.bp->after_sweep = nullptr;
         b_swept = true;
     };
     if (!enqueue_all) { // (A is the vertex-face pass on this context, B the edge-edge pass on the helper's)
@@ -695,7 +708,7 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
         narrow_phase_begin(R.ctx, R.p, narrow_counters(R.ctx), &R.toi, nullptr, R.bp->cull.on ? &sw->n_kept : &sw->n_pairs, (long long)R.bp->capacity, &x);
     };
     if (A.launched) {
-        SCCD_HIP(hipStreamWaitEvent(A.ctx->stream, c->side_event2, 0)); // (the second sweep first: above)
+        if (b_sweep_event) SCCD_HIP(hipStreamWaitEvent(A.ctx->stream, c->side_event2, 0)); // (beside the second pass's cull, not its sweep: above)
         begin_walk(A);
     }
     if (B.launched) {
