@@ -629,7 +629,8 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
     // itself.  (Rounds 4-5 started the walk kernel as soon as the second sweep's blocks were resident -- side by side, the two took
     // little longer than the longer one alone, it was thought; measured in round 6, three interleaved rounds of 100 steps: 0.786 /
     // 0.790 / 0.795 ms per step against 0.805 / 0.801 / 0.811, and 0.822 against 0.841 where the earliest impact comes late;
-    // behind the second pass's CULL as well: no better than before -- profiles/r06/ab_leading_walk_behind_the_other_sweep.log.)
+    // behind the second pass's CULL as well -- both walk kernels at once, with full or capped grids: no better than before --
+    // profiles/r06/ab_leading_walk_behind_the_other_sweep.log, ab_both_walk_kernels_at_once.log.)
     bool b_swept = false, b_sweep_event = false;
     auto start_b_sweep = [&] {
         SCCD_HIP(hipEventRecord(c->side_event3, A.ctx->stream));
