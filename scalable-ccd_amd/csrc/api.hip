@@ -149,6 +149,7 @@ void sccd_destroy(sccd_ctx* c)
     if (c->side_event) (void)hipEventDestroy(c->side_event);
     if (c->side_event2) (void)hipEventDestroy(c->side_event2);
     if (c->side_event3) (void)hipEventDestroy(c->side_event3);
+    if (c->side_event4) (void)hipEventDestroy(c->side_event4);
     if (c->records_gate.ev) (void)hipEventDestroy(c->records_gate.ev);
     if (c->side) sccd_destroy(c->side);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

@@ -190,6 +190,7 @@ struct sccd_ctx {
     double np_init_toi = 0;
     const unsigned long long* np_init_peer = nullptr; // ... and leaves this address in the counters' peer_word (NarrowCounters; null: none)
     hipEvent_t side_event2 = nullptr; // ccd(): "the helper's stream has reached its sweep" (drivers.hip)
+    hipEvent_t side_event4 = nullptr; // ccd() with a check limit: "the second pass's stream has reached its sweep" (drivers.hip)
     hipEvent_t side_event3 = nullptr; // ccd(): "the helper's sweep and cull are done" (their counters are read through this context's stream)
     // ccd(): the helper's records kernel (edge list) is ordered behind the END of this context's two-list records kernel (vertices +
     // faces) -- build.hip: records_gate_signal / records_gate_wait (from a mesh size on: drivers.hip)
