@@ -12,7 +12,9 @@ for n in sides:
     V0, V1, E, F = scenes.folded_cloth(n)
     mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
     row = []
-    for cull, halves, hist in ((1, 1, 0), (1, 0, 0), (1, 1, 1), (0, 0, 0)):
+    # (2 = forced, 0 = off: where each starts to pay -- the size rules of drivers.hip apply under 1; SIZE_SWEEP_DEFAULTS=1: 1 / 0 as before)
+    forced = 1 if os.environ.get("SIZE_SWEEP_DEFAULTS") == "1" else 2
+    for cull, halves, hist in ((forced, forced, 0), (forced, 0, 0), (forced, forced, 1), (0, 0, 0)):
         ctx.set_option(sccd.OPT_CULL, cull)
         ctx.set_option(sccd.OPT_TWO_HALVES, halves)
         ctx.set_option(sccd.OPT_TOI_GUESS, hist)
