@@ -115,8 +115,8 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        * redone from 1); 0: always from 1, as ccd.cu:125.  The same history also settles SCCD_OPT_TWO_HALVES' bet. */
 #define SCCD_OPT_TOI_GUESS_HITS 20    /* read: calls whose bound held / broke (redone); setting either resets both */
 #define SCCD_OPT_TOI_GUESS_MISSES 21
-#define SCCD_OPT_CULL 24              /* sccd_ccd / sccd_ccd_mesh / sccd_ccd_mesh_pass / sccd_ipc_ccd_strategy (double build; since 0.4 with or without a
-                                       * check limit -- a culled pair has no acceptable domain under any traversal): 1 (default) the overlap pairs of a pass
+#define SCCD_OPT_CULL 24              /* sccd_ccd / sccd_ccd_mesh / sccd_ccd_mesh_pass / sccd_ccd_collisions / sccd_ipc_ccd_strategy (since 0.4: both scalar
+                                       * builds, with or without a check limit -- a culled pair has no acceptable domain under any traversal): 1 (default) the overlap pairs of a pass
                                        * go through the PROJECTION CULL before the bisection -- a pair is dropped if some direction d puts the eight
                                        * corner values of d . F (F: the collision function, affine in each of t, u, v) all beyond the reach of any
                                        * domain the reference's bisection could accept (csrc/narrow_cull.inc): the result is unchanged, the narrow
@@ -124,7 +124,7 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        * The cull looks at the slab of time the pass's narrow launch asks about ([0, b] for a start from b; the halves
                                        * of SCCD_OPT_TWO_HALVES each have their own).  1 means "where it pays": meshes of 50,000 edges + faces or more (a
                                        * launch per sweep costs a small step more than it saves); 2: always.
-                                       * sccd_narrow_phase and the collision-list / per-query drivers never cull. */
+                                       * sccd_narrow_phase never culls (its pair list is the caller's). */
 #define SCCD_OPT_TWO_HALVES 25        /* 1 (default): a narrow-phase launch of the plain walk kernel (double build, no check limit, no per-query output) that
                                        * starts from a TOI above 0.5 runs as two launches over the halves of time: the first from the bound 0.5; if it
                                        * accepts nothing, the second bisects what lies at or beyond 0.5, from the caller's TOI (csrc/narrow_walk.inc).

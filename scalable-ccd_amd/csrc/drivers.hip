@@ -35,8 +35,8 @@ static void pass_lists(const sccd_broad_phase* bp, NarrowParams* p)
         p->second.t_hi = bp->cull.slabs.t_end;
     }
 }
-// ... and whether a pass of ccd() culls at all: the double build, with or without a check limit (SCCD_OPT_NARROW_ALGO = 1 and the
-// float build keep the reference's own list).  A CHECK LIMIT changes nothing about the cull's claim: a culled query has no domain
+// ... and whether a pass of ccd() culls at all: both scalar builds (round 6: the float build too -- narrow_cull.inc), with or without a
+// check limit (SCCD_OPT_NARROW_ALGO = 1 keeps the reference's own list).  A CHECK LIMIT changes nothing about the cull's claim: a culled query has no domain
 // that passes the inclusion test behind an acceptance (narrow_cull.inc), whatever the order of the traversal and wherever a limit
 // cuts it off; the reference counts a query's checks per query (root_finder.cu:287-305) and prunes by a TOI only accepted domains
 // lower, so a query that accepts nothing changes neither another query's count nor the running TOI -- the limited level-order
@@ -50,7 +50,7 @@ static void pass_cull_setup(sccd_ctx* c, sccd_broad_phase* bp, const sccd_mesh* 
     // (SCCD_OPT_CULL = 1: where it pays -- the cull is a launch per sweep, ~5 us of a small step's latency chain; measured on folded
     // cloths and the cloth-on-ball scenes: a gain from ~20,000 triangles on, a loss of 15 us at 10,000.  2: always)
     const bool big_enough = c->cull_on >= 2 || (long long)m->nE + m->nF >= SCCD_CULL_MIN_ELEMENTS;
-    bp->cull.on = c->cull_on && big_enough && !c->scalar_f32 && c->narrow_algo != 1 && std::isfinite(tol) && tol > 0 && ms >= 0;
+    bp->cull.on = c->cull_on && big_enough && c->narrow_algo != 1 && std::isfinite(tol) && tol > 0 && ms >= 0;
     bp->cull.mesh = m;
     bp->cull.is_vf = vf ? 1 : 0;
     bp->cull.ms = ms;

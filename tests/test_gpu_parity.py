@@ -1737,6 +1737,61 @@ def test_culled_queries_have_no_impact_in_the_oracle(sccd, ctx, orc, case, tol, 
         pytest.skip("the oracle's level-order bisection of the culled pairs outgrows its memory budget at this tolerance and scale")
 
 
+# the float build's cull (round 6): float filter constants, Condition 4 one FLOAT ulp wide, vertices rounded to float first
+_CULL_GRID_F32 = [(1e-6, 1.0), (1e-3, 1.0), (1e-5, 1.0), (1e-4, 1e3)]
+
+
+@pytest.mark.parametrize("tol,scale", _CULL_GRID_F32)
+@pytest.mark.parametrize("case", range(10))
+def test_float_build_cull_changes_no_result_and_drops_no_impact(sccd, orc, case, tol, scale):
+    """SCCD_OPT_SCALAR = 1 with the projection cull forced and off, against the oracle's float twin: the same TOI bit for bit under both
+    zero-TOI policies; and the claim itself -- no pair the cull drops (whole step, and the slabs [0, 0.5] / [0.5, 1]) has an impact
+    in the float twin's per-query output inside the slab."""
+    name, V0, V1, E, F, ms = _scaled(case, scale)
+    c = sccd.Context(0)
+    try:
+        c.set_option(sccd.OPT_TOI_GUESS, 0)
+        c.set_option(sccd.OPT_SCALAR, 1)
+        mesh = sccd.Mesh(V0, V1, E, F, ctx=c)
+        culled_total = 0
+        for allow_zero in (True, False):
+            want = orc.ccd(V0, V1, E, F, ms, -1, tol, allow_zero, nthreads=8, scalar="f32")[0]
+            c.set_option(sccd.OPT_CULL, 2)
+            got, st = sccd.ccd_mesh(mesh, ms, -1, tol, allow_zero, want_stats=True)
+            c.set_option(sccd.OPT_CULL, 0)
+            plain, st0 = sccd.ccd_mesh(mesh, ms, -1, tol, allow_zero, want_stats=True)
+            assert got == want and plain == want, (name, tol, scale, allow_zero, got, plain, want)
+            assert (st["n_vf_pairs"], st["n_ee_pairs"]) == (st0["n_vf_pairs"], st0["n_ee_pairs"]) and st0["n_vf_culled"] + st0["n_ee_culled"] == 0
+            culled_total += st["n_vf_culled"] + st["n_ee_culled"]
+        if name in ("cloth_ball", "folded") and scale == 1.0:
+            assert culled_total > 0, name  # (the float build's cull does remove pairs on ordinary scenes)
+        # pair by pair (float boxes: the float build's broad phase)
+        vb, eb, fb = orc.build_boxes(V0, V1, E, F, ms, scalar="f32")
+        key = lambda p: p[:, 0].astype(np.int64) << 32 | p[:, 1].astype(np.int64)  # noqa: E731
+        for is_vf, pairs in ((True, orc.sort_and_sweep(vb, fb, nthreads=8)[0]), (False, orc.sort_and_sweep(eb, nthreads=8)[0])):
+            pairs = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+            if len(pairs) == 0:
+                continue
+            ka = key(pairs)
+            slabs = ((0.0, 1.0), (0.0, 0.5), (0.5, 1.0))
+            gone = [~np.isin(ka, key(sccd.query_cull_slab(mesh, pairs, is_vf, ms, tol, t_lo, t_hi))) for t_lo, t_hi in slabs]
+            some = np.logical_or.reduce(gone)
+            if not some.any():
+                continue
+            try:
+                with _oracle_budget(orc, 1 << 21):
+                    pq = np.full(len(pairs), np.inf)
+                    pq[some] = orc.narrow_phase(V0, V1, E, F, pairs[some], is_vf, ms=ms, tol=tol, allow_zero_toi=True, per_query=True, scalar="f32")[1]
+            except MemoryError:
+                continue
+            for (t_lo, t_hi), g in zip(slabs, gone):
+                bad = g & (pq >= t_lo) & (pq < t_hi)
+                assert not bad.any(), (name, tol, scale, is_vf, t_lo, t_hi, int(bad.sum()), pq[bad][:4])
+        mesh.close()
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("tol,scale", _CULL_GRID)
 @pytest.mark.parametrize("case", range(10))
 def test_slab_culls_drop_no_query_with_an_impact_in_their_slab(sccd, ctx, orc, case, tol, scale):
