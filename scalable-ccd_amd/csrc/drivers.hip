@@ -177,7 +177,8 @@ __global__ void collisions_compact_k(const int2* __restrict__ pairs, const doubl
         out_idx[at] = i;
     }
 }
-static void copy_out_collisions(sccd_ctx* c, const int2* d_pairs, const double* d_pq, int64_t n, std::vector<sccd_collision>& acc)
+// ordered: the records in the order of the pair list (sccd_narrow_phase: the list is the caller's); else as the blocks reserved their slots
+static void copy_out_collisions(sccd_ctx* c, const int2* d_pairs, const double* d_pq, int64_t n, std::vector<sccd_collision>& acc, bool ordered)
 {
     if (n <= 0) return;
     DevBuf& out = c->col_out;
@@ -196,6 +197,15 @@ static void copy_out_collisions(sccd_ctx* c, const int2* d_pairs, const double* 
         rb.sync();
     }
     if (k == 0) return;
+    if (!ordered) {
+        // (ccd() with the collision list: the queries are what the projection cull kept, in the order ITS blocks appended them --
+        // "query order" means nothing there, and the reference's own order comes from atomics and is unspecified: narrow_phase.cu:84-103.
+        // No second copy, no sort of 64,000 indices on the host: 0.6 ms of the call on the 1M-triangle cloth)
+        const size_t at0 = acc.size();
+        acc.resize(at0 + (size_t)k);
+        SCCD_HIP(hipMemcpy(acc.data() + at0, out.p, sizeof(sccd_collision) * (size_t)k, hipMemcpyDeviceToHost));
+        return;
+    }
     std::vector<sccd_collision> rec((size_t)k);
     std::vector<long long> at((size_t)k);
     SCCD_HIP(hipMemcpy(rec.data(), out.p, sizeof(sccd_collision) * (size_t)k, hipMemcpyDeviceToHost));
@@ -249,7 +259,7 @@ extern "C" int sccd_narrow_phase(sccd_ctx* c, const sccd_mesh* m, const int32_t*
         run_narrow(c, m, d_pairs, n, is_vf, max_iter, tol, ms, allow_zero_toi, toi, d_pq);
         if (collisions && n > 0) {
             std::vector<sccd_collision> acc;
-            copy_out_collisions(c, d_pairs, d_pq, n, acc);
+            copy_out_collisions(c, d_pairs, d_pq, n, acc, /*ordered=*/true);
             *collisions = collisions_to_c(acc);
             if (n_collisions) *n_collisions = (int64_t)acc.size();
         }
@@ -919,7 +929,7 @@ static void ccd_pass_collisions(sccd_ctx* c, const sccd_mesh* m, Pipeline* pl, b
         if (n > 0) pq.ensure(sizeof(double) * (size_t)n);
         run_narrow(c, m, pass_pairs(&pl->bp), n, vf ? 1 : 0, max_iter, tol, ms, allow_zero_toi, toi,
                    n > 0 ? pq.as<double>() : nullptr);
-        copy_out_collisions(c, pass_pairs(&pl->bp), pq.as<double>(), n, acc);
+        copy_out_collisions(c, pass_pairs(&pl->bp), pq.as<double>(), n, acc, /*ordered=*/false);
     }
 }
 
