@@ -560,13 +560,13 @@ static void ccd_on_mesh_from(sccd_ctx* c, const sccd_mesh* m, double ms, int max
     sc->sweep_blocks_per_cu = 0;
     const NarrowParams pv0 = narrow_params(c, m, nullptr, 0, 1, max_iter, tol, ms, allow_zero_toi);
     const NarrowParams pe0 = narrow_params(sc, m, nullptr, 0, 0, max_iter, tol, ms, allow_zero_toi);
-    // (chunked sweeps, the float build, level order -- SCCD_OPT_NARROW_ALGO = 1, check limits below 4,096 or under
-    // SCCD_OPT_LIMIT_LEVEL_ORDER -- and diagnostics keep the passes in sequence, with the host between them)
+    // (chunked sweeps, level order -- SCCD_OPT_NARROW_ALGO = 1, check limits below 4,096, under SCCD_OPT_LIMIT_LEVEL_ORDER or in the
+    // float build -- and diagnostics keep the passes in sequence, with the host between them)
     // A CHECK LIMIT the fast kernel serves (narrow.hip, the certificate: the kernel runs WITHOUT the limit, the host proves afterwards
     // that the limit could not have changed the answer) goes the same way since round 6 -- each pass on a running TOI of ITS OWN (the
     // proof is about the pass's own earliest accept: no shared word, no peer), both from the TOI the call started with; the
     // edge-edge pass's proof then starts from the vertex-face pass's result, as the reference's second pass does (end_pass below).
-    const bool enqueue_all = c->max_overlap_cutoff == 0 && !c->scalar_f32 && narrow_uses_walk_kernel(c, pv0, false)
+    const bool enqueue_all = c->max_overlap_cutoff == 0 && narrow_uses_walk_kernel(c, pv0, false)
         && narrow_uses_walk_kernel(sc, pe0, false) && lab_env().np_diag == 0 && c->verdict_dev && sc->verdict_dev;
     // WHICH PASS GOES FIRST.  The second sweep waits for the first (two sweeps at once gain nothing: both are bound by instruction issue),
     // so the step's critical path is one pass's whole chain plus the other pass's tail -- and the edge-edge tail is the long one (5.1 M

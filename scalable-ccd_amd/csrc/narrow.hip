@@ -439,8 +439,15 @@ __global__ __launch_bounds__(256) void np_walk_f32_k(const double* __restrict__ 
                                                      const int2* __restrict__ pairs, long long n, float ms, float tol, bool use_ms,
                                                      bool allow_zero_toi, NarrowCounters* __restrict__ cnt,
                                                      unsigned long long* __restrict__ per_query, int* __restrict__ ovf_list,
-                                                     unsigned ovf_cap, unsigned long long* __restrict__ toi_word)
+                                                     unsigned ovf_cap, unsigned long long* __restrict__ toi_word,
+                                                     const unsigned long long* __restrict__ d_n)
 {
+    // d_n (may be null): the list's length is read HERE -- min(*d_n, n), n carrying the buffer's capacity: the launch was enqueued
+    // before the host knew it (ccd(): right behind the pass's sweep and cull, like np_walk_k)
+    if (d_n) {
+        const long long n_dev = (long long)__hip_atomic_load(d_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n_dev < n) n = n_dev;
+    }
     const long long stride = (long long)gridDim.x * blockDim.x;
     long long next = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     TIQueryF q;
@@ -737,18 +744,21 @@ static void run_dfs_f64(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
 }
 
 // ovf_list / ovf_cap: where queries beyond level NF_MAX_LEVEL are listed (always given: narrow_phase_end redoes them in level order)
+// d_n / capacity: the list's length on the device (np_walk_f32_k); vx: the pass's verdict behind the launch (np_verdict_k), as run_walk
 static void run_walk_f32(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cnt, long long n, unsigned long long* per_query,
-                         int* ovf_list, unsigned ovf_cap)
+                         int* ovf_list, unsigned ovf_cap, const unsigned long long* d_n = nullptr, long long capacity = 0,
+                         const VerdictExtras* vx = nullptr)
 {
+    if (d_n) n = std::min<long long>(capacity, (1ll << 31) - 4097); // (the kernel takes min(*d_n, n))
     SCCD_REQUIRE(n < (1ll << 31) - 4096, "narrow phase: at most 2^31 - 4097 queries per launch");
     // (lane-per-query streams: enough waves to fill the chip several times over -- a wave is as slow as its slowest lane)
-    const long long want_blocks = (n + 255) / 256;
+    const long long want_blocks = d_n ? (long long)c->num_cus * 16 : (n + 255) / 256;
     const int blocks = (int)std::max<long long>(1, std::min<long long>(want_blocks, (long long)c->num_cus * 16));
     const dim3 grid((unsigned)blocks), block(256);
     unsigned long long* const tw = p.toi_word ? p.toi_word : &d_cnt->toi_bits;
 #define SCCD_LAUNCH_NF(VF_, AR_, PQ_)                                                                                               \
     hipLaunchKernelGGL((np_walk_f32_k<VF_, AR_, PQ_>), grid, block, 0, c->stream, p.V, p.E, p.F, p.pairs, n, (float)p.ms, (float)p.tol, \
-                       p.ms > 0, (bool)p.allow_zero_toi, d_cnt, per_query, ovf_list, ovf_cap, tw)
+                       p.ms > 0, (bool)p.allow_zero_toi, d_cnt, per_query, ovf_list, ovf_cap, tw, d_n)
 #define SCCD_LAUNCH_NF2(VF_, AR_)                  \
     do {                                           \
         if (per_query) SCCD_LAUNCH_NF(VF_, AR_, true); \
@@ -764,6 +774,13 @@ static void run_walk_f32(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_c
 #undef SCCD_LAUNCH_NF2
 #undef SCCD_LAUNCH_NF
     SCCD_HIP(hipGetLastError());
+    if (vx && c->verdict_dev && !per_query && lab_env().np_diag == 0) { // (the pass's verdict in pinned memory: run_walk)
+        c->verdict_seq += 1;
+        c->verdict_armed = true;
+        hipLaunchKernelGGL(np_verdict_k, dim3(1), dim3(64), 0, c->stream, d_cnt, tw, 0ull, (unsigned long long*)nullptr,
+                           reinterpret_cast<unsigned*>(c->verdict_dev), c->verdict_seq, 0, *vx);
+        SCCD_HIP(hipGetLastError());
+    }
 }
 
 // counters = {toi, zeros}: a kernel whose arguments carry the TOI.  (It was an upload from the pinned mirror: a copy kernel that
@@ -855,11 +872,15 @@ void narrow_phase_begin(sccd_ctx* c, const NarrowParams& p, NarrowCounters* d_cn
     const bool run = (*h_toi_inout > 0) || d_per_query_toi != nullptr;
     const long long n = p.n_pairs;
     if (d_n) {
-        SCCD_REQUIRE(!d_per_query_toi && !c->scalar_f32 && narrow_uses_walk_kernel(c, p, false),
-                     "narrow_phase: a list whose length is on the device is served by the plain walk kernel only");
+        SCCD_REQUIRE(!d_per_query_toi && narrow_uses_walk_kernel(c, p, false),
+                     "narrow_phase: a list whose length is on the device is served by the plain walk kernels only");
         if (run) {
             ProfScope ps(c, p.is_vf ? SCCD_PROF_NARROW_VF : SCCD_PROF_NARROW_EE);
-            if (p.max_iter >= 0) { // a check limit: the fast kernel WITHOUT it, recording who lowered the TOI (below; narrow_phase_end: the certificate)
+            if (c->scalar_f32) { // (no limit: narrow_uses_walk_kernel) the float build's depth-first kernel; it lists what it cannot hold
+                const unsigned cap = (unsigned)std::min<long long>(std::max<long long>(capacity, 1), 1 << 20);
+                c->np_scratch3_ovf.ensure(sizeof(int) * (size_t)cap);
+                run_walk_f32(c, p, d_cnt, 0, nullptr, c->np_scratch3_ovf.as<int>(), cap, d_n, capacity, vx);
+            } else if (p.max_iter >= 0) { // a check limit: the fast kernel WITHOUT it, recording who lowered the TOI (below; narrow_phase_end: the certificate)
                 const unsigned cap = 1u << 20; // (the list's length is not known here: room for the most records a certificate looks at)
                 c->np_scratch3_ovf.ensure(sizeof(int) * 4 * (size_t)cap + 256);
                 NarrowParams pn = p;
