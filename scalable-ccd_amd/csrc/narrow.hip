@@ -142,70 +142,114 @@ __global__ void np_level_snap_k(const LvlDomain* __restrict__ cur, long long n_c
     snap[q] = s;
 }
 
+// One thread per live domain of the level.  The two counters every thread adds to -- the next level's length (a RETURNING atomic:
+// the children's place) and the checks made -- are one word each: the compiler folds a wave's adds into one atomic, and a level of a
+// million domains was still 16,000 returning atomics on one word, ~200 us of a 360 us launch (the word serves ~75 per us).  The
+// block adds once: a scan of the children over its four waves, one atomic per counter per block.  (The ORDER of the next level's
+// domains comes from atomics either way and decides nothing: LvlSnap.)  __launch_bounds__: without it the kernel is compiled for
+// 1,024 threads and its 56 bytes of dynamically indexed private arrays, which the compiler keeps in LDS, take 57 KB per block -- two
+// blocks of 256 per CU; with it 14 KB, and the registers decide (five waves per SIMD).
+constexpr int NP_LEVEL_TPB = 256;
 template <bool VF, int ARITH, bool F32>
-__global__ void np_level_k(const LvlDomain* __restrict__ cur, long long n_cur, LvlDomain* __restrict__ nxt,
+__global__ __launch_bounds__(NP_LEVEL_TPB) void np_level_k(const LvlDomain* __restrict__ cur, long long n_cur, LvlDomain* __restrict__ nxt,
                            unsigned long long* __restrict__ n_nxt, LvlData* __restrict__ data, double ms,
                            double tol, int max_iter, bool allow_zero_toi, bool per_query,
-                           NarrowCounters* __restrict__ cnt, const LvlSnap* __restrict__ snap)
+                           NarrowCounters* __restrict__ cnt, const LvlSnap* __restrict__ snap,
+                           unsigned long long* __restrict__ n_after)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_cur) return;
-    const LvlDomain dom = cur[i];
-    LvlData* dp = data + dom.query_id;
-    TIQuery q;
+    if (i == 0) *n_after = 0ull; // (the NEXT level's counter -- the one this level's launch was sized from: run_level_sync)
+    unsigned nk = 0;
+    bool checked = false;
+    LvlDomain dom {};
+    int split = 0;
+    double mid = 0.0;
+    if (i < n_cur) {
+        dom = cur[i];
+        LvlData* dp = data + dom.query_id;
+        const int before = snap ? snap[dom.query_id].nbr_checks : dp->nbr_checks; // data_in copy, root_finder.cu:287-288
+        atomicAdd(&dp->nbr_checks, 1);                                            // :289
+        const double prune = snap
+            ? __longlong_as_double((long long)(per_query ? snap[dom.query_id].toi_bits : cnt->toi_level))
+            : (per_query ? toi_load(&dp->toi_bits) : toi_load(&cnt->toi_bits));
+        if (!(dom.lo[0] >= prune)                           // :295
+            && !(max_iter >= 0 && before > max_iter)) {     // :303
+            TIQuery q;
 #pragma unroll
-    for (int a = 0; a < 8; a++)
+            for (int a = 0; a < 8; a++)
 #pragma unroll
-        for (int k = 0; k < 3; k++) q.v[a][k] = dp->v[a][k];
+                for (int k = 0; k < 3; k++) q.v[a][k] = dp->v[a][k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        q.err[k] = dp->err[k];
-        q.tol[k] = dp->tol[k];
-    }
-    const int before = snap ? snap[dom.query_id].nbr_checks : dp->nbr_checks; // data_in copy, root_finder.cu:287-288
-    atomicAdd(&dp->nbr_checks, 1);                                            // :289
-    const double prune = snap
-        ? __longlong_as_double((long long)(per_query ? snap[dom.query_id].toi_bits : cnt->toi_level))
-        : (per_query ? toi_load(&dp->toi_bits) : toi_load(&cnt->toi_bits));
-    if (dom.lo[0] >= prune) return;                       // :295
-    if (max_iter >= 0 && before > max_iter) return;       // :303
-    TIStep s;
-    if (F32) { // (every stored value is a float: the casts are exact)
-        TIQueryF qf;
+            for (int k = 0; k < 3; k++) {
+                q.err[k] = dp->err[k];
+                q.tol[k] = dp->tol[k];
+            }
+            TIStep s;
+            if (F32) { // (every stored value is a float: the casts are exact)
+                TIQueryF qf;
 #pragma unroll
-        for (int a = 0; a < 8; a++)
+                for (int a = 0; a < 8; a++)
 #pragma unroll
-            for (int k = 0; k < 3; k++) qf.v[a][k] = (float)q.v[a][k];
-        float lo[3], hi[3];
+                    for (int k = 0; k < 3; k++) qf.v[a][k] = (float)q.v[a][k];
+                float lo[3], hi[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            qf.err[k] = (float)q.err[k];
-            qf.tol[k] = (float)q.tol[k];
-            lo[k] = (float)dom.lo[k];
-            hi[k] = (float)dom.hi[k];
+                for (int k = 0; k < 3; k++) {
+                    qf.err[k] = (float)q.err[k];
+                    qf.tol[k] = (float)q.tol[k];
+                    lo[k] = (float)dom.lo[k];
+                    hi[k] = (float)dom.hi[k];
+                }
+                const TIStepF sf = tif_step<VF, ARITH>(qf, lo, hi, (float)ms, (float)tol, allow_zero_toi, (float)prune);
+                s.accept = sf.accept;
+                s.nk = sf.nk;
+                s.split = sf.split;
+                s.mid = sf.mid;
+                s.checked = sf.checked;
+            } else {
+                s = ti_step<VF, ARITH>(q, dom.lo, dom.hi, ms, tol, allow_zero_toi, prune);
+            }
+            checked = s.checked;
+            if (s.accept) {
+                toi_min(&cnt->toi_bits, dom.lo[0]);
+                toi_min(&dp->toi_bits, dom.lo[0]);
+            }
+            nk = (unsigned)s.nk;
+            split = s.split;
+            mid = s.mid;
         }
-        const TIStepF sf = tif_step<VF, ARITH>(qf, lo, hi, (float)ms, (float)tol, allow_zero_toi, (float)prune);
-        s.accept = sf.accept;
-        s.nk = sf.nk;
-        s.split = sf.split;
-        s.mid = sf.mid;
-        s.checked = sf.checked;
-    } else {
-        s = ti_step<VF, ARITH>(q, dom.lo, dom.hi, ms, tol, allow_zero_toi, prune);
     }
-    if (s.checked) atomicAdd(&cnt->n_checks, 1ull);
-    if (s.accept) {
-        toi_min(&cnt->toi_bits, dom.lo[0]);
-        toi_min(&dp->toi_bits, dom.lo[0]);
+    // the block's children and checks: one atomic each
+    __shared__ unsigned s_kids[NP_LEVEL_TPB / 64], s_chk[NP_LEVEL_TPB / 64];
+    __shared__ unsigned long long s_base;
+    const int w = (int)(threadIdx.x >> 6);
+    unsigned wave_kids;
+    const unsigned incl = wave_incl_scan_dpp(nk, &wave_kids);
+    const unsigned wave_chk = (unsigned)popc64(__ballot(checked));
+    if (lane_id() == 0) {
+        s_kids[w] = wave_kids;
+        s_chk[w] = wave_chk;
     }
-    if (s.nk > 0) {
-        const unsigned long long at = atomicAdd(n_nxt, (unsigned long long)s.nk);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned kids = 0, chk = 0;
+        for (int k = 0; k < NP_LEVEL_TPB / 64; k++) {
+            const unsigned v = s_kids[k];
+            s_kids[k] = kids; // (-> the wave's offset in the block's range)
+            kids += v;
+            chk += s_chk[k];
+        }
+        s_base = kids ? atomicAdd(n_nxt, (unsigned long long)kids) : 0ull;
+        if (chk) atomicAdd(&cnt->n_checks, (unsigned long long)chk);
+    }
+    __syncthreads();
+    if (nk > 0) {
+        const unsigned long long at = s_base + (unsigned long long)(s_kids[w] + incl - nk);
         LvlDomain c = dom;
-        c.hi[s.split] = s.mid;
+        c.hi[split] = mid;
         nxt[at] = c;
-        if (s.nk == 2) {
+        if (nk == 2) {
             c = dom;
-            c.lo[s.split] = s.mid;
+            c.lo[split] = mid;
             nxt[at + 1] = c;
         }
     }
@@ -237,9 +281,12 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
     const long long n = d_sel ? n_sel : n_all; // queries to run; data[] / snap[] stay indexed by the query's own number
     c->np_scratch0.ensure(sizeof(LvlData) * (size_t)n_all);
     LvlData* data = c->np_scratch0.as<LvlData>();
-    c->tmp0.ensure(sizeof(unsigned long long));
-    unsigned long long* d_n = c->tmp0.as<unsigned long long>();
-    const int TPB = 256;
+    // (two counters of live domains, used in turn: a level's kernel counts the next level's into one and clears the other, and the
+    // host reads the count through the mailbox (ReadBack: a publishing kernel and a polled word, ~8 us) -- a memset, a copy into
+    // pageable memory and a blocking wait per level were most of a culled call's level-order time)
+    c->tmp0.ensure(2 * sizeof(unsigned long long));
+    unsigned long long* const d_n2 = c->tmp0.as<unsigned long long>();
+    const int TPB = NP_LEVEL_TPB;
     // Level order keeps every live domain of a level in HBM, and a contact-rich scene doubles them
     // level after level.  The queries are therefore taken in slices (the reference batches too,
     // narrow_phase.cu:141-200): a slice whose level would not fit the budget is started again at
@@ -271,6 +318,8 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
         DevBuf* cur = &c->np_scratch1;
         DevBuf* nxt = &c->np_scratch2;
         bool fits = true;
+        SCCD_HIP(hipMemsetAsync(d_n2, 0, 2 * sizeof(unsigned long long), c->stream));
+        unsigned level = 0;
         while (n_cur > 0) { // root_finder.cu:431-447
             if (sizeof(LvlDomain) * (size_t)(2 * n_cur) > budget) {
                 // (a single contact-rich query can have ~(1/tolerance)^2 live domains in level order: no
@@ -291,13 +340,15 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
                 break;
             }
             nxt->ensure(sizeof(LvlDomain) * (size_t)(2 * n_cur));
-            SCCD_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream));
+            unsigned long long* const d_n = d_n2 + (level & 1u);
+            unsigned long long* const d_n_after = d_n2 + ((level + 1u) & 1u);
+            level += 1;
             const dim3 grid((unsigned)((n_cur + TPB - 1) / TPB));
             if (snap) hipLaunchKernelGGL(np_level_snap_k, grid, dim3(TPB), 0, c->stream, cur->as<LvlDomain>(), n_cur, data, snap, d_cnt);
 #define SCCD_LAUNCH_LEVEL(AR_, F32_)                                                                                   \
     hipLaunchKernelGGL((np_level_k<VF, AR_, F32_>), grid, dim3(TPB), 0, c->stream, cur->as<LvlDomain>(), n_cur,          \
                        nxt->as<LvlDomain>(), d_n, data, p.ms, p.tol, p.max_iter, (bool)p.allow_zero_toi,                 \
-                       d_per_query_toi != nullptr, d_cnt, snap)
+                       d_per_query_toi != nullptr, d_cnt, snap, d_n_after)
             if (c->scalar_f32) {
                 if (p.arith == 1) SCCD_LAUNCH_LEVEL(1, true);
                 else SCCD_LAUNCH_LEVEL(0, true);
@@ -308,8 +359,11 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
 #undef SCCD_LAUNCH_LEVEL
             SCCD_HIP(hipGetLastError());
             unsigned long long h_n = 0;
-            SCCD_HIP(hipMemcpyAsync(&h_n, d_n, sizeof h_n, hipMemcpyDeviceToHost, c->stream));
-            SCCD_HIP(hipStreamSynchronize(c->stream));
+            {
+                ReadBack rb(c);
+                rb.add(&h_n, d_n, sizeof h_n);
+                rb.sync();
+            }
             n_cur = (long long)h_n;
             std::swap(cur, nxt);
         }
