@@ -34,7 +34,7 @@ for d in sorted(glob.glob("gpurun_out/pmcsq_*/")):
     agg=collections.defaultdict(lambda:[0.0,0])
     for r in csv.DictReader(open(fs[-1])):
         nm=r["Kernel_Name"]
-        if not any(k in nm for k in ("np_walk_k", "np_cull_k", "sweep_band", "os_pass_k", "entry_record", "cell_fill_append")): continue
+        if not any(k in nm for k in ("np_walk_k", "np_cull_k", "sweep_band", "os_pass_k", "entry_record", "cell_fill_append", "np_level_k")): continue
         nm=nm.replace("(anonymous namespace)::","").split("(")[0].replace("void ","")
         agg[(nm,r["Counter_Name"])][0]+=float(r["Counter_Value"]); agg[(nm,r["Counter_Name"])][1]+=1
     for (k,c),(v,n) in agg.items(): out[k][c]=v/n
