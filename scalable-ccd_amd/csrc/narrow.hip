@@ -42,13 +42,25 @@ __device__ __forceinline__ void toi_min(unsigned long long* p, double v)
 
 // ------------------------------------------------------------------------------------------
 // algo 1: level-synchronous BFS (reference scheme)
-struct LvlData { // CCDData (ccd_data.cuh:8-26) minus ms
-    double v[8][3];
-    double err[3];
-    double tol[3];
-    unsigned long long toi_bits; // per-query toi (TOI_PER_QUERY)
-    int nbr_checks;
-    int pad;
+// CCDData (ccd_data.cuh:8-26) minus ms, one ARRAY per field (f[k * n + q]: the 24 vertex coordinates, err, tol): the threads of a
+// level are ordered by query, roughly, and a thread reads all 30 values of its query -- as 256-byte records a wave's sixteen loads
+// each touched 64 cache lines, the same 64, and twenty waves of that per CU do not fit its L1: every load went to the L2 again (a level
+// of two million domains: 670 us).  As arrays a load touches the few lines its wave's queries share.
+struct LvlData {
+    double* f;                    // [30][n]
+    unsigned long long* toi_bits; // [n] per-query toi (TOI_PER_QUERY)
+    int* nbr_checks;              // [n]
+    long long n;
+    static size_t bytes(long long n) { return (size_t)n * (30 * 8 + 8 + 4) + 64; }
+    static LvlData carve(void* base, long long n)
+    {
+        LvlData d;
+        d.f = static_cast<double*>(base);
+        d.toi_bits = reinterpret_cast<unsigned long long*>(d.f + 30 * n);
+        d.nbr_checks = reinterpret_cast<int*>(d.toi_bits + n);
+        d.n = n;
+        return d;
+    }
 };
 struct LvlDomain { // CCDDomain (interval.cuh:30-44)
     double lo[3], hi[3];
@@ -61,7 +73,7 @@ struct LvlDomain { // CCDDomain (interval.cuh:30-44)
 template <bool VF, bool F32>
 __global__ void np_level_init_k(const double* __restrict__ V, const int2* __restrict__ E, const int4* __restrict__ F,
                                 const int2* __restrict__ pairs, long long first, long long n, double tol, bool use_ms,
-                                LvlData* __restrict__ data, LvlDomain* __restrict__ dom, const int* __restrict__ sel)
+                                LvlData data, LvlDomain* __restrict__ dom, const int* __restrict__ sel)
 {
     // queries [first, first + n) of the call (of the selection `sel`, if given): data[] is indexed by query, dom[] by
     // position in the slice
@@ -91,20 +103,17 @@ __global__ void np_level_init_k(const double* __restrict__ V, const int2* __rest
         ti_tolerance<VF>(q.v, tol, q.tol);
         ti_error<VF>(q.v, use_ms, q.err);
     }
-    LvlData d;
 #pragma unroll
     for (int a = 0; a < 8; a++)
 #pragma unroll
-        for (int k = 0; k < 3; k++) d.v[a][k] = q.v[a][k];
+        for (int k = 0; k < 3; k++) data.f[(long long)(a * 3 + k) * data.n + i] = q.v[a][k];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        d.err[k] = q.err[k];
-        d.tol[k] = q.tol[k];
+        data.f[(long long)(24 + k) * data.n + i] = q.err[k];
+        data.f[(long long)(27 + k) * data.n + i] = q.tol[k];
     }
-    d.toi_bits = 0x7FF0000000000000ull; // +inf (narrow_phase.cu:70)
-    d.nbr_checks = 0;
-    d.pad = 0;
-    data[i] = d;
+    data.toi_bits[i] = 0x7FF0000000000000ull; // +inf (narrow_phase.cu:70)
+    data.nbr_checks[i] = 0;
     LvlDomain r;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -128,7 +137,7 @@ struct LvlSnap {
     int nbr_checks;
     int pad;
 };
-__global__ void np_level_snap_k(const LvlDomain* __restrict__ cur, long long n_cur, const LvlData* __restrict__ data,
+__global__ void np_level_snap_k(const LvlDomain* __restrict__ cur, long long n_cur, LvlData data,
                                 LvlSnap* __restrict__ snap, NarrowCounters* __restrict__ cnt)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -136,8 +145,8 @@ __global__ void np_level_snap_k(const LvlDomain* __restrict__ cur, long long n_c
     if (i >= n_cur) return;
     const int q = cur[i].query_id; // (several domains of one query store the same values)
     LvlSnap s;
-    s.toi_bits = data[q].toi_bits;
-    s.nbr_checks = data[q].nbr_checks;
+    s.toi_bits = data.toi_bits[q];
+    s.nbr_checks = data.nbr_checks[q];
     s.pad = 0;
     snap[q] = s;
 }
@@ -149,10 +158,13 @@ __global__ void np_level_snap_k(const LvlDomain* __restrict__ cur, long long n_c
 // domains comes from atomics either way and decides nothing: LvlSnap.)  __launch_bounds__: without it the kernel is compiled for
 // 1,024 threads and its 56 bytes of dynamically indexed private arrays, which the compiler keeps in LDS, take 57 KB per block -- two
 // blocks of 256 per CU; with it 14 KB, and the registers decide (five waves per SIMD).
-constexpr int NP_LEVEL_TPB = 256;
+#ifndef NP_LEVEL_TPB_
+#define NP_LEVEL_TPB_ 1024
+#endif
+constexpr int NP_LEVEL_TPB = NP_LEVEL_TPB_;
 template <bool VF, int ARITH, bool F32>
 __global__ __launch_bounds__(NP_LEVEL_TPB) void np_level_k(const LvlDomain* __restrict__ cur, long long n_cur, LvlDomain* __restrict__ nxt,
-                           unsigned long long* __restrict__ n_nxt, LvlData* __restrict__ data, double ms,
+                           unsigned long long* __restrict__ n_nxt, LvlData data, double ms,
                            double tol, int max_iter, bool allow_zero_toi, bool per_query,
                            NarrowCounters* __restrict__ cnt, const LvlSnap* __restrict__ snap,
                            unsigned long long* __restrict__ n_after)
@@ -166,23 +178,23 @@ __global__ __launch_bounds__(NP_LEVEL_TPB) void np_level_k(const LvlDomain* __re
     double mid = 0.0;
     if (i < n_cur) {
         dom = cur[i];
-        LvlData* dp = data + dom.query_id;
-        const int before = snap ? snap[dom.query_id].nbr_checks : dp->nbr_checks; // data_in copy, root_finder.cu:287-288
-        atomicAdd(&dp->nbr_checks, 1);                                            // :289
+        const long long qi = dom.query_id;
+        const int before = snap ? snap[qi].nbr_checks : data.nbr_checks[qi]; // data_in copy, root_finder.cu:287-288
+        atomicAdd(&data.nbr_checks[qi], 1);                                  // :289
         const double prune = snap
-            ? __longlong_as_double((long long)(per_query ? snap[dom.query_id].toi_bits : cnt->toi_level))
-            : (per_query ? toi_load(&dp->toi_bits) : toi_load(&cnt->toi_bits));
+            ? __longlong_as_double((long long)(per_query ? snap[qi].toi_bits : cnt->toi_level))
+            : (per_query ? toi_load(&data.toi_bits[qi]) : toi_load(&cnt->toi_bits));
         if (!(dom.lo[0] >= prune)                           // :295
             && !(max_iter >= 0 && before > max_iter)) {     // :303
             TIQuery q;
 #pragma unroll
             for (int a = 0; a < 8; a++)
 #pragma unroll
-                for (int k = 0; k < 3; k++) q.v[a][k] = dp->v[a][k];
+                for (int k = 0; k < 3; k++) q.v[a][k] = data.f[(long long)(a * 3 + k) * data.n + qi];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                q.err[k] = dp->err[k];
-                q.tol[k] = dp->tol[k];
+                q.err[k] = data.f[(long long)(24 + k) * data.n + qi];
+                q.tol[k] = data.f[(long long)(27 + k) * data.n + qi];
             }
             TIStep s;
             if (F32) { // (every stored value is a float: the casts are exact)
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(NP_LEVEL_TPB) void np_level_k(const LvlDomain* __re
             checked = s.checked;
             if (s.accept) {
                 toi_min(&cnt->toi_bits, dom.lo[0]);
-                toi_min(&dp->toi_bits, dom.lo[0]);
+                toi_min(&data.toi_bits[qi], dom.lo[0]);
             }
             nk = (unsigned)s.nk;
             split = s.split;
@@ -261,14 +273,14 @@ __global__ void np_fill_u64_k(unsigned long long* __restrict__ p, long long n, u
     if (i < n) p[i] = v;
 }
 
-__global__ void np_copy_per_query_k(const LvlData* __restrict__ data, long long n, double* __restrict__ out,
+__global__ void np_copy_per_query_k(LvlData data, long long n, double* __restrict__ out,
                                     const int* __restrict__ sel)
 {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    if (!sel) out[j] = __longlong_as_double((long long)data[j].toi_bits);
+    if (!sel) out[j] = __longlong_as_double((long long)data.toi_bits[j]);
     else // a selection redone in level order: fold into what the work-queue kernel had found for the query
-        atomicMin(reinterpret_cast<unsigned long long*>(out) + sel[j], data[sel[j]].toi_bits);
+        atomicMin(reinterpret_cast<unsigned long long*>(out) + sel[j], data.toi_bits[sel[j]]);
 }
 
 // d_sel / n_sel: only those queries of the call (np_walk_k's overflow list), else all n_all
@@ -279,8 +291,8 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
 {
     const bool use_ms = p.ms > 0; // narrow_phase.cu:128
     const long long n = d_sel ? n_sel : n_all; // queries to run; data[] / snap[] stay indexed by the query's own number
-    c->np_scratch0.ensure(sizeof(LvlData) * (size_t)n_all);
-    LvlData* data = c->np_scratch0.as<LvlData>();
+    c->np_scratch0.ensure(LvlData::bytes(n_all));
+    const LvlData data = LvlData::carve(c->np_scratch0.p, n_all);
     // (two counters of live domains, used in turn: a level's kernel counts the next level's into one and clears the other, and the
     // host reads the count through the mailbox (ReadBack: a publishing kernel and a polled word, ~8 us) -- a memset, a copy into
     // pageable memory and a blocking wait per level were most of a culled call's level-order time)
