@@ -45,6 +45,12 @@ def test_walk_kernels_keep_three_waves_per_simd_without_scratch(tmp_path):
     for name, r in cull.items():
         assert r["private_segment_fixed_size"] == 0 and r["next_free_vgpr"] <= 168, (name, r)
         assert r["group_segment_fixed_size"] <= 48 * 1024, (name, r)  # three four-wave blocks per CU
+    # the level-order kernel: blocks of 1,024 threads (one atomic per block on the next level's length: narrow.hip) -- 128 registers at
+    # most, no scratch, and its dynamically indexed private arrays (kept in LDS by the compiler, 56 bytes per thread) inside a block's 64 KB
+    level = {k: v for k, v in ks.items() if "np_level_kIL" in k}
+    assert len(level) == 8  # VF / EE x strict / fused x double / float build
+    for name, r in level.items():
+        assert r["private_segment_fixed_size"] == 0 and r["next_free_vgpr"] <= 128 and r["group_segment_fixed_size"] <= 64 * 1024, (name, r)
     # the bookkeeping kernels (two waves per SIMD) must not spill either
     book = {k: v for k, v in ks.items() if re.match(r"_Z9np_walk_kILb[01]ELi[01]ELi1EE", k)}
     for name, r in book.items():
