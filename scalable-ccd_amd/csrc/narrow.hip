@@ -137,11 +137,13 @@ struct LvlSnap {
     int nbr_checks;
     int pad;
 };
+// d_n_cur (may be null): the level's length is still on the device (the second level of a pair: run_level_sync) -- min(*d_n_cur, n_cur)
 __global__ void np_level_snap_k(const LvlDomain* __restrict__ cur, long long n_cur, LvlData data,
-                                LvlSnap* __restrict__ snap, NarrowCounters* __restrict__ cnt)
+                                LvlSnap* __restrict__ snap, NarrowCounters* __restrict__ cnt, const unsigned long long* __restrict__ d_n_cur)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) cnt->toi_level = cnt->toi_bits;
+    if (d_n_cur) n_cur = min(n_cur, (long long)*d_n_cur);
     if (i >= n_cur) return;
     const int q = cur[i].query_id; // (several domains of one query store the same values)
     LvlSnap s;
@@ -167,10 +169,11 @@ __global__ __launch_bounds__(NP_LEVEL_TPB) void np_level_k(const LvlDomain* __re
                            unsigned long long* __restrict__ n_nxt, LvlData data, double ms,
                            double tol, int max_iter, bool allow_zero_toi, bool per_query,
                            NarrowCounters* __restrict__ cnt, const LvlSnap* __restrict__ snap,
-                           unsigned long long* __restrict__ n_after)
+                           unsigned long long* __restrict__ n_after, const unsigned long long* __restrict__ d_n_cur)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *n_after = 0ull; // (the NEXT level's counter -- the one this level's launch was sized from: run_level_sync)
+    if (i == 0) *n_after = 0ull; // (a counter no level reads any more: it will count the level after the next -- run_level_sync)
+    if (d_n_cur) n_cur = min(n_cur, (long long)*d_n_cur); // (np_level_snap_k)
     unsigned nk = 0;
     bool checked = false;
     LvlDomain dom {};
@@ -293,11 +296,13 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
     const long long n = d_sel ? n_sel : n_all; // queries to run; data[] / snap[] stay indexed by the query's own number
     c->np_scratch0.ensure(LvlData::bytes(n_all));
     const LvlData data = LvlData::carve(c->np_scratch0.p, n_all);
-    // (two counters of live domains, used in turn: a level's kernel counts the next level's into one and clears the other, and the
-    // host reads the count through the mailbox (ReadBack: a publishing kernel and a polled word, ~8 us) -- a memset, a copy into
-    // pageable memory and a blocking wait per level were most of a culled call's level-order time)
-    c->tmp0.ensure(2 * sizeof(unsigned long long));
-    unsigned long long* const d_n2 = c->tmp0.as<unsigned long long>();
+    // (three counters of live domains, used in turn: a level's kernel counts the next level's into one and clears the one after, and
+    // the host reads a count through the mailbox (ReadBack: a publishing kernel and a polled word, ~8 us) -- a memset, a copy into
+    // pageable memory and a blocking wait per level were most of a culled call's level-order time.  LEVELS GO IN PAIRS where memory
+    // allows: the second is launched for twice the first one's length -- all it can be -- and takes the real length from the counter
+    // the first one left: one round trip to the host per two levels, three buffers of domains in turn)
+    c->tmp0.ensure(3 * sizeof(unsigned long long));
+    unsigned long long* const d_n3 = c->tmp0.as<unsigned long long>();
     const int TPB = NP_LEVEL_TPB;
     // Level order keeps every live domain of a level in HBM, and a contact-rich scene doubles them
     // level after level.  The queries are therefore taken in slices (the reference batches too,
@@ -310,7 +315,7 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
     // (SCCD_LEVEL_BUDGET_MB: a smaller budget per level buffer, for soak runs on shared test machines)
     const size_t budget_cap = lab_env().level_budget_mb > 0 ? std::max<size_t>(64, (size_t)lab_env().level_budget_mb) << 20 : (size_t)8 << 30;
     const size_t budget = std::min<size_t>(budget_cap,
-                                           std::max<size_t>((free_b + c->np_scratch1.cap + c->np_scratch2.cap) / 3, (size_t)64 << 20));
+                                           std::max<size_t>((free_b + c->np_scratch1.cap + c->np_scratch2.cap + c->np_scratch5.cap) / 4, (size_t)64 << 20));
     LvlSnap* snap = nullptr; // (a check limit: level-snapshot serialisation, see LvlSnap)
     if (p.max_iter >= 0) {
         c->np_scratch4.ensure(sizeof(LvlSnap) * (size_t)n_all);
@@ -327,11 +332,33 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
             hipLaunchKernelGGL((np_level_init_k<VF, false>), dim3((unsigned)((len + TPB - 1) / TPB)), dim3(TPB), 0, c->stream,
                                p.V, p.E, p.F, p.pairs, q0, len, p.tol, use_ms, data, c->np_scratch1.as<LvlDomain>(), d_sel);
         long long n_cur = len;
-        DevBuf* cur = &c->np_scratch1;
-        DevBuf* nxt = &c->np_scratch2;
+        DevBuf* const bufs[3] = { &c->np_scratch1, &c->np_scratch2, &c->np_scratch5 };
+        unsigned at = 0; // bufs[at] holds the level's domains
         bool fits = true;
-        SCCD_HIP(hipMemsetAsync(d_n2, 0, 2 * sizeof(unsigned long long), c->stream));
+        SCCD_HIP(hipMemsetAsync(d_n3, 0, 3 * sizeof(unsigned long long), c->stream));
         unsigned level = 0;
+        // one level: n_bound live domains at most (d_len: the real number, if it is still on the device), from `from` into `to`
+        auto launch_level = [&](const DevBuf* from, long long n_bound, const unsigned long long* d_len, DevBuf* to) {
+            unsigned long long* const d_n = d_n3 + level % 3u;
+            unsigned long long* const d_n_after = d_n3 + (level + 1u) % 3u;
+            level += 1;
+            const dim3 grid((unsigned)((n_bound + TPB - 1) / TPB));
+            if (snap) hipLaunchKernelGGL(np_level_snap_k, grid, dim3(TPB), 0, c->stream, from->as<LvlDomain>(), n_bound, data, snap, d_cnt, d_len);
+#define SCCD_LAUNCH_LEVEL(AR_, F32_)                                                                                   \
+    hipLaunchKernelGGL((np_level_k<VF, AR_, F32_>), grid, dim3(TPB), 0, c->stream, from->as<LvlDomain>(), n_bound,       \
+                       to->as<LvlDomain>(), d_n, data, p.ms, p.tol, p.max_iter, (bool)p.allow_zero_toi,                  \
+                       d_per_query_toi != nullptr, d_cnt, snap, d_n_after, d_len)
+            if (c->scalar_f32) {
+                if (p.arith == 1) SCCD_LAUNCH_LEVEL(1, true);
+                else SCCD_LAUNCH_LEVEL(0, true);
+            } else {
+                if (p.arith == 1) SCCD_LAUNCH_LEVEL(1, false);
+                else SCCD_LAUNCH_LEVEL(0, false);
+            }
+#undef SCCD_LAUNCH_LEVEL
+            SCCD_HIP(hipGetLastError());
+            return d_n; // (where the next level's length will be)
+        };
         while (n_cur > 0) { // root_finder.cu:431-447
             if (sizeof(LvlDomain) * (size_t)(2 * n_cur) > budget) {
                 // (a single contact-rich query can have ~(1/tolerance)^2 live domains in level order: no
@@ -351,33 +378,22 @@ template <bool VF> void run_level_sync(sccd_ctx* c, const NarrowParams& p, Narro
                 fits = false;
                 break;
             }
+            DevBuf* const cur = bufs[at];
+            DevBuf* const nxt = bufs[(at + 1u) % 3u];
+            DevBuf* const nx2 = bufs[(at + 2u) % 3u];
+            const bool pair = sizeof(LvlDomain) * (size_t)(4 * n_cur) <= budget; // (the level behind this one at its largest)
             nxt->ensure(sizeof(LvlDomain) * (size_t)(2 * n_cur));
-            unsigned long long* const d_n = d_n2 + (level & 1u);
-            unsigned long long* const d_n_after = d_n2 + ((level + 1u) & 1u);
-            level += 1;
-            const dim3 grid((unsigned)((n_cur + TPB - 1) / TPB));
-            if (snap) hipLaunchKernelGGL(np_level_snap_k, grid, dim3(TPB), 0, c->stream, cur->as<LvlDomain>(), n_cur, data, snap, d_cnt);
-#define SCCD_LAUNCH_LEVEL(AR_, F32_)                                                                                   \
-    hipLaunchKernelGGL((np_level_k<VF, AR_, F32_>), grid, dim3(TPB), 0, c->stream, cur->as<LvlDomain>(), n_cur,          \
-                       nxt->as<LvlDomain>(), d_n, data, p.ms, p.tol, p.max_iter, (bool)p.allow_zero_toi,                 \
-                       d_per_query_toi != nullptr, d_cnt, snap, d_n_after)
-            if (c->scalar_f32) {
-                if (p.arith == 1) SCCD_LAUNCH_LEVEL(1, true);
-                else SCCD_LAUNCH_LEVEL(0, true);
-            } else {
-                if (p.arith == 1) SCCD_LAUNCH_LEVEL(1, false);
-                else SCCD_LAUNCH_LEVEL(0, false);
-            }
-#undef SCCD_LAUNCH_LEVEL
-            SCCD_HIP(hipGetLastError());
+            if (pair) nx2->ensure(sizeof(LvlDomain) * (size_t)(4 * n_cur));
+            const unsigned long long* d_len = launch_level(cur, n_cur, nullptr, nxt);
+            if (pair) d_len = launch_level(nxt, 2 * n_cur, d_len, nx2);
             unsigned long long h_n = 0;
             {
                 ReadBack rb(c);
-                rb.add(&h_n, d_n, sizeof h_n);
+                rb.add(&h_n, d_len, sizeof h_n);
                 rb.sync();
             }
             n_cur = (long long)h_n;
-            std::swap(cur, nxt);
+            at = (at + (pair ? 2u : 1u)) % 3u;
         }
         if (!fits) {
             slice = std::max<long long>(4096, len / 8);
