@@ -1,10 +1,10 @@
 # HBM traffic of one bench workload's kernels from the TCC counters, in separate passes as
 # MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass).
-W=${1:-cloth1m}
+W=${1:-cloth1m}; shift   # (further arguments go to bench.py, e.g. --max-iter 100)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$C
-  timeout 600 rocprofv3 --pmc $C -d gpurun_out/pmc_$C --output-format csv -- python3 bench.py --workload $W --steps 2 --warmup 1 --clock-warmup 0 --no-cpu-baseline > gpurun_out/pmc_$C.log 2>&1
+  timeout 600 rocprofv3 --pmc $C -d gpurun_out/pmc_$C --output-format csv -- python3 bench.py --workload $W --steps 2 --warmup 1 --clock-warmup 0 --no-cpu-baseline "$@" > gpurun_out/pmc_$C.log 2>&1
 done
 python3 - <<PY
 import csv,glob,collections,json
