@@ -124,7 +124,8 @@ int sccd_selftest_lds_gather(sccd_ctx* ctx, int n_waves, int n_active, int64_t* 
                                        * The cull looks at the slab of time the pass's narrow launch asks about ([0, b] for a start from b; the halves
                                        * of SCCD_OPT_TWO_HALVES each have their own).  1 means "where it pays": meshes of 50,000 edges + faces or more (a
                                        * launch per sweep costs a small step more than it saves); 2: always.
-                                       * sccd_narrow_phase never culls (its pair list is the caller's). */
+                                       * sccd_narrow_phase culls a caller's list of 100,000 pairs or more (2: any list) when no collision
+                                       * records are asked for (their order is the list's): the same TOI, a fraction of the bisection. */
 #define SCCD_OPT_TWO_HALVES 25        /* 1 (default): a narrow-phase launch of the plain walk kernel (double build, no check limit, no per-query output) that
                                        * starts from a TOI above 0.5 runs as two launches over the halves of time: the first from the bound 0.5; if it
                                        * accepts nothing, the second bisects what lies at or beyond 0.5, from the caller's TOI (csrc/narrow_walk.inc).
@@ -232,7 +233,8 @@ void sccd_free(void* host_ptr);
 
 /* pairs: n rows int32[2]; is_vf: (vertex, face) else (edge, edge).  *toi is in/out and must be
  * >= 0 (narrow_phase.cu:126).  collisions (may be NULL) receives a malloc'ed list of the
- * queries with toi < 1 as in SCALABLE_CCD_TOI_PER_QUERY builds. */
+ * queries with toi < 1 as in SCALABLE_CCD_TOI_PER_QUERY builds.  Without `collisions` the list goes through the projection
+ * cull first (SCCD_OPT_CULL): the result is that of the whole list. */
 int sccd_narrow_phase(sccd_ctx* ctx, const sccd_mesh* mesh, const int32_t* pairs, int64_t n,
                       int pairs_on_device, int is_vf, int max_iter, double tol, double ms,
                       int allow_zero_toi, double* toi, sccd_collision** collisions,

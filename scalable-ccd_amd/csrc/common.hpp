@@ -254,6 +254,7 @@ struct sccd_ctx {
     long long read_backs = 0;               // SCCD_OPT_READ_BACKS: ReadBack::sync calls (a launch + a polled word each) since the context was made
     long long host_waits = 0;               // SCCD_OPT_HOST_WAITS: read-backs and early verdicts the host has waited for since the context was made (its helper counts its own)
     DevBuf np_scratch0, np_scratch1, np_scratch2, np_scratch3, np_scratch4, np_scratch3_ovf, np_scratch5;
+    DevBuf np_cull_list; // sccd_narrow_phase: what the projection cull keeps of a caller's pair list (+ its two counters)
     DevBuf tmp0, tmp1, tmp2;
     struct sccd_mesh* scratch_mesh = nullptr; // the mesh behind the host-matrix drivers (api.hip: scratch_mesh_from_host)
     void* pipeline = nullptr; // cached pipeline objects (api.hip)

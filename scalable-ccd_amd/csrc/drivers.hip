@@ -256,6 +256,38 @@ extern "C" int sccd_narrow_phase(sccd_ctx* c, const sccd_mesh* m, const int32_t*
             pq.ensure(sizeof(double) * (size_t)n);
             d_pq = pq.as<double>();
         }
+        // THE PROJECTION CULL in front of a caller's list as well (round 6; narrow_cull.inc): a pair it drops has no domain the
+        // bisection could accept in [0, toi] -- with or without a check limit (pass_cull_setup) -- so the kept list returns what the
+        // whole list returns.  Not with the per-query records (their order is the caller's list's), not for SCCD_OPT_NARROW_ALGO = 1
+        // (the reference's own traversal of the reference's own list), from a list length on (SCCD_OPT_CULL = 2: always).
+        const bool cull = !collisions && c->cull_on && c->narrow_algo != 1 && n > 0 && *toi > 0 && std::isfinite(tol) && tol > 0 && ms >= 0
+            && std::isfinite(ms) && (c->cull_on >= 2 || n >= SCCD_CULL_MIN_PAIRS);
+        if (cull) {
+            c->np_cull_list.ensure(sizeof(int2) * (size_t)n + 64);
+            int2* const kept = c->np_cull_list.as<int2>();
+            unsigned long long* const d_cnt = reinterpret_cast<unsigned long long*>(c->np_cull_list.as<char>() + ((sizeof(int2) * (size_t)n + 15) & ~(size_t)15));
+            const unsigned long long h_cnt[2] = { (unsigned long long)n, 0ull }; // {pairs in, pairs kept}
+            copy_in(c, d_cnt, h_cnt, sizeof h_cnt, 0);
+            NarrowParams p {};
+            p.V = m->V.as<double>();
+            p.E = m->E.as<int2>();
+            p.F = m->F.as<int4>();
+            p.pairs = d_pairs;
+            p.is_vf = is_vf;
+            p.ms = ms;
+            p.tol = tol;
+            {
+                ProfScope ps(c, SCCD_PROF_CULL);
+                narrow_cull_launch(c, p, d_cnt, (long long)n, kept, d_cnt + 1, 0.0, std::min(*toi, 1.0));
+            }
+            unsigned long long k = 0;
+            ReadBack rb(c);
+            rb.add(&k, d_cnt + 1, sizeof k);
+            rb.sync();
+            SCCD_REQUIRE((int64_t)k <= n, "narrow_phase: the cull kept more than it was given");
+            d_pairs = kept;
+            n = (int64_t)k;
+        }
         run_narrow(c, m, d_pairs, n, is_vf, max_iter, tol, ms, allow_zero_toi, toi, d_pq);
         if (collisions && n > 0) {
             std::vector<sccd_collision> acc;

@@ -76,6 +76,7 @@ constexpr size_t SCCD_LIST_PAD = 64; // entries allocated past the last one: the
 // ccd() on small meshes: the sizes (edges + faces) from which the projection cull and the two halves of time are used under their
 // default settings (drivers.hip: pass_cull_setup, ccd_on_mesh)
 constexpr long long SCCD_CULL_MIN_ELEMENTS = 50000, SCCD_TWO_HALVES_MIN_ELEMENTS = 600000;
+constexpr long long SCCD_CULL_MIN_PAIRS = 100000; // sccd_narrow_phase on a caller's list: the cull is a launch and a read-back, ~15 us
 // ... and the size from which the edge list's records kernel is ordered behind the end of the vertex + face one (drivers.hip, the
 // records gate): below it the cross-queue wait costs the 5-10 us a step gains above it (cloths of 100 k - 200 k triangles: +2 %)
 constexpr long long SCCD_RECORDS_GATE_MIN_ELEMENTS = 600000;

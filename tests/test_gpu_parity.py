@@ -427,6 +427,33 @@ def test_toi_matches_oracle(sccd, ctx, orc, name, arith, algo):
     assert got_vf == want_vf and got_ee == want_ee  # bit-equal under the same arithmetic contract
 
 
+@pytest.mark.parametrize("name", ["cloth_ball_small", "soup_400", "cloth_ball_10k"])
+@pytest.mark.parametrize("max_iter", [-1, 5000, 50])
+@pytest.mark.parametrize("tol", [1e-6, 1e-9])
+def test_narrow_phase_on_a_callers_list_with_the_cull_in_front(sccd, ctx, orc, name, max_iter, tol):
+    # sccd_narrow_phase culls the caller's list first (from 100,000 pairs on; forced here): the same TOI as the whole list gives in the
+    # oracle, with and without a check limit, from 1 and from a bound the first pass found, with a minimum separation
+    V0, V1, E, F = _scene(name)
+    vb, eb, fb = orc.build_boxes(V0, V1, E, F)
+    vf, _, _ = orc.sort_and_sweep(vb, fb, nthreads=8)
+    ee, _, _ = orc.sort_and_sweep(eb, nthreads=8)
+    mesh = sccd.Mesh(V0, V1, E, F, ctx=ctx)
+    ctx.set_option(sccd.OPT_CULL, 2)
+    try:
+        for ms in ((0.0, 1e-3) if tol == 1e-6 else (0.0,)): # (a minimum separation at 1e-9, unlimited: half a minute of oracle)
+            if max_iter < 0: # (no limit: the order of the traversal decides nothing -- the threaded depth-first oracle)
+                want_vf = orc.narrow_phase_mt(V0, V1, E, F, vf, True, ms, max_iter, tol, True, nthreads=8)[0]
+                want_ee = orc.narrow_phase_mt(V0, V1, E, F, ee, False, ms, max_iter, tol, True, toi=want_vf, nthreads=8)[0]
+            else:
+                want_vf = orc.narrow_phase(V0, V1, E, F, vf, True, ms, max_iter, tol, True)[0]
+                want_ee = orc.narrow_phase(V0, V1, E, F, ee, False, ms, max_iter, tol, True, toi=want_vf)[0]
+            got_vf = sccd.narrow_phase(mesh, vf, True, max_iter, tol, ms, True)
+            got_ee = sccd.narrow_phase(mesh, ee, False, max_iter, tol, ms, True, toi=got_vf)
+            assert got_vf == want_vf and got_ee == want_ee, (ms, got_vf, want_vf, got_ee, want_ee)
+    finally:
+        ctx.set_option(sccd.OPT_CULL, 1)
+
+
 @pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (1e-6, 0.0), (1e4, -3.7e6), (3.0, 1.0e9)])
 def test_pair_set_under_translation_and_scale(sccd, ctx, orc, scale, offset):
     """The composite key quantises coordinates relative to the scene bounds; tiny scenes, huge
