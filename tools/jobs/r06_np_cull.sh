@@ -17,8 +17,7 @@ for cull in (0, 1):
     for rep in range(3):
         t0 = time.perf_counter(); a = sccd.narrow_phase(mesh, vf, True); t1 = time.perf_counter(); b = sccd.narrow_phase(mesh, ee, False, toi=a); t2 = time.perf_counter()
         print("cull %d: vf %.3f ms, ee %.3f ms (host lists: upload included), toi %r" % (cull, (t1 - t0) * 1e3, (t2 - t1) * 1e3, b))
-    # the lists on the device (what a caller of BroadPhase::detect_overlaps_partial has)
-    pv, nv = bp.detect_overlaps_partial() if False else (None, 0)
+# the lists on the device (what a caller of BroadPhase::detect_overlaps_partial has)
 dv = torch.from_numpy(vf).cuda(); de = torch.from_numpy(ee).cuda(); torch.cuda.synchronize()
 for cull in (0, 1):
     ctx.set_option(sccd.OPT_CULL, cull)
